@@ -1,0 +1,866 @@
+// C ABI implementation (include/amsm.h): contexts, resident committer keys, the MSM pipeline launcher,
+// host-side finalisation.  One context = one GPU + one HIP stream + a grow-only HBM workspace.
+#include "../../include/amsm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <rocprim/rocprim.hpp>
+#include <vector>
+
+#include "fp.h"
+#include "host_field.h"
+#include "launch.h"
+
+using namespace amsm;
+
+namespace {
+
+enum Stage { ST_DIGITS = 0, ST_SORT, ST_BOUNDS, ST_ACCUM_L0, ST_ACCUM_L12, ST_REDUCE, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"digits", "sort", "bounds_scan", "accum_l0", "accum_l1_l2", "bucket_reduce_fold"};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct amsm_ctx {
+  int curve = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int window_override = 0;
+  int K0 = 64;
+  int K1 = 16;
+  int red_s = 4;
+  bool profiling = false;
+  hipEvent_t ev[ST_COUNT + 1] = {};
+  float stage_ms[ST_COUNT] = {};
+  // workspace (grow-only)
+  DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
+      sort_tmp, scan_tmp, scalars;
+  void* h_pinned = nullptr;
+  size_t h_pinned_bytes = 0;
+};
+
+struct amsm_bases {
+  int curve = 0;
+  int device = 0;
+  size_t n = 0;
+  int precomp = 0;
+  int c = 0;  // window bits fixed at creation when precomputed
+  int W = 0;
+  u32* d_table = nullptr;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      fprintf(stderr, "[amsm] HIP error %s (%d) at %s:%d: %s\n", hipGetErrorName(_e), (int)_e, __FILE__, \
+              __LINE__, #expr);                                                                        \
+      return _e == hipErrorOutOfMemory ? AMSM_E_OOM : AMSM_E_HIP;                                      \
+    }                                                                                                  \
+  } while (0)
+
+#define TRY(expr)            \
+  do {                       \
+    int _s = (expr);         \
+    if (_s != AMSM_OK) return _s; \
+  } while (0)
+
+int ensure(DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return AMSM_OK;
+  if (b.p) HIP_TRY(hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  size_t want = bytes + bytes / 8 + 256;
+  HIP_TRY(hipMalloc(&b.p, want));
+  b.bytes = want;
+  return AMSM_OK;
+}
+
+int ensure_pinned(amsm_ctx* ctx, size_t bytes) {
+  if (ctx->h_pinned_bytes >= bytes) return AMSM_OK;
+  if (ctx->h_pinned) HIP_TRY(hipHostFree(ctx->h_pinned));
+  ctx->h_pinned = nullptr;
+  HIP_TRY(hipHostMalloc(&ctx->h_pinned, bytes + 4096, hipHostMallocDefault));
+  ctx->h_pinned_bytes = bytes + 4096;
+  return AMSM_OK;
+}
+
+inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
+inline int ilog2_ceil(size_t n) {
+  int l = 0;
+  while (((size_t)1 << l) < n) l++;
+  return l;
+}
+
+// Window width.  Precomputed key: all windows share one bucket set, aim for a few hundred entries per
+// bucket.  Plain key: one bucket set per window, aim for >= ~128 entries per bucket.
+int choose_window(size_t n, bool precomp) {
+  int lg = ilog2_ceil(n < 2 ? 2 : n);
+  int c = precomp ? lg - 4 : lg - 6;
+  if (c < 4) c = 4;
+  if (c > 20) c = 20;
+  return c;
+}
+inline int windows_for(int c) { return 255 / c + 1; }  // W*c >= 256 (signed digits need one spare bit)
+
+template <class Fq>
+constexpr size_t affine_bytes() {
+  return 2 * Fq::L * 4;
+}
+template <class Fq>
+constexpr size_t xyzz_bytes() {
+  return 4 * Fq::L * 4;
+}
+
+// generator coordinates in Montgomery form (computed from canonical constants at first use)
+template <class Fq>
+std::vector<u32> generator_mont(int curve) {
+  using H = host::HFe<Fq>;
+  H gx = host::h_zero<Fq>(), gy = host::h_zero<Fq>();
+  if (curve == AMSM_PALLAS) {
+    // (-1, 2)
+    H one = host::h_zero<Fq>();
+    one.v[0] = 1;
+    H two = host::h_zero<Fq>();
+    two.v[0] = 2;
+    gx = host::h_neg<Fq>(host::h_to_mont<Fq>(one));
+    gy = host::h_to_mont<Fq>(two);
+  } else {
+    static const u64 X[6] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull,
+                             0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull};
+    static const u64 Y[6] = {0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull,
+                             0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+    for (int i = 0; i < H::N && i < 6; i++) {
+      gx.v[i] = X[i];
+      gy.v[i] = Y[i];
+    }
+    gx = host::h_to_mont<Fq>(gx);
+    gy = host::h_to_mont<Fq>(gy);
+  }
+  std::vector<u32> g(2 * Fq::L);
+  memcpy(g.data(), gx.v, 4 * Fq::L);
+  memcpy(g.data() + Fq::L, gy.v, 4 * Fq::L);
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The MSM pipeline.  Leaves n_sets folded XYZZ records in ctx->fold_out.
+// ---------------------------------------------------------------------------------------------
+struct RunInfo {
+  MsmGeom g;
+};
+
+int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n, MsmGeom* out) {
+  MsmGeom g;
+  memset(&g, 0, sizeof(g));
+  int c, W;
+  if (bases->precomp) {
+    c = bases->c;
+    W = bases->W;
+  } else {
+    c = ctx->window_override ? ctx->window_override : choose_window(n, false);
+    W = windows_for(c);
+  }
+  if (c < 2 || c > 24) return AMSM_E_INVALID_ARG;
+  g.n = (u32)n;
+  g.c = (u32)c;
+  g.W = (u32)W;
+  g.nb = 1u << (c - 1);
+  g.n_sets = bases->precomp ? 1u : (u32)W;
+  g.B = g.n_sets * g.nb;
+  if ((unsigned long long)n * W >= (1ull << 31)) return AMSM_E_UNSUPPORTED;
+  g.E = (u32)(n * W);
+  g.base_off = (u32)base_off;
+  g.table_stride = (u32)bases->n;
+  g.precomp = (u32)bases->precomp;
+  if ((unsigned long long)bases->n * (bases->precomp ? W : 1) >= (1ull << 31)) return AMSM_E_UNSUPPORTED;
+  g.K0 = (u32)ctx->K0;
+  g.K1 = (u32)ctx->K1;
+  g.red_s = std::min<u32>((u32)ctx->red_s, g.nb);
+  g.red_threads = g.nb / g.red_s;
+  *out = g;
+  return AMSM_OK;
+}
+
+void stage_mark(amsm_ctx* ctx, int idx) {
+  if (ctx->profiling) (void)hipEventRecord(ctx->ev[idx], ctx->stream);
+}
+
+template <class Fq, class Fr>
+int msm_pipeline(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
+                 int scalars_mont, MsmGeom* geom_out) {
+  MsmGeom g;
+  TRY(make_geom(ctx, bases, base_off, n, &g));
+  *geom_out = g;
+  hipStream_t st = ctx->stream;
+  const u32 max_items = g.E / g.K0 + g.B + 1;
+  const u32 red_blocks = cdiv(g.red_threads, 256);
+  TRY(ensure(ctx->keys_a, (size_t)g.E * 4));
+  TRY(ensure(ctx->keys_b, (size_t)g.E * 4));
+  TRY(ensure(ctx->vals_a, (size_t)g.E * 4));
+  TRY(ensure(ctx->vals_b, (size_t)g.E * 4));
+  TRY(ensure(ctx->start, (size_t)(g.B + 2) * 4));
+  TRY(ensure(ctx->items, (size_t)(g.B + 2) * 4));
+  TRY(ensure(ctx->item_off, (size_t)(g.B + 2) * 4));
+  TRY(ensure(ctx->partials, (size_t)max_items * xyzz_bytes<Fq>()));
+  TRY(ensure(ctx->buckets, (size_t)g.B * xyzz_bytes<Fq>()));
+  TRY(ensure(ctx->red_out, (size_t)g.n_sets * red_blocks * xyzz_bytes<Fq>()));
+  TRY(ensure(ctx->fold_out, (size_t)g.n_sets * xyzz_bytes<Fq>()));
+  TRY(ensure(ctx->heavy, (size_t)(g.B + 1) * 4));
+  TRY(ensure(ctx->misc, 64));
+  u32* d_err = (u32*)ctx->misc.p;
+  u32* d_heavy_count = d_err + 1;
+
+  u32* keys_a = (u32*)ctx->keys_a.p;
+  u32* keys_b = (u32*)ctx->keys_b.p;
+  u32* vals_a = (u32*)ctx->vals_a.p;
+  u32* vals_b = (u32*)ctx->vals_b.p;
+
+  HIP_TRY(hipMemsetAsync(ctx->misc.p, 0, 64, st));
+  stage_mark(ctx, ST_DIGITS);
+  launch_digits<Fr>(st, (const u32*)d_scalars, scalars_mont, g, keys_a, vals_a, d_err);
+  stage_mark(ctx, ST_SORT);
+  {
+    int bits = 1;
+    while ((1u << bits) <= g.B) bits++;
+    size_t tmp = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)g.E, 0u, (unsigned)bits, st));
+    TRY(ensure(ctx->sort_tmp, tmp));
+    tmp = ctx->sort_tmp.bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)g.E, 0u,
+                                      (unsigned)bits, st));
+  }
+  stage_mark(ctx, ST_BOUNDS);
+  launch_bounds(st, (const u32*)keys_b, g, (u32*)ctx->start.p, (u32*)ctx->items.p);
+  {
+    size_t tmp = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, (u32*)ctx->items.p, (u32*)ctx->item_off.p, 0u, (size_t)(g.B + 1),
+                                    rocprim::plus<u32>(), st));
+    TRY(ensure(ctx->scan_tmp, tmp));
+    tmp = ctx->scan_tmp.bytes;
+    HIP_TRY(rocprim::exclusive_scan(ctx->scan_tmp.p, tmp, (u32*)ctx->items.p, (u32*)ctx->item_off.p, 0u,
+                                    (size_t)(g.B + 1), rocprim::plus<u32>(), st));
+  }
+  stage_mark(ctx, ST_ACCUM_L0);
+  launch_accum_l0<Fq>(st, max_items, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)ctx->start.p,
+                      (const u32*)ctx->item_off.p, g, (u32*)ctx->partials.p);
+  stage_mark(ctx, ST_ACCUM_L12);
+  launch_accum_l1<Fq>(st, (const u32*)ctx->partials.p, (const u32*)ctx->items.p, (const u32*)ctx->item_off.p, g,
+                      (u32*)ctx->buckets.p, d_heavy_count, (u32*)ctx->heavy.p);
+  launch_accum_l2<Fq>(st, (const u32*)ctx->partials.p, (const u32*)ctx->items.p, (const u32*)ctx->item_off.p,
+                      (const u32*)d_heavy_count, (const u32*)ctx->heavy.p, (u32*)ctx->buckets.p);
+  stage_mark(ctx, ST_REDUCE);
+  launch_bucket_reduce<Fq>(st, red_blocks, (const u32*)ctx->buckets.p, g, (u32*)ctx->red_out.p);
+  launch_fold<Fq>(st, g.n_sets, (const u32*)ctx->red_out.p, red_blocks, (u32*)ctx->fold_out.p);
+  stage_mark(ctx, ST_COUNT);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
+}
+
+// D2H of the folded records + error flag, host Horner (plain key) -> one XYZZ on the host.
+template <class Fq>
+int msm_collect(amsm_ctx* ctx, const MsmGeom& g, host::HXYZZ<Fq>* out) {
+  size_t rec = xyzz_bytes<Fq>();
+  TRY(ensure_pinned(ctx, g.n_sets * rec + 64));
+  u32* h = (u32*)ctx->h_pinned;
+  HIP_TRY(hipMemcpyAsync(h, ctx->fold_out.p, g.n_sets * rec, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync((char*)h + g.n_sets * rec, ctx->misc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->profiling) {
+    for (int s = 0; s < ST_COUNT; s++) (void)hipEventElapsedTime(&ctx->stage_ms[s], ctx->ev[s], ctx->ev[s + 1]);
+  }
+  u32 err = *(u32*)((char*)h + g.n_sets * rec);
+  if (err) return AMSM_E_SCALAR_RANGE;
+  host::HXYZZ<Fq> acc = host::hx_from_device<Fq>(h + (size_t)(g.n_sets - 1) * (rec / 4));
+  for (int w = (int)g.n_sets - 2; w >= 0; w--) {
+    for (u32 k = 0; k < g.c; k++) acc = host::hx_dbl<Fq>(acc);
+    acc = host::hx_add<Fq>(acc, host::hx_from_device<Fq>(h + (size_t)w * (rec / 4)));
+  }
+  *out = acc;
+  return AMSM_OK;
+}
+
+template <class Fq, class Fr>
+int msm_device_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
+                    int scalars_mont, host::HXYZZ<Fq>* out) {
+  if (base_off > bases->n) return AMSM_E_INVALID_ARG;
+  n = std::min(n, bases->n - base_off);
+  if (n == 0) {
+    *out = host::hx_inf<Fq>();
+    return AMSM_OK;
+  }
+  MsmGeom g;
+  TRY((msm_pipeline<Fq, Fr>(ctx, bases, base_off, d_scalars, n, scalars_mont, &g)));
+  return msm_collect<Fq>(ctx, g, out);
+}
+
+template <class Fq, class Fr>
+int bases_finish(amsm_ctx* ctx, amsm_bases* b, unsigned flags) {
+  // decide precomputation, then build the table levels on device
+  bool pre;
+  if (flags & AMSM_BASES_PRECOMPUTE) pre = true;
+  else if (flags & AMSM_BASES_NO_PRECOMPUTE) pre = false;
+  else pre = b->n >= 256;
+  if (!pre) return AMSM_OK;
+  int c = ctx->window_override ? ctx->window_override : choose_window(b->n, true);
+  int W = windows_for(c);
+  if ((unsigned long long)b->n * W >= (1ull << 31)) return AMSM_OK;  // stay un-precomputed
+  u32* table = nullptr;
+  hipError_t e = hipMalloc((void**)&table, (size_t)b->n * W * affine_bytes<Fq>());
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return AMSM_OK;  // not enough HBM for W copies: keep the plain key
+  }
+  HIP_TRY(hipMemcpyAsync(table, b->d_table, b->n * affine_bytes<Fq>(), hipMemcpyDeviceToDevice, ctx->stream));
+  for (int w = 1; w < W; w++) {
+    launch_precompute_level<Fq>(ctx->stream, table, (u32)b->n, (u32)w, (u32)c);
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipFree(b->d_table));
+  b->d_table = table;
+  b->precomp = 1;
+  b->c = c;
+  b->W = W;
+  return AMSM_OK;
+}
+
+template <class Fq, class Fr>
+int bases_load_impl(amsm_ctx* ctx, const uint64_t* xy, const uint8_t* is_inf, size_t n, unsigned flags,
+                    amsm_bases** out) {
+  amsm_bases* b = new (std::nothrow) amsm_bases();
+  if (!b) return AMSM_E_OOM;
+  b->curve = ctx->curve;
+  b->device = ctx->device;
+  b->n = n;
+  size_t bytes = std::max<size_t>(n, 1) * affine_bytes<Fq>();
+  hipError_t e = hipMalloc((void**)&b->d_table, bytes);
+  if (e != hipSuccess) {
+    delete b;
+    return AMSM_E_OOM;
+  }
+  int s = AMSM_OK;
+  do {
+    if (n) {
+      if (hipMemcpyAsync(b->d_table, xy, n * affine_bytes<Fq>(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        s = AMSM_E_HIP;
+        break;
+      }
+      if (is_inf) {
+        s = ensure(ctx->scalars, n);
+        if (s) break;
+        if (hipMemcpyAsync(ctx->scalars.p, is_inf, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+          s = AMSM_E_HIP;
+          break;
+        }
+        launch_apply_inf<Fq>(ctx->stream, b->d_table, (const uint8_t*)ctx->scalars.p, (u32)n);
+      }
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        s = AMSM_E_HIP;
+        break;
+      }
+      s = bases_finish<Fq, Fr>(ctx, b, flags);
+    }
+  } while (0);
+  if (s != AMSM_OK) {
+    (void)hipFree(b->d_table);
+    delete b;
+    return s;
+  }
+  *out = b;
+  return AMSM_OK;
+}
+
+template <class Fq, class Fr>
+int bases_generate_impl(amsm_ctx* ctx, uint64_t seed, size_t n, unsigned flags, amsm_bases** out) {
+  amsm_bases* b = new (std::nothrow) amsm_bases();
+  if (!b) return AMSM_E_OOM;
+  b->curve = ctx->curve;
+  b->device = ctx->device;
+  b->n = n;
+  hipError_t e = hipMalloc((void**)&b->d_table, std::max<size_t>(n, 1) * affine_bytes<Fq>());
+  if (e != hipSuccess) {
+    delete b;
+    return AMSM_E_OOM;
+  }
+  int s = AMSM_OK;
+  if (n) {
+    std::vector<u32> gen = generator_mont<Fq>(ctx->curve);
+    launch_generate_bases<Fq>(ctx->stream, b->d_table, seed, (u32)n, gen.data());
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) s = AMSM_E_HIP;
+    if (s == AMSM_OK) s = bases_finish<Fq, Fr>(ctx, b, flags);
+  }
+  if (s != AMSM_OK) {
+    (void)hipFree(b->d_table);
+    delete b;
+    return s;
+  }
+  *out = b;
+  return AMSM_OK;
+}
+
+template <class Fq>
+int bases_read_impl(amsm_ctx* ctx, const amsm_bases* b, size_t off, size_t n, uint64_t* xy, uint8_t* is_inf) {
+  if (off > b->n || n > b->n - off) return AMSM_E_INVALID_ARG;
+  if (!n) return AMSM_OK;
+  HIP_TRY(hipMemcpyAsync(xy, (const char*)b->d_table + off * affine_bytes<Fq>(), n * affine_bytes<Fq>(),
+                         hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (is_inf) {
+    constexpr int N = 2 * Fq::L / 2;
+    for (size_t i = 0; i < n; i++) {
+      u64 o = 0;
+      for (int k = 0; k < N; k++) o |= xy[i * N + k];
+      is_inf[i] = o == 0;
+    }
+  }
+  return AMSM_OK;
+}
+
+template <class Fq>
+void write_affine(const host::HXYZZ<Fq>& p, uint64_t* out_xy, uint8_t* out_is_inf) {
+  uint8_t inf = 0;
+  host::hx_to_affine<Fq>(p, out_xy, &inf);
+  if (out_is_inf) *out_is_inf = inf;
+}
+
+template <class Fq, class Fr>
+int msm_host_scalars(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const uint64_t* scalars, size_t n,
+                     int mont, host::HXYZZ<Fq>* out) {
+  if (base_off > bases->n) return AMSM_E_INVALID_ARG;
+  n = std::min(n, bases->n - base_off);
+  if (n == 0) {
+    *out = host::hx_inf<Fq>();
+    return AMSM_OK;
+  }
+  TRY(ensure(ctx->scalars, n * 32));
+  HIP_TRY(hipMemcpyAsync(ctx->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return msm_device_xyzz<Fq, Fr>(ctx, bases, base_off, ctx->scalars.p, n, mont, out);
+}
+
+template <class Fq, class Fr>
+int pedersen_impl(amsm_ctx* ctx, const amsm_bases* ck, const uint64_t* elems, size_t n, const uint64_t* rand_mont,
+                  const uint64_t* hiding_xy, uint64_t* out_xy, uint8_t* out_inf) {
+  host::HXYZZ<Fq> acc;
+  TRY((msm_host_scalars<Fq, Fr>(ctx, ck, 0, elems, n, 1, &acc)));
+  if (rand_mont && hiding_xy) {
+    host::HFe<Fr> r;
+    memcpy(r.v, rand_mont, 32);
+    r = host::h_from_mont<Fr>(r);
+    host::HXYZZ<Fq> h = host::hx_from_affine<Fq>(hiding_xy, false);
+    acc = host::hx_add<Fq>(acc, host::hx_mul<Fq>(h, r.v));
+  }
+  write_affine<Fq>(acc, out_xy, out_inf);
+  return AMSM_OK;
+}
+
+template <class Fq>
+int partials_combine_impl(amsm_ctx* ctx, const void* d_partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+  size_t rec = xyzz_bytes<Fq>();
+  TRY(ensure_pinned(ctx, count * rec));
+  if (count) {
+    HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_partials, count * rec, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  host::HXYZZ<Fq> acc = host::hx_inf<Fq>();
+  for (size_t i = 0; i < count; i++)
+    acc = host::hx_add<Fq>(acc, host::hx_from_device<Fq>((const u32*)ctx->h_pinned + i * (rec / 4)));
+  write_affine<Fq>(acc, out_xy, out_inf);
+  return AMSM_OK;
+}
+
+// store a host XYZZ as a device record
+template <class Fq>
+int upload_xyzz(amsm_ctx* ctx, const host::HXYZZ<Fq>& p, void* d_out) {
+  size_t rec = xyzz_bytes<Fq>();
+  TRY(ensure_pinned(ctx, rec));
+  u32* h = (u32*)ctx->h_pinned;
+  memcpy(h, p.x.v, rec / 4);
+  memcpy(h + Fq::L, p.y.v, rec / 4);
+  memcpy(h + 2 * Fq::L, p.zz.v, rec / 4);
+  memcpy(h + 3 * Fq::L, p.zzz.v, rec / 4);
+  HIP_TRY(hipMemcpyAsync(d_out, h, rec, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return AMSM_OK;
+}
+
+template <class Fq, class Fr>
+int msm_partial_impl(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n, int mont,
+                     void* d_out) {
+  if (base_off > bases->n) return AMSM_E_INVALID_ARG;
+  n = std::min(n, bases->n - base_off);
+  if (n == 0) return upload_xyzz<Fq>(ctx, host::hx_inf<Fq>(), d_out);
+  MsmGeom g;
+  TRY((msm_pipeline<Fq, Fr>(ctx, bases, base_off, d_scalars, n, mont, &g)));
+  if (g.n_sets == 1) {
+    // single folded record: stays on the device; only the range flag comes back
+    HIP_TRY(hipMemcpyAsync(d_out, ctx->fold_out.p, xyzz_bytes<Fq>(), hipMemcpyDeviceToDevice, ctx->stream));
+    TRY(ensure_pinned(ctx, 64));
+    HIP_TRY(hipMemcpyAsync(ctx->h_pinned, ctx->misc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling)
+      for (int s = 0; s < ST_COUNT; s++) (void)hipEventElapsedTime(&ctx->stage_ms[s], ctx->ev[s], ctx->ev[s + 1]);
+    return *(u32*)ctx->h_pinned ? AMSM_E_SCALAR_RANGE : AMSM_OK;
+  }
+  host::HXYZZ<Fq> acc;
+  TRY(msm_collect<Fq>(ctx, g, &acc));
+  return upload_xyzz<Fq>(ctx, acc, d_out);
+}
+
+template <class Fr>
+int vec_combine_impl(amsm_ctx* ctx, const void* const* d_vecs, const size_t* lens, size_t n_vecs,
+                     const uint64_t* coeffs, const void* d_hiding, size_t hiding_len, void* d_out, size_t n) {
+  if (n_vecs > (size_t)VEC_MAX) return AMSM_E_UNSUPPORTED;
+  if (!n) return AMSM_OK;
+  CombineArgs a;
+  memset(&a, 0, sizeof(a));
+  for (size_t j = 0; j < n_vecs; j++) {
+    a.vec[j] = (const u32*)d_vecs[j];
+    a.len[j] = (u32)(lens ? std::min(lens[j], n) : n);
+    memcpy(a.coeff[j], coeffs + 4 * j, 32);
+  }
+  a.hiding = (const u32*)d_hiding;
+  a.hiding_len = (u32)hiding_len;
+  a.n_vecs = (u32)n_vecs;
+  a.n = (u32)n;
+  launch_vec_combine<Fr>(ctx->stream, a, (u32*)d_out);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
+}
+
+template <class Fr>
+int t_vecs_impl(amsm_ctx* ctx, const void* const* d_a, const size_t* a_lens, const void* const* d_b,
+                const size_t* b_lens, size_t n_in, const uint64_t* mu, size_t n_mu, const void* d_ha, size_t ha_len,
+                const void* d_hb, size_t hb_len, void* const* d_t, size_t len) {
+  if (n_in < 1 || n_in > (size_t)HP_MAX_INPUTS) return AMSM_E_UNSUPPORTED;
+  bool hiding = d_ha != nullptr || d_hb != nullptr;
+  // assert!(num_inputs + hiding <= mu_challenges.len())  (src/hp_as/mod.rs:295)
+  if (n_in + (hiding ? 1 : 0) > n_mu) return AMSM_E_INVALID_ARG;
+  if (!len) return AMSM_OK;
+  TVecArgs a;
+  memset(&a, 0, sizeof(a));
+  for (size_t j = 0; j < n_in; j++) {
+    a.a[j] = (const u32*)d_a[j];
+    a.b[j] = (const u32*)d_b[j];
+    a.a_len[j] = (u32)(a_lens ? std::min(a_lens[j], len) : len);
+    a.b_len[j] = (u32)(b_lens ? std::min(b_lens[j], len) : len);
+  }
+  for (size_t j = 0; j < std::min<size_t>(n_mu, HP_MAX_INPUTS + 1); j++) memcpy(a.mu[j], mu + 4 * j, 32);
+  a.hiding_a = (const u32*)d_ha;
+  a.hiding_b = (const u32*)d_hb;
+  a.hiding_a_len = (u32)ha_len;
+  a.hiding_b_len = (u32)hb_len;
+  for (size_t k = 0; k < 2 * n_in - 1; k++) a.t[k] = (u32*)d_t[k];
+  a.len = (u32)len;
+  launch_hp_t_vecs<Fr>(ctx->stream, a, (int)n_in);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
+}
+
+#define DISPATCH(ctx, CALL_P, CALL_B)                   \
+  ((ctx)->curve == AMSM_PALLAS ? (CALL_P) : (CALL_B))
+
+int bind_device(const amsm_ctx* ctx) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  return AMSM_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// extern "C"
+// =============================================================================================
+extern "C" {
+
+const char* amsm_strerror(int s) {
+  switch (s) {
+    case AMSM_OK: return "ok";
+    case AMSM_E_INVALID_ARG: return "invalid argument";
+    case AMSM_E_OOM: return "out of (device) memory";
+    case AMSM_E_HIP: return "HIP runtime error";
+    case AMSM_E_UNSUPPORTED: return "unsupported size or configuration";
+    case AMSM_E_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
+    case AMSM_E_SCALAR_RANGE: return "scalar out of range (not a canonical into_repr value)";
+    default: return "unknown error";
+  }
+}
+
+int amsm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
+  if (!out) return AMSM_E_INVALID_ARG;
+  *out = nullptr;
+  if (curve != AMSM_PALLAS && curve != AMSM_BLS12_381_G1) return AMSM_E_INVALID_ARG;
+  int ndev = amsm_device_count();
+  if (ndev <= 0) return AMSM_E_NO_DEVICE;
+  if (device_id < 0 || device_id >= ndev) return AMSM_E_INVALID_ARG;
+  HIP_TRY(hipSetDevice(device_id));
+  amsm_ctx* c = new (std::nothrow) amsm_ctx();
+  if (!c) return AMSM_E_OOM;
+  c->curve = curve;
+  c->device = device_id;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return AMSM_E_HIP;
+    }
+    c->own_stream = true;
+  }
+  for (int i = 0; i <= ST_COUNT; i++) {
+    if (hipEventCreate(&c->ev[i]) != hipSuccess) {
+      delete c;
+      return AMSM_E_HIP;
+    }
+  }
+  if (const char* e = getenv("AMSM_K0")) c->K0 = std::max(1, atoi(e));
+  if (const char* e = getenv("AMSM_K1")) c->K1 = std::max(1, atoi(e));
+  if (const char* e = getenv("AMSM_RED_S")) c->red_s = std::max(1, atoi(e));
+  if (const char* e = getenv("AMSM_WINDOW")) c->window_override = atoi(e);
+  *out = c;
+  return AMSM_OK;
+}
+
+void amsm_ctx_destroy(amsm_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf* bufs[] = {&c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->start, &c->items, &c->item_off, &c->partials,
+                    &c->buckets, &c->red_out, &c->fold_out, &c->heavy, &c->misc, &c->sort_tmp, &c->scan_tmp, &c->scalars};
+  for (DevBuf* b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  for (int i = 0; i <= ST_COUNT; i++)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int amsm_ctx_curve(const amsm_ctx* c) { return c ? c->curve : AMSM_E_INVALID_ARG; }
+int amsm_ctx_fq_limbs(const amsm_ctx* c) { return !c ? AMSM_E_INVALID_ARG : (c->curve == AMSM_PALLAS ? 4 : 6); }
+int amsm_ctx_set_window(amsm_ctx* c, int bits) {
+  if (!c || (bits != 0 && (bits < 2 || bits > 24))) return AMSM_E_INVALID_ARG;
+  c->window_override = bits;
+  return AMSM_OK;
+}
+int amsm_ctx_synchronize(amsm_ctx* c) {
+  if (!c) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return AMSM_OK;
+}
+int amsm_ctx_set_profiling(amsm_ctx* c, int on) {
+  if (!c) return AMSM_E_INVALID_ARG;
+  c->profiling = on != 0;
+  return AMSM_OK;
+}
+int amsm_stage_count(void) { return ST_COUNT; }
+const char* amsm_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
+int amsm_ctx_stage_ms(amsm_ctx* c, int s, float* ms) {
+  if (!c || !ms || s < 0 || s >= ST_COUNT) return AMSM_E_INVALID_ARG;
+  *ms = c->stage_ms[s];
+  return AMSM_OK;
+}
+
+int amsm_bases_load(amsm_ctx* c, const uint64_t* xy, const uint8_t* is_inf, size_t n, unsigned flags, amsm_bases** out) {
+  if (!c || !out || (n && !xy)) return AMSM_E_INVALID_ARG;
+  if (n >= (1ull << 31)) return AMSM_E_UNSUPPORTED;
+  TRY(bind_device(c));
+  return DISPATCH(c, (bases_load_impl<PallasFq, PallasFr>(c, xy, is_inf, n, flags, out)),
+                  (bases_load_impl<Bls12381Fq, Bls12381Fr>(c, xy, is_inf, n, flags, out)));
+}
+int amsm_bases_generate(amsm_ctx* c, uint64_t seed, size_t n, unsigned flags, amsm_bases** out) {
+  if (!c || !out) return AMSM_E_INVALID_ARG;
+  if (n >= (1ull << 31)) return AMSM_E_UNSUPPORTED;
+  TRY(bind_device(c));
+  return DISPATCH(c, (bases_generate_impl<PallasFq, PallasFr>(c, seed, n, flags, out)),
+                  (bases_generate_impl<Bls12381Fq, Bls12381Fr>(c, seed, n, flags, out)));
+}
+int amsm_bases_read(amsm_ctx* c, const amsm_bases* b, size_t off, size_t n, uint64_t* xy, uint8_t* is_inf) {
+  if (!c || !b || (n && !xy) || b->curve != c->curve) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c, (bases_read_impl<PallasFq>(c, b, off, n, xy, is_inf)),
+                  (bases_read_impl<Bls12381Fq>(c, b, off, n, xy, is_inf)));
+}
+size_t amsm_bases_len(const amsm_bases* b) { return b ? b->n : 0; }
+int amsm_bases_precomputed(const amsm_bases* b) { return b ? b->precomp : 0; }
+void amsm_bases_free(amsm_bases* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->d_table) (void)hipFree(b->d_table);
+  delete b;
+}
+
+int amsm_msm(amsm_ctx* c, const amsm_bases* b, size_t off, const uint64_t* scalars, size_t n, int mont, uint64_t* out_xy,
+             uint8_t* out_inf) {
+  if (!c || !b || !out_xy || (n && !scalars) || b->curve != c->curve || b->device != c->device) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (c->curve == AMSM_PALLAS) {
+    host::HXYZZ<PallasFq> r;
+    TRY((msm_host_scalars<PallasFq, PallasFr>(c, b, off, scalars, n, mont, &r)));
+    write_affine<PallasFq>(r, out_xy, out_inf);
+  } else {
+    host::HXYZZ<Bls12381Fq> r;
+    TRY((msm_host_scalars<Bls12381Fq, Bls12381Fr>(c, b, off, scalars, n, mont, &r)));
+    write_affine<Bls12381Fq>(r, out_xy, out_inf);
+  }
+  return AMSM_OK;
+}
+
+int amsm_msm_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* d_scalars, size_t n, int mont,
+                    uint64_t* out_xy, uint8_t* out_inf) {
+  if (!c || !b || !out_xy || (n && !d_scalars) || b->curve != c->curve || b->device != c->device)
+    return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (c->curve == AMSM_PALLAS) {
+    host::HXYZZ<PallasFq> r;
+    TRY((msm_device_xyzz<PallasFq, PallasFr>(c, b, off, d_scalars, n, mont, &r)));
+    write_affine<PallasFq>(r, out_xy, out_inf);
+  } else {
+    host::HXYZZ<Bls12381Fq> r;
+    TRY((msm_device_xyzz<Bls12381Fq, Bls12381Fr>(c, b, off, d_scalars, n, mont, &r)));
+    write_affine<Bls12381Fq>(r, out_xy, out_inf);
+  }
+  return AMSM_OK;
+}
+
+int amsm_msm_batch_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* const* d_scalars, size_t n_vecs,
+                          size_t n, int mont, uint64_t* out_xy, uint8_t* out_inf) {
+  if (!c || !b || (n_vecs && (!d_scalars || !out_xy))) return AMSM_E_INVALID_ARG;
+  size_t stride = 2 * (size_t)amsm_ctx_fq_limbs(c);
+  for (size_t v = 0; v < n_vecs; v++)
+    TRY(amsm_msm_device(c, b, off, d_scalars[v], n, mont, out_xy + v * stride, out_inf ? out_inf + v : nullptr));
+  return AMSM_OK;
+}
+
+size_t amsm_partial_bytes(const amsm_ctx* c) {
+  if (!c) return 0;
+  return c->curve == AMSM_PALLAS ? xyzz_bytes<PallasFq>() : xyzz_bytes<Bls12381Fq>();
+}
+
+int amsm_msm_partial_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* d_scalars, size_t n, int mont,
+                            void* d_out) {
+  if (!c || !b || !d_out || (n && !d_scalars) || b->curve != c->curve || b->device != c->device)
+    return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c, (msm_partial_impl<PallasFq, PallasFr>(c, b, off, d_scalars, n, mont, d_out)),
+                  (msm_partial_impl<Bls12381Fq, Bls12381Fr>(c, b, off, d_scalars, n, mont, d_out)));
+}
+
+int amsm_partials_combine(amsm_ctx* c, const void* d_partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+  if (!c || !out_xy || (count && !d_partials)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c, (partials_combine_impl<PallasFq>(c, d_partials, count, out_xy, out_inf)),
+                  (partials_combine_impl<Bls12381Fq>(c, d_partials, count, out_xy, out_inf)));
+}
+
+int amsm_pedersen_commit(amsm_ctx* c, const amsm_bases* ck, const uint64_t* elems, size_t n, const uint64_t* rand_mont,
+                         const uint64_t* hiding_xy, uint64_t* out_xy, uint8_t* out_inf) {
+  if (!c || !ck || !out_xy || (n && !elems) || ck->curve != c->curve || ck->device != c->device)
+    return AMSM_E_INVALID_ARG;
+  if ((rand_mont == nullptr) != (hiding_xy == nullptr)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c, (pedersen_impl<PallasFq, PallasFr>(c, ck, elems, n, rand_mont, hiding_xy, out_xy, out_inf)),
+                  (pedersen_impl<Bls12381Fq, Bls12381Fr>(c, ck, elems, n, rand_mont, hiding_xy, out_xy, out_inf)));
+}
+
+int amsm_dev_alloc(amsm_ctx* c, size_t bytes, void** d_ptr) {
+  if (!c || !d_ptr) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  hipError_t e = hipMalloc(d_ptr, std::max<size_t>(bytes, 16));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return AMSM_E_OOM;
+  }
+  return AMSM_OK;
+}
+int amsm_dev_free(amsm_ctx* c, void* d_ptr) {
+  if (!c) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (d_ptr) HIP_TRY(hipFree(d_ptr));
+  return AMSM_OK;
+}
+int amsm_dev_upload(amsm_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+  if (!c || (bytes && (!d_dst || !h_src))) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (bytes) {
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  return AMSM_OK;
+}
+int amsm_dev_download(amsm_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+  if (!c || (bytes && (!h_dst || !d_src))) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (bytes) {
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  return AMSM_OK;
+}
+
+int amsm_vec_random(amsm_ctx* c, uint64_t seed, size_t n, int mont, void* d_out) {
+  if (!c || (n && !d_out) || n >= (1ull << 32)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (!n) return AMSM_OK;
+  if (c->curve == AMSM_PALLAS)
+    launch_vec_random<PallasFr>(c->stream, (u32*)d_out, seed, (u32)n, mont);
+  else
+    launch_vec_random<Bls12381Fr>(c->stream, (u32*)d_out, seed, (u32)n, mont);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
+}
+
+int amsm_vec_hadamard(amsm_ctx* c, const void* d_a, const void* d_b, void* d_out, size_t n) {
+  if (!c || (n && (!d_a || !d_b || !d_out)) || n >= (1ull << 32)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (!n) return AMSM_OK;
+  if (c->curve == AMSM_PALLAS)
+    launch_vec_hadamard<PallasFr>(c->stream, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, (u32)n);
+  else
+    launch_vec_hadamard<Bls12381Fr>(c->stream, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, (u32)n);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
+}
+
+int amsm_vec_combine(amsm_ctx* c, const void* const* d_vecs, const size_t* lens, size_t n_vecs, const uint64_t* coeffs,
+                     const void* d_hiding, size_t hiding_len, void* d_out, size_t n) {
+  if (!c || (n && !d_out) || (n_vecs && (!d_vecs || !coeffs)) || n >= (1ull << 32)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c, (vec_combine_impl<PallasFr>(c, d_vecs, lens, n_vecs, coeffs, d_hiding, hiding_len, d_out, n)),
+                  (vec_combine_impl<Bls12381Fr>(c, d_vecs, lens, n_vecs, coeffs, d_hiding, hiding_len, d_out, n)));
+}
+
+int amsm_hp_t_vecs(amsm_ctx* c, const void* const* d_a, const size_t* a_lens, const void* const* d_b,
+                   const size_t* b_lens, size_t n_inputs, const uint64_t* mu_mont, size_t n_mu, const void* d_hiding_a,
+                   size_t hiding_a_len, const void* d_hiding_b, size_t hiding_b_len, void* const* d_t, size_t len) {
+  if (!c || !d_a || !d_b || !mu_mont || !d_t || len >= (1ull << 32)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c,
+                  (t_vecs_impl<PallasFr>(c, d_a, a_lens, d_b, b_lens, n_inputs, mu_mont, n_mu, d_hiding_a, hiding_a_len,
+                                         d_hiding_b, hiding_b_len, d_t, len)),
+                  (t_vecs_impl<Bls12381Fr>(c, d_a, a_lens, d_b, b_lens, n_inputs, mu_mont, n_mu, d_hiding_a,
+                                           hiding_a_len, d_hiding_b, hiding_b_len, d_t, len)));
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+// Host-side (x86-64, u64 limbs, unsigned __int128) field + curve arithmetic used by the C ABI for the
+// O(1)-sized work that stays on the host by design: folding the handful of per-block / per-window
+// partial sums the GPU hands back, the final projective -> affine normalisation (what the reference
+// does with `.into_affine()` / `batch_normalization_into_affine`, src/hp_as/mod.rs:468) and the single
+// scalar-mul of a hiding term ("stay on host").
+// This is product code, independent of oracle/ (which is test infrastructure).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "fp.h"
+
+namespace amsm {
+namespace host {
+
+typedef unsigned __int128 u128;
+
+template <class P>
+struct HFe {
+  static constexpr int N = P::L / 2;
+  u64 v[N];
+};
+
+template <class P>
+constexpr u64 hmod(int i) {
+  return (u64)P::mod(2 * i) | ((u64)P::mod(2 * i + 1) << 32);
+}
+template <class P>
+constexpr u64 hone(int i) {
+  return (u64)P::one(2 * i) | ((u64)P::one(2 * i + 1) << 32);
+}
+template <class P>
+constexpr u64 hr2(int i) {
+  return (u64)P::r2(2 * i) | ((u64)P::r2(2 * i + 1) << 32);
+}
+template <class P>
+constexpr u64 hinv64() {  // -m^-1 mod 2^64 by Newton iteration
+  u64 m = hmod<P>(0), x = 1;
+  for (int i = 0; i < 6; i++) x *= 2 - m * x;
+  return (u64)0 - x;
+}
+
+template <class P>
+inline HFe<P> h_zero() {
+  HFe<P> r;
+  for (int i = 0; i < HFe<P>::N; i++) r.v[i] = 0;
+  return r;
+}
+template <class P>
+inline HFe<P> h_one() {
+  HFe<P> r;
+  for (int i = 0; i < HFe<P>::N; i++) r.v[i] = hone<P>(i);
+  return r;
+}
+template <class P>
+inline bool h_is_zero(const HFe<P>& a) {
+  u64 o = 0;
+  for (int i = 0; i < HFe<P>::N; i++) o |= a.v[i];
+  return o == 0;
+}
+template <class P>
+inline bool h_eq(const HFe<P>& a, const HFe<P>& b) {
+  u64 o = 0;
+  for (int i = 0; i < HFe<P>::N; i++) o |= a.v[i] ^ b.v[i];
+  return o == 0;
+}
+template <class P>
+inline bool h_geq_mod(const HFe<P>& a) {
+  for (int i = HFe<P>::N - 1; i >= 0; i--) {
+    if (a.v[i] > hmod<P>(i)) return true;
+    if (a.v[i] < hmod<P>(i)) return false;
+  }
+  return true;
+}
+template <class P>
+inline void h_sub_mod(HFe<P>& a) {
+  u64 br = 0;
+  for (int i = 0; i < HFe<P>::N; i++) {
+    u128 x = (u128)a.v[i] - hmod<P>(i) - br;
+    a.v[i] = (u64)x;
+    br = (u64)(x >> 64) & 1;
+  }
+}
+template <class P>
+inline HFe<P> h_add(const HFe<P>& a, const HFe<P>& b) {
+  HFe<P> r;
+  u128 c = 0;
+  for (int i = 0; i < HFe<P>::N; i++) {
+    c += (u128)a.v[i] + b.v[i];
+    r.v[i] = (u64)c;
+    c >>= 64;
+  }
+  if (c || h_geq_mod<P>(r)) h_sub_mod<P>(r);
+  return r;
+}
+template <class P>
+inline HFe<P> h_sub(const HFe<P>& a, const HFe<P>& b) {
+  HFe<P> r;
+  u64 br = 0;
+  for (int i = 0; i < HFe<P>::N; i++) {
+    u128 x = (u128)a.v[i] - b.v[i] - br;
+    r.v[i] = (u64)x;
+    br = (u64)(x >> 64) & 1;
+  }
+  if (br) {
+    u128 c = 0;
+    for (int i = 0; i < HFe<P>::N; i++) {
+      c += (u128)r.v[i] + hmod<P>(i);
+      r.v[i] = (u64)c;
+      c >>= 64;
+    }
+  }
+  return r;
+}
+template <class P>
+inline HFe<P> h_neg(const HFe<P>& a) {
+  if (h_is_zero<P>(a)) return a;
+  return h_sub<P>(h_zero<P>(), a);
+}
+template <class P>
+inline HFe<P> h_mul(const HFe<P>& a, const HFe<P>& b) {
+  constexpr int N = HFe<P>::N;
+  constexpr u64 inv = hinv64<P>();
+  u64 t[N + 2];
+  for (int i = 0; i < N + 2; i++) t[i] = 0;
+  for (int i = 0; i < N; i++) {
+    u128 c = 0;
+    for (int j = 0; j < N; j++) {
+      c += (u128)a.v[j] * b.v[i] + t[j];
+      t[j] = (u64)c;
+      c >>= 64;
+    }
+    c += t[N];
+    t[N] = (u64)c;
+    t[N + 1] = (u64)(c >> 64);
+    u64 m = t[0] * inv;
+    c = ((u128)m * hmod<P>(0) + t[0]) >> 64;
+    for (int j = 1; j < N; j++) {
+      c += (u128)m * hmod<P>(j) + t[j];
+      t[j - 1] = (u64)c;
+      c >>= 64;
+    }
+    c += t[N];
+    t[N - 1] = (u64)c;
+    t[N] = t[N + 1] + (u64)(c >> 64);
+  }
+  HFe<P> r;
+  for (int i = 0; i < N; i++) r.v[i] = t[i];
+  if (t[N] || h_geq_mod<P>(r)) h_sub_mod<P>(r);
+  return r;
+}
+template <class P>
+inline HFe<P> h_sqr(const HFe<P>& a) {
+  return h_mul<P>(a, a);
+}
+template <class P>
+inline HFe<P> h_inv(const HFe<P>& a) {  // a^(m-2)
+  constexpr int N = HFe<P>::N;
+  u64 e[N];
+  u64 br = 2;
+  for (int i = 0; i < N; i++) {
+    u128 x = (u128)hmod<P>(i) - br;
+    e[i] = (u64)x;
+    br = (u64)(x >> 64) & 1;
+  }
+  HFe<P> r = h_one<P>();
+  for (int i = N * 64 - 1; i >= 0; i--) {
+    r = h_sqr<P>(r);
+    if ((e[i >> 6] >> (i & 63)) & 1) r = h_mul<P>(r, a);
+  }
+  return r;
+}
+template <class P>
+inline HFe<P> h_from_mont(const HFe<P>& a) {
+  HFe<P> o = h_zero<P>();
+  o.v[0] = 1;
+  return h_mul<P>(a, o);
+}
+template <class P>
+inline HFe<P> h_to_mont(const HFe<P>& a) {
+  HFe<P> r2;
+  for (int i = 0; i < HFe<P>::N; i++) r2.v[i] = hr2<P>(i);
+  return h_mul<P>(a, r2);
+}
+
+// ---- curve (a = 0), XYZZ ---------------------------------------------------------------------
+template <class P>
+struct HXYZZ {
+  HFe<P> x, y, zz, zzz;
+};
+template <class P>
+inline HXYZZ<P> hx_inf() {
+  HXYZZ<P> r;
+  r.x = r.y = r.zz = r.zzz = h_zero<P>();
+  return r;
+}
+template <class P>
+inline bool hx_is_inf(const HXYZZ<P>& p) {
+  return h_is_zero<P>(p.zz);
+}
+template <class P>
+inline HXYZZ<P> hx_dbl(const HXYZZ<P>& p) {
+  if (hx_is_inf<P>(p)) return p;
+  HFe<P> u = h_add<P>(p.y, p.y);
+  HFe<P> v = h_sqr<P>(u);
+  HFe<P> w = h_mul<P>(u, v);
+  HFe<P> s = h_mul<P>(p.x, v);
+  HFe<P> xx = h_sqr<P>(p.x);
+  HFe<P> m = h_add<P>(h_add<P>(xx, xx), xx);
+  HXYZZ<P> r;
+  r.x = h_sub<P>(h_sub<P>(h_sqr<P>(m), s), s);
+  r.y = h_sub<P>(h_mul<P>(m, h_sub<P>(s, r.x)), h_mul<P>(w, p.y));
+  r.zz = h_mul<P>(v, p.zz);
+  r.zzz = h_mul<P>(w, p.zzz);
+  return r;
+}
+template <class P>
+inline HXYZZ<P> hx_add(const HXYZZ<P>& a, const HXYZZ<P>& b) {
+  if (hx_is_inf<P>(b)) return a;
+  if (hx_is_inf<P>(a)) return b;
+  HFe<P> u1 = h_mul<P>(a.x, b.zz), u2 = h_mul<P>(b.x, a.zz);
+  HFe<P> s1 = h_mul<P>(a.y, b.zzz), s2 = h_mul<P>(b.y, a.zzz);
+  HFe<P> p = h_sub<P>(u2, u1), r = h_sub<P>(s2, s1);
+  if (h_is_zero<P>(p)) {
+    if (h_is_zero<P>(r)) return hx_dbl<P>(a);
+    return hx_inf<P>();
+  }
+  HFe<P> pp = h_sqr<P>(p), ppp = h_mul<P>(p, pp), q = h_mul<P>(u1, pp);
+  HXYZZ<P> o;
+  o.x = h_sub<P>(h_sub<P>(h_sub<P>(h_sqr<P>(r), ppp), q), q);
+  o.y = h_sub<P>(h_mul<P>(r, h_sub<P>(q, o.x)), h_mul<P>(s1, ppp));
+  o.zz = h_mul<P>(h_mul<P>(a.zz, b.zz), pp);
+  o.zzz = h_mul<P>(h_mul<P>(a.zzz, b.zzz), ppp);
+  return o;
+}
+// affine (Montgomery x|y) -> XYZZ; (0,0) or is_inf -> infinity
+template <class P>
+inline HXYZZ<P> hx_from_affine(const u64* xy, bool is_inf) {
+  constexpr int N = HFe<P>::N;
+  HXYZZ<P> r;
+  memcpy(r.x.v, xy, 8 * N);
+  memcpy(r.y.v, xy + N, 8 * N);
+  if (is_inf || (h_is_zero<P>(r.x) && h_is_zero<P>(r.y))) return hx_inf<P>();
+  r.zz = h_one<P>();
+  r.zzz = h_one<P>();
+  return r;
+}
+template <class P>
+inline void hx_to_affine(const HXYZZ<P>& p, u64* xy, uint8_t* is_inf) {
+  constexpr int N = HFe<P>::N;
+  if (hx_is_inf<P>(p)) {
+    memset(xy, 0, 16 * N);
+    *is_inf = 1;
+    return;
+  }
+  HFe<P> inv = h_inv<P>(h_mul<P>(p.zz, p.zzz));
+  HFe<P> x = h_mul<P>(p.x, h_mul<P>(inv, p.zzz));
+  HFe<P> y = h_mul<P>(p.y, h_mul<P>(inv, p.zz));
+  memcpy(xy, x.v, 8 * N);
+  memcpy(xy + N, y.v, 8 * N);
+  *is_inf = 0;
+}
+// k * P, k = canonical 256-bit integer (4 u64), double-and-add MSB first
+template <class P>
+inline HXYZZ<P> hx_mul(const HXYZZ<P>& p, const u64 k[4]) {
+  HXYZZ<P> acc = hx_inf<P>();
+  for (int i = 255; i >= 0; i--) {
+    acc = hx_dbl<P>(acc);
+    if ((k[i >> 6] >> (i & 63)) & 1) acc = hx_add<P>(acc, p);
+  }
+  return acc;
+}
+// device XYZZ record (4*L u32, little-endian) -> host
+template <class P>
+inline HXYZZ<P> hx_from_device(const u32* rec) {
+  constexpr int N = HFe<P>::N;
+  HXYZZ<P> r;
+  memcpy(r.x.v, rec, 8 * N);
+  memcpy(r.y.v, rec + P::L, 8 * N);
+  memcpy(r.zz.v, rec + 2 * P::L, 8 * N);
+  memcpy(r.zzz.v, rec + 3 * P::L, 8 * N);
+  return r;
+}
+
+}  // namespace host
+}  // namespace amsm

@@ -1,0 +1,45 @@
+// Scalar-field kernels (digit extraction, synthetic vectors, Hadamard / linear-combination / t-vector
+// loops) instantiated for the scalar fields of both curves, plus the curve-independent bounds kernel.
+#include "launch.h"
+#include "vec_kernels.h"
+
+namespace amsm {
+
+static inline u32 cdiv_(u32 a, u32 b) { return (a + b - 1) / b; }
+
+void launch_bounds(hipStream_t st, const u32* keys_sorted, MsmGeom g, u32* start, u32* items) {
+  hipLaunchKernelGGL(k_bounds, dim3(cdiv_(g.B, 256)), dim3(256), 0, st, keys_sorted, g, start, items);
+}
+
+#define AMSM_FR_LAUNCHERS(FR)                                                                                        \
+  template <>                                                                                                        \
+  void launch_digits<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, u32* keys, u32* vals, u32* err) {   \
+    hipLaunchKernelGGL((k_digits<FR>), dim3(cdiv_(g.n, 256)), dim3(256), 0, st, scalars, mont, g, keys, vals, err);   \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  void launch_vec_random<FR>(hipStream_t st, u32* out, u64 seed, u32 n, int mont) {                                  \
+    hipLaunchKernelGGL((k_vec_random<FR>), dim3(cdiv_(n, 256)), dim3(256), 0, st, out, seed, n, mont);               \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  void launch_vec_hadamard<FR>(hipStream_t st, const u32* a, const u32* b, u32* out, u32 n) {                        \
+    hipLaunchKernelGGL((k_vec_hadamard<FR>), dim3(cdiv_(n, 256)), dim3(256), 0, st, a, b, out, n);                   \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  void launch_vec_combine<FR>(hipStream_t st, const CombineArgs& a, u32* out) {                                      \
+    hipLaunchKernelGGL((k_vec_combine<FR>), dim3(cdiv_(a.n, 256)), dim3(256), 0, st, a, out);                        \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  void launch_hp_t_vecs<FR>(hipStream_t st, const TVecArgs& a, int n_inputs) {                                       \
+    dim3 grid(cdiv_(a.len, 256)), block(256);                                                                        \
+    switch (n_inputs) {                                                                                              \
+      case 1: hipLaunchKernelGGL((k_hp_t_vecs<FR, 1>), grid, block, 0, st, a); break;                                \
+      case 2: hipLaunchKernelGGL((k_hp_t_vecs<FR, 2>), grid, block, 0, st, a); break;                                \
+      case 3: hipLaunchKernelGGL((k_hp_t_vecs<FR, 3>), grid, block, 0, st, a); break;                                \
+      default: hipLaunchKernelGGL((k_hp_t_vecs<FR, 4>), grid, block, 0, st, a); break;                               \
+    }                                                                                                                \
+  }
+
+AMSM_FR_LAUNCHERS(PallasFr)
+AMSM_FR_LAUNCHERS(Bls12381Fr)
+
+}  // namespace amsm

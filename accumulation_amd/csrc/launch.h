@@ -1,0 +1,46 @@
+// Host-callable launchers for the device kernels.  The heavy elliptic-curve kernels are compiled in one
+// translation unit per curve (kern_pallas.hip / kern_bls12_381.hip), the scalar-field kernels in
+// kern_fr.hip, so the library builds in parallel; api.hip only sees these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "msm_types.h"
+
+namespace amsm {
+
+// ---- per-curve (Fq) launchers ------------------------------------------------------------------
+template <class Fq>
+void launch_accum_l0(hipStream_t st, u32 max_items, const u32* table, const u32* vals_sorted, const u32* start,
+                     const u32* item_off, MsmGeom g, u32* partials);
+template <class Fq>
+void launch_accum_l1(hipStream_t st, const u32* partials, const u32* items, const u32* item_off, MsmGeom g,
+                     u32* buckets, u32* heavy_count, u32* heavy_list);
+template <class Fq>
+void launch_accum_l2(hipStream_t st, const u32* partials, const u32* items, const u32* item_off,
+                     const u32* heavy_count, const u32* heavy_list, u32* buckets);
+template <class Fq>
+void launch_bucket_reduce(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* out);
+template <class Fq>
+void launch_fold(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out);
+template <class Fq>
+void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c);
+template <class Fq>
+void launch_apply_inf(hipStream_t st, u32* table, const uint8_t* is_inf, u32 n);
+template <class Fq>
+void launch_generate_bases(hipStream_t st, u32* table, u64 seed, u32 n, const u32* gen_xy_mont);
+
+// ---- scalar-field (Fr) launchers ----------------------------------------------------------------
+template <class Fr>
+void launch_digits(hipStream_t st, const u32* scalars, int mont, MsmGeom g, u32* keys, u32* vals, u32* err);
+template <class Fr>
+void launch_vec_random(hipStream_t st, u32* out, u64 seed, u32 n, int mont);
+template <class Fr>
+void launch_vec_hadamard(hipStream_t st, const u32* a, const u32* b, u32* out, u32 n);
+template <class Fr>
+void launch_vec_combine(hipStream_t st, const CombineArgs& a, u32* out);
+template <class Fr>
+void launch_hp_t_vecs(hipStream_t st, const TVecArgs& a, int n_inputs);
+
+void launch_bounds(hipStream_t st, const u32* keys_sorted, MsmGeom g, u32* start, u32* items);
+
+}  // namespace amsm

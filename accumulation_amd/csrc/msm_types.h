@@ -1,0 +1,53 @@
+// Plain-data types shared by the host launcher (api.hip) and the kernel translation units.
+#pragma once
+#include <stdint.h>
+
+namespace amsm {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int VEC_MAX = 8;        // max vectors combined in one launch (reference uses 2..4)
+constexpr int HP_MAX_INPUTS = 4;  // max inputs+accumulators of one hp_as t-vector launch
+
+struct MsmGeom {
+  u32 n;             // pairs in this call
+  u32 c;             // window bits (2..24)
+  u32 W;             // windows
+  u32 nb;            // buckets per set = 2^(c-1)
+  u32 n_sets;        // 1 when precomputed, else W
+  u32 B;             // n_sets * nb  (key B = "digit 0", dropped)
+  u32 E;             // n * W entries
+  u32 base_off;      // first generator used
+  u32 table_stride;  // generators per table level (key length)
+  u32 precomp;       // table has W levels
+  u32 K0;            // entries per L0 work item
+  u32 K1;            // max partials folded by one L1 lane
+  u32 red_s;         // buckets per reduce lane
+  u32 red_threads;   // reduce lanes per set
+};
+
+struct CombineArgs {
+  const u32* vec[VEC_MAX];
+  u32 len[VEC_MAX];
+  u32 coeff[VEC_MAX][8];
+  const u32* hiding;
+  u32 hiding_len;
+  u32 n_vecs;
+  u32 n;
+};
+
+struct TVecArgs {
+  const u32* a[HP_MAX_INPUTS];
+  const u32* b[HP_MAX_INPUTS];
+  u32 a_len[HP_MAX_INPUTS];
+  u32 b_len[HP_MAX_INPUTS];
+  u32 mu[HP_MAX_INPUTS + 1][8];
+  const u32* hiding_a;
+  const u32* hiding_b;
+  u32 hiding_a_len, hiding_b_len;
+  u32* t[2 * HP_MAX_INPUTS - 1];
+  u32 len;
+};
+
+}  // namespace amsm

@@ -1,0 +1,165 @@
+// Scalar-field (Fr) vector kernels: the data-parallel loops of the reference that PRODUCE the MSM
+// scalars, so that those vectors are born in HBM and feed `amsm_msm_device` without a PCIe round trip.
+// All operands are Montgomery-form 32-byte elements (raw `Vec<Fr>` memory); one lane per element,
+// 2 x dwordx4 loads/stores per operand (coalesced 1 KiB per wave-instruction pair).
+//
+//   k_vec_hadamard : `compute_hp`                   src/hp_as/mod.rs:278-285   (K4, 96 B/elem)
+//   k_vec_combine  : `combine_vectors`/`scale_vector` src/hp_as/mod.rs:482-512 (K6, 32(n+1) B/elem)
+//   k_hp_t_vecs    : `compute_t_vecs`               src/hp_as/mod.rs:288-349   (K5, fused: reads 2n
+//                    vectors once, writes the 2n-2 committed coefficient vectors)
+#pragma once
+#include "fp.h"
+#include "msm_types.h"
+#include "rng.h"
+
+namespace amsm {
+
+
+template <class Fr>
+__global__ void __launch_bounds__(256)
+    k_vec_hadamard(const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<Fr> x = fe_load<Fr>(a + (size_t)i * 8);
+  Fe<Fr> y = fe_load<Fr>(b + (size_t)i * 8);
+  fe_store<Fr>(out + (size_t)i * 8, fe_mul<Fr>(x, y));
+}
+
+
+template <class Fr>
+__global__ void __launch_bounds__(256) k_vec_combine(CombineArgs a, u32* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  Fe<Fr> acc = fe_zero<Fr>();
+  if (a.hiding && i < a.hiding_len) acc = fe_load<Fr>(a.hiding + (size_t)i * 8);
+  for (u32 j = 0; j < a.n_vecs; j++) {
+    if (i < a.len[j]) {
+      Fe<Fr> cf;
+#pragma unroll
+      for (int k = 0; k < 8; k++) cf.v[k] = a.coeff[j][k];
+      Fe<Fr> x = fe_load<Fr>(a.vec[j] + (size_t)i * 8);
+      acc = fe_add<Fr>(acc, fe_mul<Fr>(cf, x));
+    }
+  }
+  fe_store<Fr>(out + (size_t)i * 8, acc);
+}
+
+
+// N = number of inputs (compile time so the N x N product stays in registers)
+template <class Fr, int N>
+__global__ void __launch_bounds__(256) k_hp_t_vecs(TVecArgs a) {
+  u32 li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= a.len) return;
+  Fe<Fr> ac[N], bc[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    Fe<Fr> mu;
+#pragma unroll
+    for (int k = 0; k < 8; k++) mu.v[k] = a.mu[j][k];
+    ac[j] = li < a.a_len[j] ? fe_mul<Fr>(mu, fe_load<Fr>(a.a[j] + (size_t)li * 8)) : fe_zero<Fr>();
+    // b coefficients are reversed: B(X) = sum_j b_{N-1-j} X^j   (src/hp_as/mod.rs:320)
+    bc[N - 1 - j] = li < a.b_len[j] ? fe_load<Fr>(a.b[j] + (size_t)li * 8) : fe_zero<Fr>();
+  }
+  if (a.hiding_a && li < a.hiding_a_len) {  // a_coeffs[0] += hiding_a[li] * mu[N]   (:322-325)
+    Fe<Fr> mu;
+#pragma unroll
+    for (int k = 0; k < 8; k++) mu.v[k] = a.mu[N][k];
+    ac[0] = fe_add<Fr>(ac[0], fe_mul<Fr>(fe_load<Fr>(a.hiding_a + (size_t)li * 8), mu));
+  }
+  if (a.hiding_b && li < a.hiding_b_len) {  // b_coeffs[0] += hiding_b[li] * mu[1]   (:327-329)
+    Fe<Fr> mu;
+#pragma unroll
+    for (int k = 0; k < 8; k++) mu.v[k] = a.mu[1][k];
+    bc[0] = fe_add<Fr>(bc[0], fe_mul<Fr>(fe_load<Fr>(a.hiding_b + (size_t)li * 8), mu));
+  }
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; k++) {
+    if (a.t[k] == nullptr) continue;  // uniform branch: coefficient N-1 is never committed
+    Fe<Fr> s = fe_zero<Fr>();
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      int j = k - i;
+      if (j >= 0 && j < N) s = fe_add<Fr>(s, fe_mul<Fr>(ac[i], bc[j]));
+    }
+    fe_store<Fr>(a.t[k] + (size_t)li * 8, s);
+  }
+}
+
+template <class Fr>
+__global__ void __launch_bounds__(256) k_vec_random(u32* __restrict__ out, u64 seed, u32 n, int mont) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<Fr> s;
+  rng_scalar(seed, i, s.v);
+  if (mont) s = fe_to_mont<Fr>(s);
+  fe_store<Fr>(out + (size_t)i * 8, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// digits: scalar -> W signed digits -> (key, value) entries, window-major (entry w*n + i).
+// Reads are 2 x dwordx4 per lane, coalesced; writes are coalesced per window.
+// ---------------------------------------------------------------------------------------------
+template <class Fr>
+__global__ void __launch_bounds__(256)
+    k_digits(const u32* __restrict__ scalars, int mont, MsmGeom g, u32* __restrict__ keys, u32* __restrict__ vals,
+             u32* __restrict__ err) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.n) return;
+  Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
+  if (mont) s = fe_from_mont<Fr>(s);
+  const u32 c = g.c;
+  const u32 mask = (1u << c) - 1u;
+  const u32 half = 1u << (c - 1);
+  u32 carry = 0;
+  for (u32 w = 0; w < g.W; w++) {
+    u32 raw = (s.v[0] & mask) + carry;
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
+    s.v[7] >>= c;
+    u32 neg = 0;
+    carry = 0;
+    u32 d = raw;
+    if (raw > half) {
+      d = (1u << c) - raw;
+      neg = 1;
+      carry = 1;
+    }
+    u32 set = g.precomp ? 0u : w;
+    u32 key = d == 0 ? g.B : set * g.nb + (d - 1);
+    u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
+    keys[(size_t)w * g.n + i] = key;
+    vals[(size_t)w * g.n + i] = idx | (neg << 31);
+  }
+  u32 rest = carry;
+#pragma unroll
+  for (int k = 0; k < 8; k++) rest |= s.v[k];
+  if (rest) atomicOr(err, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bounds: start[b] = first sorted entry with key >= b (b = 0..B); items[b] = ceil(len_b / K0).
+// ---------------------------------------------------------------------------------------------
+AMSM_DEV u32 lower_bound_u32(const u32* __restrict__ a, u32 n, u32 x) {
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    u32 mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256)
+    k_bounds(const u32* __restrict__ keys_sorted, MsmGeom g, u32* __restrict__ start, u32* __restrict__ items) {
+  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= g.B) return;
+  u32 lo = lower_bound_u32(keys_sorted, g.E, b);
+  u32 hi = lower_bound_u32(keys_sorted, g.E, b + 1);
+  start[b] = lo;
+  items[b] = (hi - lo + g.K0 - 1) / g.K0;
+  if (b == g.B - 1) {
+    start[g.B] = hi;
+    items[g.B] = 0;
+  }
+}
+
+}  // namespace amsm

@@ -1,0 +1,232 @@
+"""Host-side mirror (Python, over the C ABI) of the reference interfaces on the MSM hot path.
+
+Names follow the reference so parity tests read like its own:
+  * `VariableBaseMSM.multi_scalar_mul(bases, scalars)`  -- ark_ec::msm (ext), SURVEY.md section 8(a) a1
+  * `PedersenCommitment.{setup, commit}` / `CommitterKey` -- ark_poly_commit::trivial_pc (ext), a2;
+    call sites src/hp_as/mod.rs:196,377,911
+  * `FrVector` = a `Vec<G::ScalarField>` resident in HBM (raw Montgomery memory)
+
+numpy carries the data: scalars are (n, 4) uint64 little-endian limbs; affine points are
+(n, 2*limbs) uint64 (x_mont | y_mont) plus an (n,) uint8 infinity mask.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import ffi
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU + one HIP stream + workspace (amsm_ctx)."""
+
+    def __init__(self, curve: int = ffi.AMSM_PALLAS, device: int = 0, stream: Optional[int] = None):
+        self._lib = ffi.load()
+        h = C.c_void_p()
+        ffi.check(self._lib.amsm_ctx_create(C.byref(h), curve, device, C.c_void_p(stream) if stream else None),
+                  "amsm_ctx_create")
+        self._h = h
+        self.curve = curve
+        self.device = device
+        self.fq_limbs = self._lib.amsm_ctx_fq_limbs(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.amsm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_window(self, c_bits: int):
+        ffi.check(self._lib.amsm_ctx_set_window(self._h, c_bits), "amsm_ctx_set_window")
+
+    def set_profiling(self, on: bool):
+        ffi.check(self._lib.amsm_ctx_set_profiling(self._h, 1 if on else 0), "amsm_ctx_set_profiling")
+
+    def stage_ms(self) -> dict:
+        out = {}
+        for i in range(self._lib.amsm_stage_count()):
+            ms = C.c_float()
+            ffi.check(self._lib.amsm_ctx_stage_ms(self._h, i, C.byref(ms)), "amsm_ctx_stage_ms")
+            out[self._lib.amsm_stage_name(i).decode()] = ms.value
+        return out
+
+    def synchronize(self):
+        ffi.check(self._lib.amsm_ctx_synchronize(self._h), "amsm_ctx_synchronize")
+
+    # ---- Fr vectors in HBM ----
+    def vector(self, n: int) -> "FrVector":
+        return FrVector(self, n)
+
+    def upload(self, limbs: np.ndarray) -> "FrVector":
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, 4)
+        v = FrVector(self, limbs.shape[0])
+        if v.n:
+            ffi.check(self._lib.amsm_dev_upload(self._h, v.ptr, _ptr(limbs), limbs.nbytes), "amsm_dev_upload")
+        return v
+
+    def random_vector(self, seed: int, n: int, mont: bool) -> "FrVector":
+        v = FrVector(self, n)
+        ffi.check(self._lib.amsm_vec_random(self._h, seed, n, 1 if mont else 0, v.ptr), "amsm_vec_random")
+        return v
+
+
+class FrVector:
+    """n scalar-field elements (32 B each) in device memory."""
+
+    def __init__(self, ctx: Context, n: int):
+        self.ctx = ctx
+        self.n = n
+        p = C.c_void_p()
+        ffi.check(ctx._lib.amsm_dev_alloc(ctx._h, max(n, 1) * 32, C.byref(p)), "amsm_dev_alloc")
+        self.ptr = p
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.n, 4), dtype=np.uint64)
+        if self.n:
+            ffi.check(self.ctx._lib.amsm_dev_download(self.ctx._h, _ptr(out), self.ptr, out.nbytes), "amsm_dev_download")
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ctx._h:
+            self.ctx._lib.amsm_dev_free(self.ctx._h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n
+
+
+class CommitterKey:
+    """Generators of a Pedersen committer key resident in HBM (amsm_bases).
+    Mirrors ark_poly_commit::trivial_pc::CommitterKey{generators, hiding_generator}."""
+
+    def __init__(self, ctx: Context, handle, hiding_generator: Optional[np.ndarray] = None):
+        self.ctx = ctx
+        self._h = handle
+        self.hiding_generator = hiding_generator  # (2*limbs,) uint64 Montgomery affine, host side
+
+    @classmethod
+    def load(cls, ctx: Context, xy_mont: np.ndarray, is_inf: Optional[np.ndarray] = None,
+             flags: int = ffi.AMSM_BASES_DEFAULT, hiding_generator: Optional[np.ndarray] = None) -> "CommitterKey":
+        xy = np.ascontiguousarray(xy_mont, dtype=np.uint64).reshape(-1, 2 * ctx.fq_limbs)
+        inf = None if is_inf is None else np.ascontiguousarray(is_inf, dtype=np.uint8)
+        h = C.c_void_p()
+        ffi.check(ctx._lib.amsm_bases_load(ctx._h, _ptr(xy), _ptr(inf), xy.shape[0], flags, C.byref(h)), "amsm_bases_load")
+        return cls(ctx, h, hiding_generator)
+
+    @classmethod
+    def generate(cls, ctx: Context, seed: int, n: int, flags: int = ffi.AMSM_BASES_DEFAULT) -> "CommitterKey":
+        h = C.c_void_p()
+        ffi.check(ctx._lib.amsm_bases_generate(ctx._h, seed, n, flags, C.byref(h)), "amsm_bases_generate")
+        return cls(ctx, h)
+
+    def supported_num_elems(self) -> int:
+        return int(self.ctx._lib.amsm_bases_len(self._h))
+
+    def __len__(self):
+        return self.supported_num_elems()
+
+    @property
+    def precomputed(self) -> bool:
+        return bool(self.ctx._lib.amsm_bases_precomputed(self._h))
+
+    def read(self, off: int = 0, n: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        n = len(self) - off if n is None else n
+        xy = np.empty((n, 2 * self.ctx.fq_limbs), dtype=np.uint64)
+        inf = np.empty((n,), dtype=np.uint8)
+        ffi.check(self.ctx._lib.amsm_bases_read(self.ctx._h, self._h, off, n, _ptr(xy), _ptr(inf)), "amsm_bases_read")
+        return xy, inf
+
+    def free(self):
+        if self._h is not None:
+            self.ctx._lib.amsm_bases_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class VariableBaseMSM:
+    """ark_ec::msm::VariableBaseMSM (ext).  Results are affine (x_mont|y_mont, is_inf)."""
+
+    @staticmethod
+    def multi_scalar_mul(bases: CommitterKey, scalars, base_off: int = 0, mont: bool = False
+                         ) -> Tuple[np.ndarray, bool]:
+        ctx = bases.ctx
+        out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+        inf = C.c_uint8(0)
+        if isinstance(scalars, FrVector):
+            ffi.check(ctx._lib.amsm_msm_device(ctx._h, bases._h, base_off, scalars.ptr, scalars.n, 1 if mont else 0,
+                                               _ptr(out), C.byref(inf)), "amsm_msm_device")
+        else:
+            s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+            ffi.check(ctx._lib.amsm_msm(ctx._h, bases._h, base_off, _ptr(s), s.shape[0], 1 if mont else 0, _ptr(out),
+                                        C.byref(inf)), "amsm_msm")
+        return out, bool(inf.value)
+
+    @staticmethod
+    def multi_scalar_mul_batch(bases: CommitterKey, vectors: Sequence[FrVector], mont: bool = True, base_off: int = 0):
+        ctx = bases.ctx
+        k = len(vectors)
+        n = vectors[0].n if k else 0
+        assert all(v.n == n for v in vectors)
+        ptrs = (C.c_void_p * max(k, 1))(*[v.ptr for v in vectors])
+        out = np.zeros((k, 2 * ctx.fq_limbs), dtype=np.uint64)
+        inf = np.zeros((k,), dtype=np.uint8)
+        ffi.check(ctx._lib.amsm_msm_batch_device(ctx._h, bases._h, base_off, ptrs, k, n, 1 if mont else 0, _ptr(out),
+                                                 _ptr(inf)), "amsm_msm_batch_device")
+        return out, inf
+
+
+class PedersenCommitment:
+    """ark_poly_commit::trivial_pc::PedersenCommitment (ext): setup / commit."""
+
+    @staticmethod
+    def setup(ctx: Context, n: int, seed: int = 0x5EED1001, flags: int = ffi.AMSM_BASES_DEFAULT) -> CommitterKey:
+        """n generators + one hiding generator (the (n+1)-th point of the synthetic stream)."""
+        ck = CommitterKey.generate(ctx, seed, n + 1, ffi.AMSM_BASES_NO_PRECOMPUTE)
+        xy, _ = ck.read(0, n + 1)
+        ck.free()
+        out = CommitterKey.load(ctx, xy[:n], None, flags, hiding_generator=xy[n].copy())
+        return out
+
+    @staticmethod
+    def commit(ck: CommitterKey, elems, randomizer: Optional[np.ndarray] = None) -> Tuple[np.ndarray, bool]:
+        """commit(ck, &[F] (Montgomery), Option<F>) -> affine point."""
+        ctx = ck.ctx
+        if isinstance(elems, FrVector):
+            out, inf = VariableBaseMSM.multi_scalar_mul(ck, elems, mont=True)
+            if randomizer is None:
+                return out, inf
+            elems = elems.download()
+        e = np.ascontiguousarray(elems, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+        inf = C.c_uint8(0)
+        r = None if randomizer is None else np.ascontiguousarray(randomizer, dtype=np.uint64)
+        hg = None
+        if r is not None:
+            if ck.hiding_generator is None:
+                raise ValueError("committer key has no hiding generator")
+            hg = np.ascontiguousarray(ck.hiding_generator, dtype=np.uint64)
+        ffi.check(ctx._lib.amsm_pedersen_commit(ctx._h, ck._h, _ptr(e), e.shape[0], _ptr(r), _ptr(hg), _ptr(out),
+                                                C.byref(inf)), "amsm_pedersen_commit")
+        return out, bool(inf.value)

@@ -1,0 +1,104 @@
+"""ctypes binding of the C ABI in include/amsm.h (libamsm.so, built in-tree by build.py).
+
+There is no CPU fallback: importing works without a GPU (so the symbol table can be checked on a
+build box) but every compute entry point returns AMSM_E_NO_DEVICE there, and `load()` raises if the
+shared library itself is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamsm.so")
+
+AMSM_PALLAS = 0
+AMSM_BLS12_381_G1 = 1
+
+AMSM_OK = 0
+AMSM_E_INVALID_ARG = -1
+AMSM_E_OOM = -2
+AMSM_E_HIP = -3
+AMSM_E_UNSUPPORTED = -4
+AMSM_E_NO_DEVICE = -5
+AMSM_E_SCALAR_RANGE = -6
+
+AMSM_BASES_DEFAULT = 0
+AMSM_BASES_PRECOMPUTE = 1
+AMSM_BASES_NO_PRECOMPUTE = 2
+
+_vp = C.c_void_p
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/amsm.h declares (tests check this)
+SIGNATURES = {
+    "amsm_strerror": (C.c_char_p, [C.c_int]),
+    "amsm_device_count": (C.c_int, []),
+    "amsm_ctx_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),
+    "amsm_ctx_destroy": (None, [_vp]),
+    "amsm_ctx_curve": (C.c_int, [_vp]),
+    "amsm_ctx_fq_limbs": (C.c_int, [_vp]),
+    "amsm_ctx_set_window": (C.c_int, [_vp, C.c_int]),
+    "amsm_ctx_synchronize": (C.c_int, [_vp]),
+    "amsm_ctx_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "amsm_stage_count": (C.c_int, []),
+    "amsm_stage_name": (C.c_char_p, [C.c_int]),
+    "amsm_ctx_stage_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
+    "amsm_bases_load": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint, C.POINTER(_vp)]),
+    "amsm_bases_generate": (C.c_int, [_vp, C.c_uint64, _sz, C.c_uint, C.POINTER(_vp)]),
+    "amsm_bases_read": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "amsm_bases_len": (_sz, [_vp]),
+    "amsm_bases_precomputed": (C.c_int, [_vp]),
+    "amsm_bases_free": (None, [_vp]),
+    "amsm_msm": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
+    "amsm_msm_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
+    "amsm_msm_batch_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_vp), _sz, _sz, C.c_int, _vp, _vp]),
+    "amsm_partial_bytes": (_sz, [_vp]),
+    "amsm_msm_partial_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp]),
+    "amsm_partials_combine": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
+    "amsm_pedersen_commit": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "amsm_dev_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "amsm_dev_free": (C.c_int, [_vp, _vp]),
+    "amsm_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "amsm_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "amsm_vec_random": (C.c_int, [_vp, C.c_uint64, _sz, C.c_int, _vp]),
+    "amsm_vec_hadamard": (C.c_int, [_vp, _vp, _vp, _vp, _sz]),
+    "amsm_vec_combine": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _vp, _sz, _vp, _sz]),
+    "amsm_hp_t_vecs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _sz,
+                                 _vp, _sz, _vp, _sz, C.POINTER(_vp), _sz]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class AmsmError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        msg = load().amsm_strerror(status)
+        super().__init__(f"{where}: {msg.decode() if msg else status} ({status})")
+
+
+def load() -> C.CDLL:
+    """Load libamsm.so (raises if it has not been built -- no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or python -m accumulation_amd.build)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, where: str) -> None:
+    if status != AMSM_OK:
+        raise AmsmError(status, where)

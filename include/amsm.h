@@ -1,0 +1,172 @@
+/* amsm.h -- C ABI of the MI355X-native MSM engine for accumulation-scheme provers.
+ *
+ * This is the drop-in boundary for the ONE hot path of arkworks-rs/accumulation: the multi-scalar
+ * multiplications / Pedersen commitments inside the hp_as, r1cs_nark_as, ipa_pc_as (and trivial_pc_as)
+ * provers and deciders, plus the scalar-field vector loops that produce the MSM scalars.
+ *
+ * The reference has no FFI seam (src/lib.rs:24 `#![forbid(unsafe_code)]`); the calls replaced are
+ * monomorphised Rust generics.  Each entry point below names the reference interface it stands in
+ * for (paths relative to /root/reference; "ext" = a dependency whose source is not in that tree).
+ * INTEGRATION.md shows the Rust `extern "C"` adapter a maintainer would add.
+ *
+ * Data formats (identical to ark-ff 0.2 memory, so Rust slices can be passed zero-copy):
+ *   - field element  : little-endian u64 limbs of x*R mod m (Montgomery form), R = 2^(64*limbs);
+ *                      limbs = 4 for Pallas Fq/Fr and BLS12-381 Fr, 6 for BLS12-381 Fq.
+ *   - scalar (BigInt): 4 little-endian u64 limbs of the canonical integer in [0, r)  (`into_repr()`),
+ *                      or Montgomery form when the `scalars_mont` argument is non-zero (raw `Vec<Fr>`).
+ *   - affine point   : 2*limbs u64 = x_mont | y_mont, plus a separate is_inf byte (ark-ec
+ *                      `GroupAffine{x,y,infinity}` is not repr(C), so the adapter marshals it).
+ *
+ * Ownership: the caller owns every host buffer; calls are synchronous (results are on the host when
+ * the call returns) unless the name ends in `_device`/`_async`.  Device memory lives behind the
+ * opaque handles.  A ctx is NOT thread-safe; an amsm_bases is immutable after creation.
+ * Errors: 0 = OK, negative = AMSM_E_*; nothing throws across the boundary.
+ * There is NO CPU fallback: every entry point fails with AMSM_E_NO_DEVICE when no gfx950 GPU is usable.
+ */
+#ifndef AMSM_H
+#define AMSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct amsm_ctx amsm_ctx;
+typedef struct amsm_bases amsm_bases;
+
+enum amsm_curve {
+  AMSM_PALLAS = 0,       /* ark_pallas::Affine -- the only curve the reference exercises (Cargo.toml:39) */
+  AMSM_BLS12_381_G1 = 1, /* BASELINE.json config 3 (384-bit base field); extension, no reference harness */
+};
+
+enum amsm_status {
+  AMSM_OK = 0,
+  AMSM_E_INVALID_ARG = -1,
+  AMSM_E_OOM = -2,
+  AMSM_E_HIP = -3,
+  AMSM_E_UNSUPPORTED = -4,
+  AMSM_E_NO_DEVICE = -5,
+  AMSM_E_SCALAR_RANGE = -6, /* a scalar was >= 2^255 (not a canonical `into_repr()` value) */
+};
+
+/* flags for amsm_bases_load / amsm_bases_generate */
+enum amsm_bases_flags {
+  AMSM_BASES_DEFAULT = 0,      /* library picks (precompute when the key is large enough to benefit) */
+  AMSM_BASES_PRECOMPUTE = 1,   /* keep 2^(c*w)*G_i for every window w resident in HBM (W x memory) */
+  AMSM_BASES_NO_PRECOMPUTE = 2 /* one copy of the key; windows are combined on the host */
+};
+
+const char* amsm_strerror(int status);
+/* Number of usable gfx950 devices (0 when there is none); never initialises a context. */
+int amsm_device_count(void);
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* One context = one GPU + one HIP stream + a grow-only workspace.
+ * `stream` is a hipStream_t owned by the caller (e.g. torch.cuda.current_stream().cuda_stream) or
+ * NULL to let the context create its own non-blocking stream. */
+int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream);
+void amsm_ctx_destroy(amsm_ctx* ctx);
+int amsm_ctx_curve(const amsm_ctx* ctx);
+/* limbs (u64) of a base-field element: 4 (Pallas) or 6 (BLS12-381). */
+int amsm_ctx_fq_limbs(const amsm_ctx* ctx);
+/* Override the Pippenger window width c (bits); 0 restores the automatic choice. */
+int amsm_ctx_set_window(amsm_ctx* ctx, int c_bits);
+int amsm_ctx_synchronize(amsm_ctx* ctx);
+
+/* Per-stage device timings of the LAST msm call (hipEvent pairs on the context's stream).
+ * Enable with on != 0; stage names: amsm_stage_name(i), i in [0, amsm_stage_count()). */
+int amsm_ctx_set_profiling(amsm_ctx* ctx, int on);
+int amsm_stage_count(void);
+const char* amsm_stage_name(int stage);
+int amsm_ctx_stage_ms(amsm_ctx* ctx, int stage, float* ms);
+
+/* ---- committer key (generators) ------------------------------------------------------------- */
+/* Replaces the generator vector of `ark_poly_commit::trivial_pc::CommitterKey` (ext) built by
+ * `PedersenCommitment::setup/trim` -- call sites src/hp_as/mod.rs:640-641,
+ * src/r1cs_nark_as/r1cs_nark/mod.rs:107-108.  Generators are static per key, so they are copied to
+ * HBM once and stay resident.  xy_mont: n * 2 * limbs u64; is_inf: n bytes or NULL. */
+int amsm_bases_load(amsm_ctx* ctx, const uint64_t* xy_mont, const uint8_t* is_inf, size_t n, unsigned flags,
+                    amsm_bases** out);
+/* Synthetic key: G_i = k_i * G with k_i from the counter-based splitmix64 stream `seed`
+ * (oracle/pyref.py:rng_points is the definition).  Stands in for `PedersenCommitment::setup(n)`
+ * (ext; ark-poly-commit hashes to the curve -- any fixed set of distinct subgroup points is
+ * equivalent for this path). */
+int amsm_bases_generate(amsm_ctx* ctx, uint64_t seed, size_t n, unsigned flags, amsm_bases** out);
+/* Copy generators [off, off+n) back to the host (affine, Montgomery). */
+int amsm_bases_read(amsm_ctx* ctx, const amsm_bases* bases, size_t off, size_t n, uint64_t* xy_mont, uint8_t* is_inf);
+size_t amsm_bases_len(const amsm_bases* bases);
+int amsm_bases_precomputed(const amsm_bases* bases);
+void amsm_bases_free(amsm_bases* bases);
+
+/* ---- MSM ------------------------------------------------------------------------------------ */
+/* Replaces `ark_ec::msm::VariableBaseMSM::multi_scalar_mul(&bases[off..], &scalars)` (ext, ark-ec
+ * ^0.2.0, Cargo.toml:15) followed by `.into_affine()`, i.e. what every
+ * `PedersenCommitment::commit(ck, v, None)` call site needs: src/hp_as/mod.rs:377,911-918;
+ * src/r1cs_nark_as/mod.rs:394-410,1081-1093; src/r1cs_nark_as/r1cs_nark/mod.rs:216-218,234-236,251,261,375-403;
+ * and the (d+1)-point MSM under src/ipa_pc_as/mod.rs:836.
+ * Semantics kept: uses min(n, len - base_off) pairs; zero scalars and identity bases contribute
+ * nothing; n = 0 returns the identity; the result does not depend on pair order.
+ * scalars: n * 4 u64 (host).  scalars_mont != 0 => Montgomery form (device performs `into_repr`).
+ * out_xy_mont: 2 * limbs u64 (zeroed when the result is the identity); out_is_inf: 1 byte. */
+int amsm_msm(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const uint64_t* scalars, size_t n,
+             int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+/* Same with the scalar vector already resident in HBM (device pointer, n * 32 bytes, 16-byte
+ * aligned) -- the form the field-vector kernels below feed, and the form bench.py times. */
+int amsm_msm_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
+                    int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+/* n_vecs independent MSMs over the same generators (replaces the sequential loop of
+ * `compute_product_poly_comm`, src/hp_as/mod.rs:354-388).  d_scalars[v] are device pointers;
+ * outputs are n_vecs consecutive points. */
+int amsm_msm_batch_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* const* d_scalars,
+                          size_t n_vecs, size_t n, int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+
+/* Multi-GPU (one process per GPU): each rank runs the MSM over its shard of the key and leaves a
+ * fixed-size un-normalised partial in device memory; ranks all-gather the partials (RCCL, raw bytes)
+ * and every rank folds them.  amsm_partial_bytes() is the per-rank record size. */
+size_t amsm_partial_bytes(const amsm_ctx* ctx);
+int amsm_msm_partial_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
+                            int scalars_mont, void* d_partial_out);
+int amsm_partials_combine(amsm_ctx* ctx, const void* d_partials, size_t n_partials, uint64_t* out_xy_mont,
+                          uint8_t* out_is_inf);
+
+/* Replaces `PedersenCommitment::commit(ck, elems, Some(r))` (ext): MSM over ck.generators[..n] plus
+ * r * hiding_generator (single scalar-mul, done on the host like SURVEY.md section 8(a) row a11).
+ * elems_mont: raw `&[Fr]` memory (Montgomery).  randomizer_mont / hiding_xy_mont may be NULL (no
+ * hiding term, `commit(.., None)`). */
+int amsm_pedersen_commit(amsm_ctx* ctx, const amsm_bases* ck, const uint64_t* elems_mont, size_t n,
+                         const uint64_t* randomizer_mont, const uint64_t* hiding_xy_mont, uint64_t* out_xy_mont,
+                         uint8_t* out_is_inf);
+
+/* ---- device buffers for scalar-field vectors ------------------------------------------------- */
+int amsm_dev_alloc(amsm_ctx* ctx, size_t bytes, void** d_ptr);
+int amsm_dev_free(amsm_ctx* ctx, void* d_ptr);
+int amsm_dev_upload(amsm_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int amsm_dev_download(amsm_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+/* Fill d_out with n synthetic scalars of stream `seed` (oracle/pyref.py:rng_scalar), canonical
+ * integers (mont == 0) or the Montgomery form of the same integers (mont != 0). */
+int amsm_vec_random(amsm_ctx* ctx, uint64_t seed, size_t n, int mont, void* d_out);
+
+/* ---- scalar-field (Fr) vector kernels; all operands Montgomery, n elements of 32 bytes -------- */
+/* out[i] = a[i]*b[i]                      -- `compute_hp`, src/hp_as/mod.rs:278-285 */
+int amsm_vec_hadamard(amsm_ctx* ctx, const void* d_a, const void* d_b, void* d_out, size_t n);
+/* out[i] = sum_j coeff[j]*vecs[j][i] (+ hiding[i])  -- `combine_vectors` / `scale_vector`,
+ * src/hp_as/mod.rs:482-512.  coeffs_mont: host, n_vecs*4 u64.  d_hiding may be NULL.
+ * lens[j] (host, may be NULL = all n) gives ragged lengths; missing entries read as zero. */
+int amsm_vec_combine(amsm_ctx* ctx, const void* const* d_vecs, const size_t* lens, size_t n_vecs,
+                     const uint64_t* coeffs_mont, const void* d_hiding, size_t hiding_len, void* d_out, size_t n);
+/* t-vectors of `compute_t_vecs`, src/hp_as/mod.rs:288-349: for every position li the 2n-1
+ * coefficients of (sum_j mu_j a_j[li] X^j) * (sum_j b_{n-1-j}[li] X^j), hiding terms optional.
+ * d_t[k] (k = 0..2n-2) receive the coefficient vectors; d_t[n-1] may be NULL (it is never
+ * committed, src/hp_as/mod.rs:373-375).  a_lens/b_lens (host, NULL = all `len`) give ragged witness
+ * lengths: missing entries read as zero like `.get(li)` at :306-318.  Returns AMSM_E_INVALID_ARG when
+ * n_inputs + (hiding ? 1 : 0) > n_mu (the reference's assert at :295). */
+int amsm_hp_t_vecs(amsm_ctx* ctx, const void* const* d_a, const size_t* a_lens, const void* const* d_b,
+                   const size_t* b_lens, size_t n_inputs, const uint64_t* mu_mont, size_t n_mu, const void* d_hiding_a,
+                   size_t hiding_a_len, const void* d_hiding_b, size_t hiding_b_len, void* const* d_t, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMSM_H */

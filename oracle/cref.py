@@ -1,0 +1,121 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes loader for oracle/libark_msm.so (built from oracle/ark_msm.c by
+oracle/Makefile).  Same restrictions as oracle/pyref.py: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this.  PARITY UNPINNED (see oracle/ark_msm.c header)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libark_msm.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "ark_msm.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libark_msm.so"])
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = C.CDLL(LIB_PATH)
+        vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+        lib.ark_msm.restype = C.c_int
+        lib.ark_msm.argtypes = [C.c_int, vp, vp, vp, sz, C.c_int, vp, vp]
+        lib.ark_msm_window_bits.restype = C.c_int
+        lib.ark_msm_window_bits.argtypes = [sz]
+        lib.ark_rng_scalars.restype = None
+        lib.ark_rng_scalars.argtypes = [u64, sz, vp]
+        lib.ark_rng_points.restype = C.c_int
+        lib.ark_rng_points.argtypes = [C.c_int, u64, sz, C.c_int, vp]
+        lib.ark_fr_hadamard.restype = C.c_int
+        lib.ark_fr_hadamard.argtypes = [C.c_int, vp, vp, sz, vp]
+        lib.ark_fr_combine.restype = C.c_int
+        lib.ark_fr_combine.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(sz), sz, vp, vp, sz, sz, vp]
+        lib.ark_fr_to_mont.restype = C.c_int
+        lib.ark_fr_to_mont.argtypes = [C.c_int, vp, sz, vp]
+        lib.ark_fr_from_mont.restype = C.c_int
+        lib.ark_fr_from_mont.argtypes = [C.c_int, vp, sz, vp]
+        _lib = lib
+    return _lib
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def fq_limbs(curve_id: int) -> int:
+    return 4 if curve_id == 0 else 6
+
+
+def msm(curve_id: int, bases_xy: np.ndarray, scalars: np.ndarray, is_inf: Optional[np.ndarray] = None,
+        threads: int = 1) -> Tuple[np.ndarray, bool]:
+    """ark-ec-style CPU MSM.  bases_xy (n, 2L) uint64 Montgomery affine; scalars (n, 4) canonical."""
+    L = fq_limbs(curve_id)
+    b = np.ascontiguousarray(bases_xy, dtype=np.uint64).reshape(-1, 2 * L)
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    n = min(b.shape[0], s.shape[0])
+    inf = None if is_inf is None else np.ascontiguousarray(is_inf, dtype=np.uint8)
+    out = np.zeros((2 * L,), dtype=np.uint64)
+    oinf = C.c_uint8(0)
+    rc = load().ark_msm(curve_id, _p(b), _p(inf), _p(s), n, threads, _p(out), C.byref(oinf))
+    assert rc == 0
+    return out, bool(oinf.value)
+
+
+def rng_scalars(seed: int, n: int) -> np.ndarray:
+    out = np.empty((n, 4), dtype=np.uint64)
+    load().ark_rng_scalars(seed, n, _p(out))
+    return out
+
+
+def rng_points(curve_id: int, seed: int, n: int, threads: int = 8) -> np.ndarray:
+    out = np.zeros((n, 2 * fq_limbs(curve_id)), dtype=np.uint64)
+    rc = load().ark_rng_points(curve_id, seed, n, threads, _p(out))
+    assert rc == 0
+    return out
+
+
+def fr_hadamard(curve_id: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    n = min(a.shape[0], b.shape[0])
+    out = np.empty((n, 4), dtype=np.uint64)
+    assert load().ark_fr_hadamard(curve_id, _p(a), _p(b), n, _p(out)) == 0
+    return out
+
+
+def fr_combine(curve_id: int, vecs: Sequence[np.ndarray], coeffs: np.ndarray,
+               hiding: Optional[np.ndarray] = None) -> np.ndarray:
+    vecs = [np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4) for v in vecs]
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    n = max([v.shape[0] for v in vecs] + ([hiding.shape[0]] if hiding is not None else [0]))
+    ptrs = (C.c_void_p * max(len(vecs), 1))(*[v.ctypes.data for v in vecs])
+    lens = (C.c_size_t * max(len(vecs), 1))(*[v.shape[0] for v in vecs])
+    h = None if hiding is None else np.ascontiguousarray(hiding, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty((n, 4), dtype=np.uint64)
+    assert load().ark_fr_combine(curve_id, ptrs, lens, len(vecs), _p(coeffs), _p(h), 0 if h is None else h.shape[0], n,
+                                 _p(out)) == 0
+    return out
+
+
+def fr_to_mont(curve_id: int, a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty_like(a)
+    assert load().ark_fr_to_mont(curve_id, _p(a), a.shape[0], _p(out)) == 0
+    return out
+
+
+def fr_from_mont(curve_id: int, a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty_like(a)
+    assert load().ark_fr_from_mont(curve_id, _p(a), a.shape[0], _p(out)) == 0
+    return out
