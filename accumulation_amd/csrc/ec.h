@@ -55,7 +55,7 @@ AMSM_DEV XYZZ<P> xyzz_from_affine(const Affine<P>& p) {
 
 // dbl-2008-s-1 with a = 0: 6M + 3S
 template <class P>
-__device__ __noinline__ XYZZ<P> xyzz_dbl(const XYZZ<P>& p) {
+AMSM_DEV XYZZ<P> xyzz_dbl(const XYZZ<P>& p) {
   if (xyzz_is_inf<P>(p)) return p;
   Fe<P> u = fe_dbl<P>(p.y);
   Fe<P> v = fe_sqr<P>(u);
@@ -73,7 +73,7 @@ __device__ __noinline__ XYZZ<P> xyzz_dbl(const XYZZ<P>& p) {
 
 // mdbl-2008-s-1 with a = 0 (affine input): 3M + 3S
 template <class P>
-__device__ __noinline__ XYZZ<P> xyzz_dbl_affine(const Affine<P>& p) {
+AMSM_DEV XYZZ<P> xyzz_dbl_affine(const Affine<P>& p) {
   Fe<P> u = fe_dbl<P>(p.y);
   Fe<P> v = fe_sqr<P>(u);
   Fe<P> w = fe_mul<P>(u, v);

@@ -107,17 +107,15 @@ AMSM_DEV bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
   return o == 0;
 }
 
+// Carry chains are written with __builtin_addc/__builtin_subc so hipcc emits v_add_co/v_addc_co (and
+// pads the gfx950 VCC-write -> carry-read hazard itself) instead of emulating carries in 64-bit adds.
 // r = a - m if a >= m else a   (a < 2m, possibly with a carry word `hi` in {0,1})
 template <class P>
 AMSM_DEV void fe_cond_sub(Fe<P>& a, u32 hi = 0) {
   u32 d[P::L];
-  u64 br = 0;
+  u32 br = 0;
 #pragma unroll
-  for (int i = 0; i < P::L; i++) {
-    u64 x = (u64)a.v[i] - P::mod(i) - br;
-    d[i] = (u32)x;
-    br = (x >> 32) & 1;
-  }
+  for (int i = 0; i < P::L; i++) d[i] = __builtin_subc(a.v[i], P::mod(i), br, &br);
   bool ge = (hi != 0) || (br == 0);
 #pragma unroll
   for (int i = 0; i < P::L; i++) a.v[i] = ge ? d[i] : a.v[i];
@@ -126,36 +124,24 @@ AMSM_DEV void fe_cond_sub(Fe<P>& a, u32 hi = 0) {
 template <class P>
 AMSM_DEV Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
   Fe<P> r;
-  u64 c = 0;
+  u32 c = 0;
 #pragma unroll
-  for (int i = 0; i < P::L; i++) {
-    c += (u64)a.v[i] + b.v[i];
-    r.v[i] = (u32)c;
-    c >>= 32;
-  }
-  fe_cond_sub<P>(r, (u32)c);
+  for (int i = 0; i < P::L; i++) r.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
+  fe_cond_sub<P>(r, c);
   return r;
 }
 
 template <class P>
 AMSM_DEV Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
   Fe<P> r;
-  u64 br = 0;
+  u32 br = 0;
 #pragma unroll
-  for (int i = 0; i < P::L; i++) {
-    u64 x = (u64)a.v[i] - b.v[i] - br;
-    r.v[i] = (u32)x;
-    br = (x >> 32) & 1;
-  }
+  for (int i = 0; i < P::L; i++) r.v[i] = __builtin_subc(a.v[i], b.v[i], br, &br);
   // add the modulus back when the subtraction borrowed
-  u32 mask = (u32)0 - (u32)br;
-  u64 c = 0;
+  u32 mask = (u32)0 - br;
+  u32 c = 0;
 #pragma unroll
-  for (int i = 0; i < P::L; i++) {
-    c += (u64)r.v[i] + (P::mod(i) & mask);
-    r.v[i] = (u32)c;
-    c >>= 32;
-  }
+  for (int i = 0; i < P::L; i++) r.v[i] = __builtin_addc(r.v[i], P::mod(i) & mask, c, &c);
   return r;
 }
 
@@ -163,13 +149,9 @@ template <class P>
 AMSM_DEV Fe<P> fe_neg(const Fe<P>& a) {
   if (fe_is_zero<P>(a)) return a;
   Fe<P> r;
-  u64 br = 0;
+  u32 br = 0;
 #pragma unroll
-  for (int i = 0; i < P::L; i++) {
-    u64 x = (u64)P::mod(i) - a.v[i] - br;
-    r.v[i] = (u32)x;
-    br = (x >> 32) & 1;
-  }
+  for (int i = 0; i < P::L; i++) r.v[i] = __builtin_subc(P::mod(i), a.v[i], br, &br);
   return r;
 }
 
@@ -185,7 +167,7 @@ AMSM_DEV Fe<P> fe_dbl(const Fe<P>& a) {
 // the limb equal to 1 becomes an add (Pallas Fq/Fr: mod = {1,p1,p2,p3,0,0,0,2^30}).
 // ------------------------------------------------------------------------------------------------
 template <class P>
-AMSM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+AMSM_DEV Fe<P> fe_mul_ref(const Fe<P>& a, const Fe<P>& b) {
   constexpr int L = P::L;
   u32 t[L + 2];
 #pragma unroll
@@ -220,6 +202,20 @@ AMSM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
   fe_cond_sub<P>(r, t[L]);
   return r;
 }
+
+// fe_mul: the portable loop above is the definition; for gfx950 every field gets a generated
+// column-wise v_mad_u64_u32 / v_addc_co_u32 schedule (fp_mul_gfx950.h, tools/gen_fp_asm.py) which is
+// bit-identical and ~2x fewer VALU instructions.  -DAMSM_NO_ASM_MUL keeps the portable loop (A/B, debug).
+template <class P>
+AMSM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+  return fe_mul_ref<P>(a, b);
+}
+
+}  // namespace amsm
+#if !defined(AMSM_NO_ASM_MUL) && defined(__HIP_DEVICE_COMPILE__)
+#include "fp_mul_gfx950.h"
+#endif
+namespace amsm {
 
 template <class P>
 AMSM_DEV Fe<P> fe_sqr(const Fe<P>& a) {

@@ -50,18 +50,18 @@ __global__ void __launch_bounds__(256)
   u32 s = start[b] + j * g.K0;
   u32 e = min(s + g.K0, start[b + 1]);
   XYZZ<Fq> acc = xyzz_inf<Fq>();
+  // software pipeline: entry index two ahead, point one ahead (the vals -> point loads are dependent)
   u32 v = vals_sorted[s];
+  u32 v1 = vals_sorted[min(s + 1, e - 1)];
   Affine<Fq> pt = affine_load<Fq>(table, v & 0x7fffffffu);
   for (u32 k = s; k < e; k++) {
-    // issue the next gather before the (long) mixed addition so its latency is hidden
-    u32 vn = v;
-    Affine<Fq> ptn = pt;
-    if (k + 1 < e) {
-      vn = vals_sorted[k + 1];
-      ptn = affine_load<Fq>(table, vn & 0x7fffffffu);
-    }
+    // issued unconditionally (the tail re-reads its last entry) so hipcc keeps the loads in flight
+    // across the long mixed addition instead of branching around them
+    u32 v2 = vals_sorted[min(k + 2, e - 1)];
+    Affine<Fq> ptn = affine_load<Fq>(table, v1 & 0x7fffffffu);
     xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (v >> 31) != 0));
-    v = vn;
+    v = v1;
+    v1 = v2;
     pt = ptn;
   }
   xyzz_store<Fq>(partials, gid, acc);

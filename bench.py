@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- MSM throughput (point-scalar pairs/sec) at 2^20 Pallas on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: one MSM of 2^log2n pairs per
+GPU (scalars and the committer key already resident in HBM), result normalised to affine on the host.
+With N > 1 each rank owns a disjoint shard of the key (weak scaling: 2^log2n pairs per GPU, the job is
+one N*2^log2n-pair MSM); ranks all-gather their 128-byte partial sums over RCCL and fold them.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit/..., plus
+  "roofline":     the dominant kernel (bucket accumulation) against the HBM roofline, achieved =
+                  algorithmic bytes (96 B per pair) / mean kernel time measured
+                  with hipEvents on the engine's stream inside the timed region;
+  "cpu_baseline": the plain-C ark-ec-style restatement (oracle/ark_msm.c, kind "port") timed on this
+                  box's host cores on the same inputs (rank 0, N = 1 only), and used to check the GPU
+                  result bit-for-bit.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SEED_SCALARS = 0x5EED0001
+SEED_POINTS = 0x5EED1001
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n")
+    ap.add_argument("--curve", default="pallas", choices=["pallas", "bls12_381_g1"])
+    ap.add_argument("--no-precompute", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2n", type=int, default=None, help="sample size of the CPU baseline (default: log2n)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM, ffi
+    from accumulation_amd.engine import _ptr
+    import ctypes as C
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    curve_id = ffi.AMSM_PALLAS if args.curve == "pallas" else ffi.AMSM_BLS12_381_G1
+    n = 1 << args.log2n
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = Context(curve_id, device=local_rank, stream=stream.cuda_stream)
+        flags = ffi.AMSM_BASES_NO_PRECOMPUTE if args.no_precompute else ffi.AMSM_BASES_PRECOMPUTE
+        t0 = time.time()
+        ck = CommitterKey.generate(ctx, SEED_POINTS + rank, n, flags)
+        t_key = time.time() - t0
+        scalars = ctx.random_vector(SEED_SCALARS + rank, n, mont=False)
+        ctx.synchronize()
+        rec = int(ctx._lib.amsm_partial_bytes(ctx._h))
+        partial = torch.zeros(rec, dtype=torch.uint8, device="cuda")
+        gathered = torch.zeros(rec * world, dtype=torch.uint8, device="cuda")
+        out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+        inf = C.c_uint8(0)
+
+        def step():
+            if world == 1:
+                ffi.check(ctx._lib.amsm_msm_device(ctx._h, ck._h, 0, scalars.ptr, n, 0, _ptr(out), C.byref(inf)),
+                          "amsm_msm_device")
+            else:
+                ffi.check(ctx._lib.amsm_msm_partial_device(ctx._h, ck._h, 0, scalars.ptr, n, 0,
+                                                           C.c_void_p(partial.data_ptr())), "amsm_msm_partial_device")
+                dist.all_gather_into_tensor(gathered, partial)
+                ffi.check(ctx._lib.amsm_partials_combine(ctx._h, C.c_void_p(gathered.data_ptr()), world, _ptr(out),
+                                                         C.byref(inf)), "amsm_partials_combine")
+
+        def sync_all():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        ctx.set_profiling(True)
+        stage_sum = {}
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            for k, v in ctx.stage_ms().items():
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        ctx.set_profiling(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_pairs = n * world * args.steps
+    value = total_pairs / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
+
+    result = None
+    if rank == 0:
+        bytes_per_pair = 32 + 16 * ctx.fq_limbs  # 32 B scalar + affine point (64 B Pallas / 96 B BLS12-381)
+        dom = "accum_l0"
+        dom_ms = stage_ms.get(dom, 0.0)
+        achieved = (n * bytes_per_pair / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0
+        result = {
+            "metric": "MSM throughput (point-scalar pairs/sec) at 2^20 Pallas",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"2^{args.log2n}-pair {args.curve} MSM per GPU (north_star size; uniform 254-bit scalars, "
+                            f"G_i = k_i*G), key resident{'' if args.no_precompute else ' + precomputed window multiples'}",
+                "pairs_per_gpu": n,
+                "curve": args.curve,
+                "precomputed_key": bool(ck.precomputed),
+                "parallelism": f"point-sharded x{world}" + (" + RCCL all-gather of 1 partial/rank" if world > 1 else ""),
+                "key_setup_s": round(t_key, 3),
+                "seeds": {"scalars": SEED_SCALARS, "points": SEED_POINTS},
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_accum_l0 (bucket accumulation)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms": dom_ms,
+                "algorithmic_bytes_per_launch": n * bytes_per_pair,
+            },
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(ctx, ck, scalars, curve_id, args, out.copy(), bool(inf.value))
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(ctx, ck, scalars, curve_id, args, gpu_out, gpu_inf):
+    """Time the plain-C ark-ec-style restatement on the host cores, on the same inputs, and check the
+    GPU result against it bit-for-bit.  (Only this leg of bench.py touches oracle/.)"""
+    from oracle import cref
+
+    cpu_log2n = args.cpu_log2n if args.cpu_log2n is not None else args.log2n
+    m = min(1 << cpu_log2n, len(ck))
+    xy, _ = ck.read(0, m)
+    sc = scalars.download()[:m]
+    cores = os.cpu_count() or 1
+    n_windows = -(-255 // cref.load().ark_msm_window_bits(m))
+    threads = max(1, min(cores, n_windows))
+    t0 = time.perf_counter()
+    cpu_out, cpu_inf = cref.msm(curve_id, xy, sc, threads=threads)
+    t_par = time.perf_counter() - t0
+    # single-thread figure (the reference's default features) on a bounded 2^16 sample
+    ms = min(m, 1 << 16)
+    t0 = time.perf_counter()
+    cref.msm(curve_id, xy[:ms], sc[:ms], threads=1)
+    t_one = time.perf_counter() - t0
+    match = None
+    if m == len(ck):
+        match = bool(np.array_equal(cpu_out, gpu_out) and cpu_inf == gpu_inf)
+    return {
+        "value": m / t_par,
+        "unit": "pairs/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"one 2^{cpu_log2n}-pair MSM on the bench inputs, window-parallel on {threads} threads "
+                  f"(ark-ec `parallel` semantics; host has {cores} cores); {t_par:.2f} s",
+        "single_thread_value": ms / t_one,
+        "single_thread_sample": f"one 2^{ms.bit_length() - 1}-pair MSM, 1 thread (reference default features); {t_one:.2f} s",
+        "gpu_result_bit_exact_vs_cpu": match,
+    }
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,47 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu() -> bool:
+    try:
+        from accumulation_amd import ffi
+        return ffi.load().amsm_device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # -m gpu on a box without a GPU must fail loudly, not skip: the HIP path has no fallback.
+    pass
+
+
+@pytest.fixture(scope="session")
+def have_gpu():
+    return _have_gpu()
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libamsm.so must exist (build it if the tree is fresh); CPU-only boxes can still load it."""
+    from accumulation_amd import build, ffi
+    if not os.path.exists(ffi.LIB_PATH):
+        build.build_lib()
+    return ffi.load()
+
+
+@pytest.fixture(scope="session")
+def cref():
+    from oracle import cref as c
+    c.build()
+    c.load()
+    return c
