@@ -1,0 +1,73 @@
+"""Point-sharded MSM across the GPUs of one node (one process per GPU, torch.distributed).
+
+SURVEY.md section 8(e): sum_i s_i*G_i over disjoint index ranges are independent; the total is the EC sum of
+the per-rank partials.  Rank r keeps generators [lo_r, hi_r) resident (loaded once per key) and gets only
+its slice of the scalars per call.  The only exchange is an all-gather of one fixed-size partial record
+per rank (128 B Pallas / 192 B BLS12-381) as raw bytes -- EC addition is not an RCCL reduction op -- after
+which every rank folds the records identically.  With backend "nccl" the all-gather runs over RCCL/xGMI.
+
+The reference has no counterpart (single process, CPU only); this is the new component C1 of SURVEY.md section 2.1.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced ranges: the first n_total % world ranks get one extra element."""
+    q, r = divmod(n_total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+class HipEngine:
+    """Per-rank engine: libamsm.so context + this rank's shard of the committer key."""
+
+    def __init__(self, ctx, ck):
+        import torch
+        self.ctx, self.ck = ctx, ck
+        self.record_bytes = int(ctx._lib.amsm_partial_bytes(ctx._h))
+        self._partial = torch.zeros(self.record_bytes, dtype=torch.uint8, device=f"cuda:{ctx.device}")
+
+    def partial(self, scalars, mont: bool):
+        """scalars: FrVector (this rank's slice).  Returns a uint8 CUDA tensor holding the record."""
+        from . import ffi
+        ffi.check(self.ctx._lib.amsm_msm_partial_device(self.ctx._h, self.ck._h, 0, scalars.ptr, scalars.n,
+                                                        1 if mont else 0, C.c_void_p(self._partial.data_ptr())),
+                  "amsm_msm_partial_device")
+        return self._partial
+
+    def combine(self, gathered, count: int):
+        from . import ffi
+        from .engine import _ptr
+        out = np.zeros((2 * self.ctx.fq_limbs,), dtype=np.uint64)
+        inf = C.c_uint8(0)
+        ffi.check(self.ctx._lib.amsm_partials_combine(self.ctx._h, C.c_void_p(gathered.data_ptr()), count, _ptr(out),
+                                                      C.byref(inf)), "amsm_partials_combine")
+        return out, bool(inf.value)
+
+
+class ShardedMSM:
+    """msm(local_scalars) -> the affine result of the WHOLE (all ranks) MSM, identical on every rank."""
+
+    def __init__(self, engine, group=None):
+        import torch.distributed as dist
+        self.engine = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._gathered = None
+
+    def msm(self, local_scalars, mont: bool = True):
+        import torch
+        import torch.distributed as dist
+        part = self.engine.partial(local_scalars, mont)
+        if self.world == 1:
+            return self.engine.combine(part, 1)
+        if self._gathered is None or self._gathered.numel() != part.numel() * self.world:
+            self._gathered = torch.empty(part.numel() * self.world, dtype=torch.uint8, device=part.device)
+        dist.all_gather_into_tensor(self._gathered, part, group=self.group)
+        return self.engine.combine(self._gathered, self.world)

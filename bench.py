@@ -79,22 +79,21 @@ def main() -> int:
         t_key = time.time() - t0
         scalars = ctx.random_vector(SEED_SCALARS + rank, n, mont=False)
         ctx.synchronize()
-        rec = int(ctx._lib.amsm_partial_bytes(ctx._h))
-        partial = torch.zeros(rec, dtype=torch.uint8, device="cuda")
-        gathered = torch.zeros(rec * world, dtype=torch.uint8, device="cuda")
         out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
         inf = C.c_uint8(0)
+        sharded = None
+        if world > 1:
+            from accumulation_amd.dist import HipEngine, ShardedMSM
+            sharded = ShardedMSM(HipEngine(ctx, ck))
+        last = {}
 
         def step():
             if world == 1:
                 ffi.check(ctx._lib.amsm_msm_device(ctx._h, ck._h, 0, scalars.ptr, n, 0, _ptr(out), C.byref(inf)),
                           "amsm_msm_device")
             else:
-                ffi.check(ctx._lib.amsm_msm_partial_device(ctx._h, ck._h, 0, scalars.ptr, n, 0,
-                                                           C.c_void_p(partial.data_ptr())), "amsm_msm_partial_device")
-                dist.all_gather_into_tensor(gathered, partial)
-                ffi.check(ctx._lib.amsm_partials_combine(ctx._h, C.c_void_p(gathered.data_ptr()), world, _ptr(out),
-                                                         C.byref(inf)), "amsm_partials_combine")
+                # local MSM -> 1 partial record -> RCCL all-gather (raw bytes) -> identical fold on every rank
+                last["xy"], last["inf"] = sharded.msm(scalars, mont=False)
 
         def sync_all():
             torch.cuda.synchronize()

@@ -1,0 +1,137 @@
+"""GPU parity tests for the scalar-field vector kernels (compute_hp, combine_vectors, scale_vector,
+compute_t_vecs) against the restatements in oracle/, bit-exact on Montgomery limbs; plus the reference's
+decider identity driven end-to-end on the device."""
+import numpy as np
+import pytest
+
+from oracle import pyref as o
+from tests import helpers as h
+
+pytestmark = pytest.mark.gpu
+CURVES = [o.PALLAS, o.BLS12_381_G1]
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    from accumulation_amd import Context
+    out = {c.name: Context(c.curve_id) for c in CURVES}
+    yield out
+    for c in out.values():
+        c.close()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 5000])
+def test_compute_hp(ctxs, cref, c, n):
+    from accumulation_amd.hp_as import compute_hp
+    ctx = ctxs[c.name]
+    a = cref.fr_to_mont(c.curve_id, cref.rng_scalars(1, n))
+    b = cref.fr_to_mont(c.curve_id, cref.rng_scalars(2, n + 3))  # zip truncates to the shorter
+    got = compute_hp(ctx, ctx.upload(a), ctx.upload(b)).download()
+    assert np.array_equal(got, cref.fr_hadamard(c.curve_id, a, b[:n]))
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_combine_vectors_ragged_and_hiding(ctxs, cref, c):
+    from accumulation_amd.hp_as import combine_vectors, scale_vector
+    ctx = ctxs[c.name]
+    lens = [700, 513, 700, 1]
+    vecs = [cref.fr_to_mont(c.curve_id, cref.rng_scalars(10 + j, ln)) for j, ln in enumerate(lens)]
+    ch = cref.fr_to_mont(c.curve_id, cref.rng_scalars(20, len(lens)))
+    hid = cref.fr_to_mont(c.curve_id, cref.rng_scalars(21, 650))
+    dv = [ctx.upload(v) for v in vecs]
+    got = combine_vectors(ctx, dv, ch, ctx.upload(hid)).download()
+    assert np.array_equal(got, cref.fr_combine(c.curve_id, vecs, ch, hiding=hid))
+    got = combine_vectors(ctx, dv[:2], ch[:2]).download()
+    assert np.array_equal(got, cref.fr_combine(c.curve_id, vecs[:2], ch[:2]))
+    got = scale_vector(ctx, dv[0], ch[3]).download()
+    assert np.array_equal(got, cref.fr_combine(c.curve_id, vecs[:1], ch[3:4]))
+    # python restatement agrees too (small slice)
+    exp = o.combine_vectors(c, [h.fr_from_mont_np(c, v[:9]) for v in vecs[:2]], h.fr_from_mont_np(c, ch[:2]))
+    assert h.fr_from_mont_np(c, got[:0]) == [] and h.fr_from_mont_np(
+        c, combine_vectors(ctx, [ctx.upload(vecs[0][:9]), ctx.upload(vecs[1][:9])], ch[:2]).download()) == exp
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n_in", [1, 2, 3, 4])
+@pytest.mark.parametrize("zk", [False, True])
+def test_compute_t_vecs(ctxs, c, n_in, zk):
+    from accumulation_amd.hp_as import compute_t_vecs
+    ctx = ctxs[c.name]
+    ln = 77
+    a = [o.rng_scalars(100 + j, ln if j != 1 else ln - 5) for j in range(n_in)]  # one ragged witness
+    b = [o.rng_scalars(200 + j, ln) for j in range(n_in)]
+    mu = [1] + o.rng_scalars(300, n_in)  # n_in + 1 challenges (the last only used when zk)
+    hiding = (o.rng_scalars(400, ln), o.rng_scalars(401, ln - 2)) if zk else None
+    exp = o.compute_t_vecs(c, a, b, mu, ln, hiding)
+    da = [ctx.upload(h.fr_mont_np(c, v)) for v in a]
+    db = [ctx.upload(h.fr_mont_np(c, v)) for v in b]
+    dh = None if not zk else (ctx.upload(h.fr_mont_np(c, hiding[0])), ctx.upload(h.fr_mont_np(c, hiding[1])))
+    got = compute_t_vecs(ctx, da, db, h.fr_mont_np(c, mu), ln, dh)
+    assert len(got) == 2 * n_in - 1
+    for k in range(2 * n_in - 1):
+        assert h.fr_from_mont_np(c, got[k].download()) == exp[k], k
+    # the committed subset only (coefficient n-1 is never committed, src/hp_as/mod.rs:373-375)
+    got2 = compute_t_vecs(ctx, da, db, h.fr_mont_np(c, mu), ln, dh, skip_uncommitted=True)
+    assert got2[n_in - 1] is None
+    for k in range(2 * n_in - 1):
+        if k != n_in - 1:
+            assert np.array_equal(got2[k].download(), got[k].download())
+
+
+def test_t_vecs_rejects_too_few_challenges(ctxs):
+    from accumulation_amd import ffi
+    from accumulation_amd.hp_as import compute_t_vecs
+    c = o.PALLAS
+    ctx = ctxs[c.name]
+    v = ctx.upload(h.fr_mont_np(c, [1, 2, 3]))
+    with pytest.raises(ffi.AmsmError) as e:  # assert!(n + hiding <= mu.len())  src/hp_as/mod.rs:295
+        compute_t_vecs(ctx, [v, v], [v, v], h.fr_mont_np(c, [1]), 3)
+    assert e.value.status == ffi.AMSM_E_INVALID_ARG
+
+
+def test_hp_accumulation_decider_identity(ctxs):
+    """One no-zk hp_as accumulation of two inputs with every vector loop and every MSM on the GPU
+    (Appendix A.1 of SURVEY.md): the decider's checks commit(a') == C1', commit(b') == C2',
+    commit(a' o b') == C3' must hold for the combined instance computed the verifier's way
+    (src/hp_as/mod.rs:409-479, 894-925).  Challenges are injected (the sponge stays on the host)."""
+    from accumulation_amd import PedersenCommitment, VariableBaseMSM
+    from accumulation_amd.hp_as import (combine_vectors, compute_hp, compute_product_poly_comm, compute_t_vecs,
+                                        decide_commitments)
+    c = o.PALLAS
+    ctx = ctxs[c.name]
+    ln, n = 1 << 12, 2
+    ck = PedersenCommitment.setup(ctx, ln, seed=123)
+    a = [ctx.random_vector(500 + j, ln, mont=True) for j in range(n)]
+    b = [ctx.random_vector(600 + j, ln, mont=True) for j in range(n)]
+    # input instances: (commit(a_j), commit(b_j), commit(a_j o b_j))
+    inst = []
+    for j in range(n):
+        pts, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [a[j], b[j], compute_hp(ctx, a[j], b[j])], mont=True)
+        inst.append([h.np_to_point(c, pts[i], infs[i]) for i in range(3)])
+    mu = [1, o.rng_scalar(700, 0) % (1 << 128)]
+    nu1 = o.rng_scalar(701, 0) % (1 << 128)
+    nu = [pow(nu1, k, c.r) for k in range(2 * n - 1)]
+    t = compute_t_vecs(ctx, a, b, h.fr_mont_np(c, mu), ln, None, skip_uncommitted=True)
+    low, high = compute_product_poly_comm(ck, t)
+    low = [h.np_to_point(c, p, i) for p, i in low]
+    high = [h.np_to_point(c, p, i) for p, i in high]
+    chi = [mu[i] * nu[i] % c.r for i in range(n)]
+    # verifier side (host, O(n) scalar-muls): combined commitments
+    C1 = C2 = C3 = None
+    for i in range(n):
+        C1 = o.add(c, C1, o.mul(c, chi[i], inst[i][0]))
+        C2 = o.add(c, C2, o.mul(c, nu[i], inst[n - 1 - i][1]))
+    inner = None
+    for i in range(n):
+        inner = o.add(c, inner, o.mul(c, mu[i], inst[i][2]))
+    for i in range(n - 1):
+        C3 = o.add(c, C3, o.mul(c, nu[i], low[i]))
+        C3 = o.add(c, C3, o.mul(c, nu[n + i], high[i]))
+    C3 = o.add(c, C3, o.mul(c, nu[n - 1], inner))
+    # prover side (device): combined openings
+    a_new = combine_vectors(ctx, a, h.fr_mont_np(c, chi))
+    b_new = combine_vectors(ctx, list(reversed(b)), h.fr_mont_np(c, nu[:n]))
+    got = decide_commitments(ck, a_new, b_new)
+    got = [h.np_to_point(c, p, i) for p, i in got]
+    assert got[0] == C1 and got[1] == C2 and got[2] == C3
