@@ -30,23 +30,43 @@ struct DevBuf {
 
 }  // namespace
 
+// One pipeline slot = one stream + one private workspace, so two MSMs of a batch can be in flight:
+// the latency-bound tail of MSM i (fold partials, bucket reduce) overlaps the throughput-bound head of
+// MSM i+1 on the other slot's stream.
+constexpr int N_SLOTS = 3;  // MSMs of one batch in flight
+
+struct Slot {
+  hipStream_t stream = nullptr;  // head: digits, sort, bounds, accumulate L0 (throughput-bound)
+  hipStream_t tail = nullptr;    // tail: fold partials, bucket reduce, D2H (latency-bound) -- high priority, so
+                                 // its few waves are dispatched ahead of the next MSM's not-yet-resident L0 blocks
+  bool own_stream = false;
+  hipEvent_t l0_done = nullptr;
+  hipEvent_t ev[ST_COUNT + 1] = {};
+  hipEvent_t done = nullptr;
+  DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
+      sort_tmp, scan_tmp;
+  void* h_pinned = nullptr;
+  size_t h_pinned_bytes = 0;
+  MsmGeom geom = {};
+  bool busy = false;
+};
+
 struct amsm_ctx {
   int curve = 0;
   int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
+  hipStream_t stream = nullptr;  // == slot[0].stream
   int window_override = 0;
-  int K0 = 64;
-  int K1 = 16;
+  int K0 = 0;          // 0 = automatic (see make_geom)
+  int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x 4 SIMDs x 4 waves
+  int K1 = 64;
   int red_s = 4;
   bool profiling = false;
-  hipEvent_t ev[ST_COUNT + 1] = {};
-  float stage_ms[ST_COUNT] = {};
-  // workspace (grow-only)
-  DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
-      sort_tmp, scan_tmp, scalars;
-  void* h_pinned = nullptr;
-  size_t h_pinned_bytes = 0;
+  float stage_ms[ST_COUNT] = {};  // mean over the MSMs of the last call
+  float stage_acc[ST_COUNT] = {};
+  int stage_n = 0;
+  Slot slot[N_SLOTS];
+  hipEvent_t fork = nullptr;
+  DevBuf scalars;
 };
 
 struct amsm_bases {
@@ -88,12 +108,12 @@ int ensure(DevBuf& b, size_t bytes) {
   return AMSM_OK;
 }
 
-int ensure_pinned(amsm_ctx* ctx, size_t bytes) {
-  if (ctx->h_pinned_bytes >= bytes) return AMSM_OK;
-  if (ctx->h_pinned) HIP_TRY(hipHostFree(ctx->h_pinned));
-  ctx->h_pinned = nullptr;
-  HIP_TRY(hipHostMalloc(&ctx->h_pinned, bytes + 4096, hipHostMallocDefault));
-  ctx->h_pinned_bytes = bytes + 4096;
+int ensure_pinned(Slot* sl, size_t bytes) {
+  if (sl->h_pinned_bytes >= bytes) return AMSM_OK;
+  if (sl->h_pinned) HIP_TRY(hipHostFree(sl->h_pinned));
+  sl->h_pinned = nullptr;
+  HIP_TRY(hipHostMalloc(&sl->h_pinned, bytes + 4096, hipHostMallocDefault));
+  sl->h_pinned_bytes = bytes + 4096;
   return AMSM_OK;
 }
 
@@ -186,7 +206,19 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   g.table_stride = (u32)bases->n;
   g.precomp = (u32)bases->precomp;
   if ((unsigned long long)bases->n * (bases->precomp ? W : 1) >= (1ull << 31)) return AMSM_E_UNSUPPORTED;
-  g.K0 = (u32)ctx->K0;
+  // chunk length of accumulate L0: the grid should be a whole number of rounds of the resident wave
+  // slots (4 waves/SIMD at ~122 VGPRs), so that no SIMD idles while a partial last round drains
+  if (ctx->K0 > 0) {
+    g.K0 = (u32)ctx->K0;
+  } else {
+    unsigned long long lanes = (unsigned long long)ctx->wave_slots * 64ull;
+    // <= 32 entries per lane per round: measured best on MI355X (2^20 Pallas: 2 rounds of 32 beat 1 round of 64
+    // once consecutive MSMs of a batch overlap, because the other MSM's sort/tail kernels get wave slots at
+    // the round boundary)
+    unsigned long long rounds = (g.E + lanes * 32ull - 1) / (lanes * 32ull);
+    unsigned long long k = (g.E + lanes * rounds - 1) / (lanes * rounds);
+    g.K0 = (u32)std::min<unsigned long long>(std::max<unsigned long long>(k, 16ull), 32ull);
+  }
   g.K1 = (u32)ctx->K1;
   g.red_s = std::min<u32>((u32)ctx->red_s, g.nb);
   g.red_threads = g.nb / g.red_s;
@@ -194,93 +226,115 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   return AMSM_OK;
 }
 
-void stage_mark(amsm_ctx* ctx, int idx) {
-  if (ctx->profiling) (void)hipEventRecord(ctx->ev[idx], ctx->stream);
+void stage_mark(amsm_ctx* ctx, Slot* sl, int idx) {
+  if (ctx->profiling) (void)hipEventRecord(sl->ev[idx], sl->stream);
 }
 
+// lanes cooperating on one bucket in accumulate L1 (tree over partials): more lanes = lower latency,
+// but only worth it when buckets have several partials each
+u32 l1_lanes(const MsmGeom& g) {
+  double avg = ((double)g.E / g.K0) / g.B;
+  return avg >= 48.0 ? 16u : (avg >= 3.0 ? 4u : 1u);
+}
+
+// Enqueue the whole pipeline for one MSM on slot `sl` (asynchronous); leaves n_sets folded XYZZ records
+// in sl->fold_out and queues their D2H into sl->h_pinned.
 template <class Fq, class Fr>
-int msm_pipeline(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
-                 int scalars_mont, MsmGeom* geom_out) {
+int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
+                int scalars_mont) {
   MsmGeom g;
   TRY(make_geom(ctx, bases, base_off, n, &g));
-  *geom_out = g;
-  hipStream_t st = ctx->stream;
+  sl->geom = g;
+  hipStream_t st = sl->stream;
   const u32 max_items = g.E / g.K0 + g.B + 1;
   const u32 red_blocks = cdiv(g.red_threads, 256);
-  TRY(ensure(ctx->keys_a, (size_t)g.E * 4));
-  TRY(ensure(ctx->keys_b, (size_t)g.E * 4));
-  TRY(ensure(ctx->vals_a, (size_t)g.E * 4));
-  TRY(ensure(ctx->vals_b, (size_t)g.E * 4));
-  TRY(ensure(ctx->start, (size_t)(g.B + 2) * 4));
-  TRY(ensure(ctx->items, (size_t)(g.B + 2) * 4));
-  TRY(ensure(ctx->item_off, (size_t)(g.B + 2) * 4));
-  TRY(ensure(ctx->partials, (size_t)max_items * xyzz_bytes<Fq>()));
-  TRY(ensure(ctx->buckets, (size_t)g.B * xyzz_bytes<Fq>()));
-  TRY(ensure(ctx->red_out, (size_t)g.n_sets * red_blocks * xyzz_bytes<Fq>()));
-  TRY(ensure(ctx->fold_out, (size_t)g.n_sets * xyzz_bytes<Fq>()));
-  TRY(ensure(ctx->heavy, (size_t)(g.B + 1) * 4));
-  TRY(ensure(ctx->misc, 64));
-  u32* d_err = (u32*)ctx->misc.p;
+  TRY(ensure(sl->keys_a, (size_t)g.E * 4));
+  TRY(ensure(sl->keys_b, (size_t)g.E * 4));
+  TRY(ensure(sl->vals_a, (size_t)g.E * 4));
+  TRY(ensure(sl->vals_b, (size_t)g.E * 4));
+  TRY(ensure(sl->start, (size_t)(g.B + 2) * 4));
+  TRY(ensure(sl->items, (size_t)(g.B + 2) * 4));
+  TRY(ensure(sl->item_off, (size_t)(g.B + 2) * 4));
+  TRY(ensure(sl->partials, (size_t)max_items * xyzz_bytes<Fq>()));
+  TRY(ensure(sl->buckets, (size_t)g.B * xyzz_bytes<Fq>()));
+  TRY(ensure(sl->red_out, (size_t)g.n_sets * red_blocks * xyzz_bytes<Fq>()));
+  TRY(ensure(sl->fold_out, (size_t)g.n_sets * xyzz_bytes<Fq>()));
+  TRY(ensure(sl->heavy, (size_t)(g.B + 1) * 4));
+  TRY(ensure(sl->misc, 64));
+  size_t rec = xyzz_bytes<Fq>();
+  TRY(ensure_pinned(sl, g.n_sets * rec + 64));
+  u32* d_err = (u32*)sl->misc.p;
   u32* d_heavy_count = d_err + 1;
+  u32* keys_a = (u32*)sl->keys_a.p;
+  u32* keys_b = (u32*)sl->keys_b.p;
+  u32* vals_a = (u32*)sl->vals_a.p;
+  u32* vals_b = (u32*)sl->vals_b.p;
 
-  u32* keys_a = (u32*)ctx->keys_a.p;
-  u32* keys_b = (u32*)ctx->keys_b.p;
-  u32* vals_a = (u32*)ctx->vals_a.p;
-  u32* vals_b = (u32*)ctx->vals_b.p;
-
-  HIP_TRY(hipMemsetAsync(ctx->misc.p, 0, 64, st));
-  stage_mark(ctx, ST_DIGITS);
+  HIP_TRY(hipMemsetAsync(sl->misc.p, 0, 64, st));
+  stage_mark(ctx, sl, ST_DIGITS);
   launch_digits<Fr>(st, (const u32*)d_scalars, scalars_mont, g, keys_a, vals_a, d_err);
-  stage_mark(ctx, ST_SORT);
+  stage_mark(ctx, sl, ST_SORT);
   {
     int bits = 1;
     while ((1u << bits) <= g.B) bits++;
     size_t tmp = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)g.E, 0u, (unsigned)bits, st));
-    TRY(ensure(ctx->sort_tmp, tmp));
-    tmp = ctx->sort_tmp.bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)g.E, 0u,
+    TRY(ensure(sl->sort_tmp, tmp));
+    tmp = sl->sort_tmp.bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(sl->sort_tmp.p, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)g.E, 0u,
                                       (unsigned)bits, st));
   }
-  stage_mark(ctx, ST_BOUNDS);
-  launch_bounds(st, (const u32*)keys_b, g, (u32*)ctx->start.p, (u32*)ctx->items.p);
+  stage_mark(ctx, sl, ST_BOUNDS);
+  launch_bounds(st, (const u32*)keys_b, g, (u32*)sl->start.p, (u32*)sl->items.p);
   {
     size_t tmp = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, (u32*)ctx->items.p, (u32*)ctx->item_off.p, 0u, (size_t)(g.B + 1),
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, (u32*)sl->items.p, (u32*)sl->item_off.p, 0u, (size_t)(g.B + 1),
                                     rocprim::plus<u32>(), st));
-    TRY(ensure(ctx->scan_tmp, tmp));
-    tmp = ctx->scan_tmp.bytes;
-    HIP_TRY(rocprim::exclusive_scan(ctx->scan_tmp.p, tmp, (u32*)ctx->items.p, (u32*)ctx->item_off.p, 0u,
+    TRY(ensure(sl->scan_tmp, tmp));
+    tmp = sl->scan_tmp.bytes;
+    HIP_TRY(rocprim::exclusive_scan(sl->scan_tmp.p, tmp, (u32*)sl->items.p, (u32*)sl->item_off.p, 0u,
                                     (size_t)(g.B + 1), rocprim::plus<u32>(), st));
   }
-  stage_mark(ctx, ST_ACCUM_L0);
-  launch_accum_l0<Fq>(st, max_items, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)ctx->start.p,
-                      (const u32*)ctx->item_off.p, g, (u32*)ctx->partials.p);
-  stage_mark(ctx, ST_ACCUM_L12);
-  launch_accum_l1<Fq>(st, (const u32*)ctx->partials.p, (const u32*)ctx->items.p, (const u32*)ctx->item_off.p, g,
-                      (u32*)ctx->buckets.p, d_heavy_count, (u32*)ctx->heavy.p);
-  launch_accum_l2<Fq>(st, (const u32*)ctx->partials.p, (const u32*)ctx->items.p, (const u32*)ctx->item_off.p,
-                      (const u32*)d_heavy_count, (const u32*)ctx->heavy.p, (u32*)ctx->buckets.p);
-  stage_mark(ctx, ST_REDUCE);
-  launch_bucket_reduce<Fq>(st, red_blocks, (const u32*)ctx->buckets.p, g, (u32*)ctx->red_out.p);
-  launch_fold<Fq>(st, g.n_sets, (const u32*)ctx->red_out.p, red_blocks, (u32*)ctx->fold_out.p);
-  stage_mark(ctx, ST_COUNT);
+  stage_mark(ctx, sl, ST_ACCUM_L0);
+  launch_accum_l0<Fq>(st, (const u32*)bases->d_table, (const u32*)keys_b, (const u32*)vals_b, (const u32*)sl->start.p,
+                      (const u32*)sl->item_off.p, g, (u32*)sl->partials.p);
+  HIP_TRY(hipEventRecord(sl->l0_done, st));
+  hipStream_t tl = sl->tail;
+  HIP_TRY(hipStreamWaitEvent(tl, sl->l0_done, 0));
+  if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_ACCUM_L12], tl);
+  launch_accum_l1<Fq>(tl, l1_lanes(g), (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
+                      g, (u32*)sl->buckets.p, d_heavy_count, (u32*)sl->heavy.p);
+  launch_accum_l2<Fq>(tl, (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
+                      (const u32*)d_heavy_count, (const u32*)sl->heavy.p, (u32*)sl->buckets.p);
+  if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_REDUCE], tl);
+  launch_bucket_reduce<Fq>(tl, red_blocks, (const u32*)sl->buckets.p, g, (u32*)sl->red_out.p);
+  launch_fold<Fq>(tl, g.n_sets, (const u32*)sl->red_out.p, red_blocks, (u32*)sl->fold_out.p);
+  if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_COUNT], tl);
   HIP_TRY(hipGetLastError());
+  u32* h = (u32*)sl->h_pinned;
+  HIP_TRY(hipMemcpyAsync(h, sl->fold_out.p, g.n_sets * rec, hipMemcpyDeviceToHost, tl));
+  HIP_TRY(hipMemcpyAsync((char*)h + g.n_sets * rec, sl->misc.p, 8, hipMemcpyDeviceToHost, tl));
+  HIP_TRY(hipEventRecord(sl->done, tl));
+  sl->busy = true;
   return AMSM_OK;
 }
 
-// D2H of the folded records + error flag, host Horner (plain key) -> one XYZZ on the host.
+// Wait for slot `sl`, then host Horner over the window sums (plain key) -> one XYZZ on the host.
 template <class Fq>
-int msm_collect(amsm_ctx* ctx, const MsmGeom& g, host::HXYZZ<Fq>* out) {
+int msm_collect(amsm_ctx* ctx, Slot* sl, host::HXYZZ<Fq>* out) {
+  const MsmGeom& g = sl->geom;
   size_t rec = xyzz_bytes<Fq>();
-  TRY(ensure_pinned(ctx, g.n_sets * rec + 64));
-  u32* h = (u32*)ctx->h_pinned;
-  HIP_TRY(hipMemcpyAsync(h, ctx->fold_out.p, g.n_sets * rec, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync((char*)h + g.n_sets * rec, ctx->misc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipEventSynchronize(sl->done));
+  sl->busy = false;
   if (ctx->profiling) {
-    for (int s = 0; s < ST_COUNT; s++) (void)hipEventElapsedTime(&ctx->stage_ms[s], ctx->ev[s], ctx->ev[s + 1]);
+    for (int s = 0; s < ST_COUNT; s++) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, sl->ev[s], sl->ev[s + 1]);
+      ctx->stage_acc[s] += ms;
+    }
+    ctx->stage_n++;
   }
+  u32* h = (u32*)sl->h_pinned;
   u32 err = *(u32*)((char*)h + g.n_sets * rec);
   if (err) return AMSM_E_SCALAR_RANGE;
   host::HXYZZ<Fq> acc = host::hx_from_device<Fq>(h + (size_t)(g.n_sets - 1) * (rec / 4));
@@ -292,6 +346,15 @@ int msm_collect(amsm_ctx* ctx, const MsmGeom& g, host::HXYZZ<Fq>* out) {
   return AMSM_OK;
 }
 
+void stage_begin(amsm_ctx* ctx) {
+  for (int s = 0; s < ST_COUNT; s++) ctx->stage_acc[s] = 0;
+  ctx->stage_n = 0;
+}
+void stage_end(amsm_ctx* ctx) {
+  if (!ctx->stage_n) return;
+  for (int s = 0; s < ST_COUNT; s++) ctx->stage_ms[s] = ctx->stage_acc[s] / ctx->stage_n;
+}
+
 template <class Fq, class Fr>
 int msm_device_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
                     int scalars_mont, host::HXYZZ<Fq>* out) {
@@ -301,9 +364,73 @@ int msm_device_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, con
     *out = host::hx_inf<Fq>();
     return AMSM_OK;
   }
-  MsmGeom g;
-  TRY((msm_pipeline<Fq, Fr>(ctx, bases, base_off, d_scalars, n, scalars_mont, &g)));
-  return msm_collect<Fq>(ctx, g, out);
+  stage_begin(ctx);
+  TRY((msm_enqueue<Fq, Fr>(ctx, &ctx->slot[0], bases, base_off, d_scalars, n, scalars_mont)));
+  int rc = msm_collect<Fq>(ctx, &ctx->slot[0], out);
+  stage_end(ctx);
+  return rc;
+}
+
+// n_vecs MSMs over the same key, N_SLOTS in flight (slot 0 heads run on the context's stream).
+template <class Fq, class Fr>
+int msm_batch_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* const* d_scalars,
+                   size_t n_vecs, size_t n, int scalars_mont, std::vector<host::HXYZZ<Fq>>* out) {
+  if (base_off > bases->n) return AMSM_E_INVALID_ARG;
+  n = std::min(n, bases->n - base_off);
+  out->assign(n_vecs, host::hx_inf<Fq>());
+  if (n == 0 || n_vecs == 0) return AMSM_OK;
+  stage_begin(ctx);
+  // work already queued on the caller's stream (e.g. the kernels that produced the scalars) must be
+  // visible to the second stream
+  HIP_TRY(hipEventRecord(ctx->fork, ctx->slot[0].stream));
+  for (int k = 1; k < N_SLOTS; k++) HIP_TRY(hipStreamWaitEvent(ctx->slot[k].stream, ctx->fork, 0));
+  int rc = AMSM_OK;
+  for (size_t v = 0; v < n_vecs && rc == AMSM_OK; v++) {
+    Slot* sl = &ctx->slot[v % N_SLOTS];
+    if (sl->busy) rc = msm_collect<Fq>(ctx, sl, &(*out)[v - N_SLOTS]);
+    if (rc == AMSM_OK) rc = msm_enqueue<Fq, Fr>(ctx, sl, bases, base_off, d_scalars[v], n, scalars_mont);
+  }
+  for (size_t v = (n_vecs >= (size_t)N_SLOTS ? n_vecs - N_SLOTS : 0); v < n_vecs; v++) {
+    Slot* sl = &ctx->slot[v % N_SLOTS];
+    if (sl->busy) {
+      int r2 = msm_collect<Fq>(ctx, sl, &(*out)[v]);
+      if (rc == AMSM_OK) rc = r2;
+    }
+  }
+  stage_end(ctx);
+  return rc;
+}
+
+// batch_normalization_into_affine (src/hp_as/mod.rs:468): one inversion for the whole batch
+template <class Fq>
+void write_affine_batch(const std::vector<host::HXYZZ<Fq>>& pts, uint64_t* out_xy, uint8_t* out_is_inf) {
+  using H = host::HFe<Fq>;
+  constexpr int N = H::N;
+  size_t k = pts.size();
+  std::vector<H> z(k), pre(k);
+  H run = host::h_one<Fq>();
+  for (size_t i = 0; i < k; i++) {
+    bool inf = host::hx_is_inf<Fq>(pts[i]);
+    z[i] = inf ? host::h_one<Fq>() : host::h_mul<Fq>(pts[i].zz, pts[i].zzz);
+    pre[i] = run;
+    run = host::h_mul<Fq>(run, z[i]);
+  }
+  H inv = host::h_inv<Fq>(run);
+  for (size_t i = k; i-- > 0;) {
+    H zi = host::h_mul<Fq>(inv, pre[i]);  // 1 / (zz*zzz)
+    inv = host::h_mul<Fq>(inv, z[i]);
+    uint64_t* o = out_xy + i * 2 * N;
+    if (host::hx_is_inf<Fq>(pts[i])) {
+      memset(o, 0, 16 * N);
+      if (out_is_inf) out_is_inf[i] = 1;
+      continue;
+    }
+    H x = host::h_mul<Fq>(pts[i].x, host::h_mul<Fq>(zi, pts[i].zzz));
+    H y = host::h_mul<Fq>(pts[i].y, host::h_mul<Fq>(zi, pts[i].zz));
+    memcpy(o, x.v, 8 * N);
+    memcpy(o + N, y.v, 8 * N);
+    if (out_is_inf) out_is_inf[i] = 0;
+  }
 }
 
 template <class Fq, class Fr>
@@ -469,14 +596,15 @@ int pedersen_impl(amsm_ctx* ctx, const amsm_bases* ck, const uint64_t* elems, si
 template <class Fq>
 int partials_combine_impl(amsm_ctx* ctx, const void* d_partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
   size_t rec = xyzz_bytes<Fq>();
-  TRY(ensure_pinned(ctx, count * rec));
+  Slot* sl = &ctx->slot[0];
+  TRY(ensure_pinned(sl, count * rec));
   if (count) {
-    HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_partials, count * rec, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(sl->h_pinned, d_partials, count * rec, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   host::HXYZZ<Fq> acc = host::hx_inf<Fq>();
   for (size_t i = 0; i < count; i++)
-    acc = host::hx_add<Fq>(acc, host::hx_from_device<Fq>((const u32*)ctx->h_pinned + i * (rec / 4)));
+    acc = host::hx_add<Fq>(acc, host::hx_from_device<Fq>((const u32*)sl->h_pinned + i * (rec / 4)));
   write_affine<Fq>(acc, out_xy, out_inf);
   return AMSM_OK;
 }
@@ -485,8 +613,9 @@ int partials_combine_impl(amsm_ctx* ctx, const void* d_partials, size_t count, u
 template <class Fq>
 int upload_xyzz(amsm_ctx* ctx, const host::HXYZZ<Fq>& p, void* d_out) {
   size_t rec = xyzz_bytes<Fq>();
-  TRY(ensure_pinned(ctx, rec));
-  u32* h = (u32*)ctx->h_pinned;
+  Slot* sl = &ctx->slot[0];
+  TRY(ensure_pinned(sl, rec + 64));
+  u32* h = (u32*)sl->h_pinned;
   memcpy(h, p.x.v, rec / 4);
   memcpy(h + Fq::L, p.y.v, rec / 4);
   memcpy(h + 2 * Fq::L, p.zz.v, rec / 4);
@@ -502,20 +631,23 @@ int msm_partial_impl(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, co
   if (base_off > bases->n) return AMSM_E_INVALID_ARG;
   n = std::min(n, bases->n - base_off);
   if (n == 0) return upload_xyzz<Fq>(ctx, host::hx_inf<Fq>(), d_out);
-  MsmGeom g;
-  TRY((msm_pipeline<Fq, Fr>(ctx, bases, base_off, d_scalars, n, mont, &g)));
-  if (g.n_sets == 1) {
-    // single folded record: stays on the device; only the range flag comes back
-    HIP_TRY(hipMemcpyAsync(d_out, ctx->fold_out.p, xyzz_bytes<Fq>(), hipMemcpyDeviceToDevice, ctx->stream));
-    TRY(ensure_pinned(ctx, 64));
-    HIP_TRY(hipMemcpyAsync(ctx->h_pinned, ctx->misc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->profiling)
-      for (int s = 0; s < ST_COUNT; s++) (void)hipEventElapsedTime(&ctx->stage_ms[s], ctx->ev[s], ctx->ev[s + 1]);
-    return *(u32*)ctx->h_pinned ? AMSM_E_SCALAR_RANGE : AMSM_OK;
+  Slot* sl = &ctx->slot[0];
+  stage_begin(ctx);
+  TRY((msm_enqueue<Fq, Fr>(ctx, sl, bases, base_off, d_scalars, n, mont)));
+  if (sl->geom.n_sets == 1) {
+    // single folded record: it stays on the device (copied record-to-record); the host only waits for
+    // the range flag
+    HIP_TRY(hipMemcpyAsync(d_out, sl->fold_out.p, xyzz_bytes<Fq>(), hipMemcpyDeviceToDevice, sl->tail));
+    HIP_TRY(hipEventRecord(sl->done, sl->tail));
+    host::HXYZZ<Fq> unused;
+    int rc = msm_collect<Fq>(ctx, sl, &unused);
+    stage_end(ctx);
+    return rc;
   }
   host::HXYZZ<Fq> acc;
-  TRY(msm_collect<Fq>(ctx, g, &acc));
+  int rc = msm_collect<Fq>(ctx, sl, &acc);
+  stage_end(ctx);
+  if (rc != AMSM_OK) return rc;
   return upload_xyzz<Fq>(ctx, acc, d_out);
 }
 
@@ -618,22 +750,40 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   if (!c) return AMSM_E_OOM;
   c->curve = curve;
   c->device = device_id;
+  bool ok = true;
   if (stream) {
-    c->stream = (hipStream_t)stream;
+    c->slot[0].stream = (hipStream_t)stream;
   } else {
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-      delete c;
-      return AMSM_E_HIP;
-    }
-    c->own_stream = true;
+    ok = ok && hipStreamCreateWithFlags(&c->slot[0].stream, hipStreamNonBlocking) == hipSuccess;
+    c->slot[0].own_stream = ok;
   }
-  for (int i = 0; i <= ST_COUNT; i++) {
-    if (hipEventCreate(&c->ev[i]) != hipSuccess) {
-      delete c;
-      return AMSM_E_HIP;
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  for (int k = 0; k < N_SLOTS && ok; k++) {
+    if (k > 0) {
+      ok = ok && hipStreamCreateWithFlags(&c->slot[k].stream, hipStreamNonBlocking) == hipSuccess;
+      c->slot[k].own_stream = ok;
     }
+    ok = ok && hipStreamCreateWithPriority(&c->slot[k].tail, hipStreamNonBlocking, prio_hi) == hipSuccess;
   }
-  if (const char* e = getenv("AMSM_K0")) c->K0 = std::max(1, atoi(e));
+  c->stream = c->slot[0].stream;
+  for (int k = 0; k < N_SLOTS && ok; k++) {
+    for (int i = 0; i <= ST_COUNT && ok; i++) ok = hipEventCreate(&c->slot[k].ev[i]) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->slot[k].l0_done, hipEventDisableTiming) == hipSuccess;
+  }
+  ok = ok && hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    amsm_ctx_destroy(c);
+    return AMSM_E_HIP;
+  }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+      c->wave_slots = prop.multiProcessorCount * 4 * 4;
+  }
+  if (const char* e = getenv("AMSM_K0")) c->K0 = std::max(0, atoi(e));
   if (const char* e = getenv("AMSM_K1")) c->K1 = std::max(1, atoi(e));
   if (const char* e = getenv("AMSM_RED_S")) c->red_s = std::max(1, atoi(e));
   if (const char* e = getenv("AMSM_WINDOW")) c->window_override = atoi(e);
@@ -644,15 +794,25 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
 void amsm_ctx_destroy(amsm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->keys_a, &c->keys_b, &c->vals_a, &c->vals_b, &c->start, &c->items, &c->item_off, &c->partials,
-                    &c->buckets, &c->red_out, &c->fold_out, &c->heavy, &c->misc, &c->sort_tmp, &c->scan_tmp, &c->scalars};
-  for (DevBuf* b : bufs)
-    if (b->p) (void)hipFree(b->p);
-  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-  for (int i = 0; i <= ST_COUNT; i++)
-    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  for (int k = 0; k < N_SLOTS; k++) {
+    Slot* sl = &c->slot[k];
+    if (sl->stream) (void)hipStreamSynchronize(sl->stream);
+    if (sl->tail) (void)hipStreamSynchronize(sl->tail);
+    DevBuf* bufs[] = {&sl->keys_a, &sl->keys_b, &sl->vals_a, &sl->vals_b, &sl->start, &sl->items, &sl->item_off,
+                      &sl->partials, &sl->buckets, &sl->red_out, &sl->fold_out, &sl->heavy, &sl->misc, &sl->sort_tmp,
+                      &sl->scan_tmp};
+    for (DevBuf* b : bufs)
+      if (b->p) (void)hipFree(b->p);
+    if (sl->h_pinned) (void)hipHostFree(sl->h_pinned);
+    for (int i = 0; i <= ST_COUNT; i++)
+      if (sl->ev[i]) (void)hipEventDestroy(sl->ev[i]);
+    if (sl->done) (void)hipEventDestroy(sl->done);
+    if (sl->l0_done) (void)hipEventDestroy(sl->l0_done);
+    if (sl->tail) (void)hipStreamDestroy(sl->tail);
+    if (sl->own_stream && sl->stream) (void)hipStreamDestroy(sl->stream);
+  }
+  if (c->fork) (void)hipEventDestroy(c->fork);
+  if (c->scalars.p) (void)hipFree(c->scalars.p);
   delete c;
 }
 
@@ -666,7 +826,10 @@ int amsm_ctx_set_window(amsm_ctx* c, int bits) {
 int amsm_ctx_synchronize(amsm_ctx* c) {
   if (!c) return AMSM_E_INVALID_ARG;
   TRY(bind_device(c));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < N_SLOTS; k++) {
+    HIP_TRY(hipStreamSynchronize(c->slot[k].stream));
+    HIP_TRY(hipStreamSynchronize(c->slot[k].tail));
+  }
   return AMSM_OK;
 }
 int amsm_ctx_set_profiling(amsm_ctx* c, int on) {
@@ -746,10 +909,20 @@ int amsm_msm_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* d_
 
 int amsm_msm_batch_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* const* d_scalars, size_t n_vecs,
                           size_t n, int mont, uint64_t* out_xy, uint8_t* out_inf) {
-  if (!c || !b || (n_vecs && (!d_scalars || !out_xy))) return AMSM_E_INVALID_ARG;
-  size_t stride = 2 * (size_t)amsm_ctx_fq_limbs(c);
+  if (!c || !b || (n_vecs && (!d_scalars || !out_xy)) || b->curve != c->curve || b->device != c->device)
+    return AMSM_E_INVALID_ARG;
   for (size_t v = 0; v < n_vecs; v++)
-    TRY(amsm_msm_device(c, b, off, d_scalars[v], n, mont, out_xy + v * stride, out_inf ? out_inf + v : nullptr));
+    if (n && !d_scalars[v]) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (c->curve == AMSM_PALLAS) {
+    std::vector<host::HXYZZ<PallasFq>> r;
+    TRY((msm_batch_xyzz<PallasFq, PallasFr>(c, b, off, d_scalars, n_vecs, n, mont, &r)));
+    write_affine_batch<PallasFq>(r, out_xy, out_inf);
+  } else {
+    std::vector<host::HXYZZ<Bls12381Fq>> r;
+    TRY((msm_batch_xyzz<Bls12381Fq, Bls12381Fr>(c, b, off, d_scalars, n_vecs, n, mont, &r)));
+    write_affine_batch<Bls12381Fq>(r, out_xy, out_inf);
+  }
   return AMSM_OK;
 }
 

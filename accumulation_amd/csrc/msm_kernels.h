@@ -30,72 +30,55 @@ namespace amsm {
 
 
 // ---------------------------------------------------------------------------------------------
-// accumulate L0: lane g handles work item g = (bucket b, slice j): <= K0 gathered mixed adds.
+// accumulate L0: lane c owns the fixed-size chunk [c*K0, (c+1)*K0) of the SORTED entry list, whatever
+// buckets it spans: every lane does exactly K0 gathered mixed additions, so all SIMDs stay at full
+// occupancy until the end of the kernel and wave64 lanes stay converged for ANY digit distribution
+// (uniform, or the all-equal vectors of SURVEY.md F8).  When the bucket id changes inside a chunk the
+// lane flushes its running sum as one partial of the finished bucket.  The partials of bucket b are the
+// consecutive records item_off[b] + (chunk - first_chunk(b)); k_bounds counted them (items[b]).
 // ---------------------------------------------------------------------------------------------
 template <class Fq>
 __global__ void __launch_bounds__(256)
-    k_accum_l0(const u32* __restrict__ table, const u32* __restrict__ vals_sorted, const u32* __restrict__ start,
-               const u32* __restrict__ item_off, MsmGeom g, u32* __restrict__ partials) {
-  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 total = item_off[g.B];
-  if (gid >= total) return;
-  // largest b with item_off[b] <= gid  (empty buckets have item_off[b] == item_off[b+1])
-  u32 lo = 0, hi = g.B;
-  while (lo < hi) {
-    u32 mid = (lo + hi + 1) >> 1;
-    if (item_off[mid] <= gid) lo = mid; else hi = mid - 1;
-  }
-  u32 b = lo;
-  u32 j = gid - item_off[b];
-  u32 s = start[b] + j * g.K0;
-  u32 e = min(s + g.K0, start[b + 1]);
+    k_accum_l0(const u32* __restrict__ table, const u32* __restrict__ keys_sorted, const u32* __restrict__ vals_sorted,
+               const u32* __restrict__ start, const u32* __restrict__ item_off, MsmGeom g, u32* __restrict__ partials) {
+  u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 e_valid = start[g.B];  // entries with a non-zero digit (key B = digit 0 sorts last)
+  u32 s = c * g.K0;
+  if (s >= e_valid) return;
+  u32 e = min(s + g.K0, e_valid);
   XYZZ<Fq> acc = xyzz_inf<Fq>();
-  // software pipeline: entry index two ahead, point one ahead (the vals -> point loads are dependent)
+  // software pipeline: entry (key, value) two ahead, point one ahead (vals -> point loads are dependent);
+  // issued unconditionally (the tail re-reads its last entry) so hipcc keeps them in flight across the
+  // long mixed addition instead of branching around them
   u32 v = vals_sorted[s];
-  u32 v1 = vals_sorted[min(s + 1, e - 1)];
+  u32 b_cur = keys_sorted[s];
+  u32 i1 = min(s + 1, e - 1);
+  u32 v1 = vals_sorted[i1], k1 = keys_sorted[i1];
   Affine<Fq> pt = affine_load<Fq>(table, v & 0x7fffffffu);
   for (u32 k = s; k < e; k++) {
-    // issued unconditionally (the tail re-reads its last entry) so hipcc keeps the loads in flight
-    // across the long mixed addition instead of branching around them
-    u32 v2 = vals_sorted[min(k + 2, e - 1)];
+    u32 i2 = min(k + 2, e - 1);
+    u32 v2 = vals_sorted[i2], k2 = keys_sorted[i2];
     Affine<Fq> ptn = affine_load<Fq>(table, v1 & 0x7fffffffu);
     xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (v >> 31) != 0));
+    if (k1 != b_cur || k + 1 == e) {  // bucket finished inside this chunk (or chunk finished): flush
+      u32 slot = item_off[b_cur] + (c - start[b_cur] / g.K0);
+      xyzz_store<Fq>(partials, slot, acc);
+      acc = xyzz_inf<Fq>();
+      b_cur = k1;
+    }
     v = v1;
     v1 = v2;
+    k1 = k2;
     pt = ptn;
   }
-  xyzz_store<Fq>(partials, gid, acc);
 }
 
-// ---------------------------------------------------------------------------------------------
-// accumulate L1: lane b folds the partials of bucket b (<= K1), else records it as heavy.
-// ---------------------------------------------------------------------------------------------
-template <class Fq>
-__global__ void __launch_bounds__(256)
-    k_accum_l1(const u32* __restrict__ partials, const u32* __restrict__ items, const u32* __restrict__ item_off,
-               MsmGeom g, u32* __restrict__ buckets, u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
-  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= g.B) return;
-  u32 n = items[b];
-  if (n > g.K1) {
-    u32 slot = atomicAdd(heavy_count, 1u);
-    heavy_list[slot] = b;
-    return;
-  }
-  XYZZ<Fq> acc = xyzz_inf<Fq>();
-  u32 off = item_off[b];
-  for (u32 k = 0; k < n; k++) {
-    XYZZ<Fq> p = xyzz_load<Fq>(partials, off + k);
-    xyzz_add<Fq>(acc, p);
-  }
-  xyzz_store<Fq>(buckets, b, acc);
-}
-
-// Wave64 butterfly reduction of one XYZZ per lane with __shfl_xor; every lane ends with the sum.
-template <class Fq>
-AMSM_DEV void wave_reduce_xyzz(XYZZ<Fq>& acc) {
+// Butterfly reduction of one XYZZ per lane over aligned groups of WIDTH lanes (WIDTH = 64: whole wave) with
+// __shfl_xor; every lane of a group ends with the group's sum.  All 64 lanes must be active.
+template <class Fq, int WIDTH>
+AMSM_DEV void group_reduce_xyzz(XYZZ<Fq>& acc) {
 #pragma unroll 1
-  for (int m = 32; m >= 1; m >>= 1) {
+  for (int m = WIDTH / 2; m >= 1; m >>= 1) {
     XYZZ<Fq> o;
 #pragma unroll
     for (int i = 0; i < Fq::L; i++) {
@@ -110,6 +93,44 @@ AMSM_DEV void wave_reduce_xyzz(XYZZ<Fq>& acc) {
     XYZZ<Fq> b2 = low ? o : acc;
     xyzz_add<Fq>(a, b2);
     acc = a;
+  }
+}
+
+template <class Fq>
+AMSM_DEV void wave_reduce_xyzz(XYZZ<Fq>& acc) {
+  group_reduce_xyzz<Fq, 64>(acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// accumulate L1: LPB lanes cooperate on bucket b: lane j sums partials j, j+LPB, ... then a shuffle
+// butterfly over the LPB lanes (latency log2(LPB) + n/LPB additions instead of n).  Buckets with more
+// than K1 partials are recorded as heavy for L2.
+// ---------------------------------------------------------------------------------------------
+template <class Fq, int LPB>
+__global__ void __launch_bounds__(256)
+    k_accum_l1(const u32* __restrict__ partials, const u32* __restrict__ items, const u32* __restrict__ item_off,
+               MsmGeom g, u32* __restrict__ buckets, u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
+  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 b = gid / LPB, j = gid % LPB;
+  bool valid = b < g.B;
+  u32 n = valid ? items[b] : 0u;
+  bool heavy = n > g.K1;
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  if (valid && !heavy) {
+    u32 off = item_off[b];
+    for (u32 k = j; k < n; k += LPB) {
+      XYZZ<Fq> p = xyzz_load<Fq>(partials, off + k);
+      xyzz_add<Fq>(acc, p);
+    }
+  }
+  if (LPB > 1) group_reduce_xyzz<Fq, LPB>(acc);
+  if (valid && j == 0) {
+    if (heavy) {
+      u32 slot = atomicAdd(heavy_count, 1u);
+      heavy_list[slot] = b;
+    } else {
+      xyzz_store<Fq>(buckets, b, acc);
+    }
   }
 }
 

@@ -137,7 +137,9 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------------------------------------
-// bounds: start[b] = first sorted entry with key >= b (b = 0..B); items[b] = ceil(len_b / K0).
+// bounds: start[b] = first sorted entry with key >= b (b = 0..B); items[b] = number of K0-sized chunks
+// of the sorted entry list that bucket b's run [start[b], start[b+1]) touches = number of partials
+// k_accum_l0 will write for it.
 // ---------------------------------------------------------------------------------------------
 AMSM_DEV u32 lower_bound_u32(const u32* __restrict__ a, u32 n, u32 x) {
   u32 lo = 0, hi = n;
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256)
   u32 lo = lower_bound_u32(keys_sorted, g.E, b);
   u32 hi = lower_bound_u32(keys_sorted, g.E, b + 1);
   start[b] = lo;
-  items[b] = (hi - lo + g.K0 - 1) / g.K0;
+  items[b] = hi > lo ? (hi - 1) / g.K0 - lo / g.K0 + 1 : 0u;
   if (b == g.B - 1) {
     start[g.B] = hi;
     items[g.B] = 0;

@@ -45,6 +45,7 @@ def main() -> int:
     ap.add_argument("--curve", default="pallas", choices=["pallas", "bls12_381_g1"])
     ap.add_argument("--no-precompute", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync", action="store_true", help="one synchronous MSM call per step (no MSMs overlapped)")
     ap.add_argument("--cpu-log2n", type=int, default=None, help="sample size of the CPU baseline (default: log2n)")
     args = ap.parse_args()
 
@@ -77,23 +78,32 @@ def main() -> int:
         t0 = time.time()
         ck = CommitterKey.generate(ctx, SEED_POINTS + rank, n, flags)
         t_key = time.time() - t0
-        scalars = ctx.random_vector(SEED_SCALARS + rank, n, mont=False)
+        # four distinct scalar vectors, cycled over the steps (step k uses vector k % 4)
+        n_distinct = 4
+        vecs = [ctx.random_vector(SEED_SCALARS + 1000 * j + rank, n, mont=False) for j in range(n_distinct)]
+        scalars = vecs[0]
         ctx.synchronize()
-        out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
-        inf = C.c_uint8(0)
         sharded = None
         if world > 1:
             from accumulation_amd.dist import HipEngine, ShardedMSM
             sharded = ShardedMSM(HipEngine(ctx, ck))
         last = {}
 
-        def step():
-            if world == 1:
-                ffi.check(ctx._lib.amsm_msm_device(ctx._h, ck._h, 0, scalars.ptr, n, 0, _ptr(out), C.byref(inf)),
-                          "amsm_msm_device")
+        def run_steps(k):
+            """k steps = k MSMs.  N = 1: one batch call (the ABI keeps two MSMs in flight so the latency-bound
+            tail of one overlaps the head of the next, like the prover's back-to-back commits of
+            src/hp_as/mod.rs:354-388).  N > 1: per step local MSM -> 1 partial record -> RCCL all-gather of
+            raw bytes -> identical fold on every rank."""
+            if world == 1 and args.sync:
+                for i in range(k):
+                    last["xy"], last["inf"] = VariableBaseMSM.multi_scalar_mul(ck, vecs[i % n_distinct])
+            elif world == 1:
+                pts, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [vecs[i % n_distinct] for i in range(k)],
+                                                                   mont=False)
+                last["xy"], last["inf"] = pts[0], bool(infs[0])
             else:
-                # local MSM -> 1 partial record -> RCCL all-gather (raw bytes) -> identical fold on every rank
-                last["xy"], last["inf"] = sharded.msm(scalars, mont=False)
+                for i in range(k):
+                    last["xy"], last["inf"] = sharded.msm(vecs[i % n_distinct], mont=False)
 
         def sync_all():
             torch.cuda.synchronize()
@@ -101,19 +111,23 @@ def main() -> int:
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(args.warmup):
-            step()
+        run_steps(args.warmup)
         ctx.set_profiling(True)
-        stage_sum = {}
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-            for k, v in ctx.stage_ms().items():
-                stage_sum[k] = stage_sum.get(k, 0.0) + v
+        run_steps(args.steps)
         sync_all()
         elapsed = time.perf_counter() - t0
+        stage_ms = ctx.stage_ms()
         ctx.set_profiling(False)
+        # latency of ONE synchronous MSM call (no overlap between consecutive MSMs), for reference
+        out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+        inf = C.c_uint8(0)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ffi.check(ctx._lib.amsm_msm_device(ctx._h, ck._h, 0, scalars.ptr, n, 0, _ptr(out), C.byref(inf)),
+                      "amsm_msm_device")
+        ms_sync = (time.perf_counter() - t1) / 5 * 1e3
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -122,7 +136,6 @@ def main() -> int:
     total_pairs = n * world * args.steps
     value = total_pairs / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
 
     result = None
     if rank == 0:
@@ -151,6 +164,8 @@ def main() -> int:
                 "precomputed_key": bool(ck.precomputed),
                 "parallelism": f"point-sharded x{world}" + (" + RCCL all-gather of 1 partial/rank" if world > 1 else ""),
                 "key_setup_s": round(t_key, 3),
+                "ms_per_msm_synchronous_call": round(ms_sync, 4),
+                "msms_in_flight": 2 if (world == 1 and not args.sync) else 1,
                 "seeds": {"scalars": SEED_SCALARS, "points": SEED_POINTS},
             },
             "roofline": {
@@ -167,7 +182,8 @@ def main() -> int:
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(ctx, ck, scalars, curve_id, args, out.copy(), bool(inf.value))
+            result["cpu_baseline"] = cpu_baseline(ctx, ck, scalars, curve_id, args, out.copy(), bool(inf.value),
+                                                  last["xy"], last["inf"])
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -175,7 +191,7 @@ def main() -> int:
     return 0
 
 
-def cpu_baseline(ctx, ck, scalars, curve_id, args, gpu_out, gpu_inf):
+def cpu_baseline(ctx, ck, scalars, curve_id, args, gpu_out, gpu_inf, batch_out, batch_inf):
     """Time the plain-C ark-ec-style restatement on the host cores, on the same inputs, and check the
     GPU result against it bit-for-bit.  (Only this leg of bench.py touches oracle/.)"""
     from oracle import cref
@@ -197,7 +213,8 @@ def cpu_baseline(ctx, ck, scalars, curve_id, args, gpu_out, gpu_inf):
     t_one = time.perf_counter() - t0
     match = None
     if m == len(ck):
-        match = bool(np.array_equal(cpu_out, gpu_out) and cpu_inf == gpu_inf)
+        match = bool(np.array_equal(cpu_out, gpu_out) and cpu_inf == gpu_inf
+                     and np.array_equal(cpu_out, batch_out) and cpu_inf == batch_inf)
     return {
         "value": m / t_par,
         "unit": "pairs/s",

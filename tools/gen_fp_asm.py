@@ -49,6 +49,8 @@ def emit_column_stmt(terms, first):
     for t, (x, xc, y, yc) in enumerate(terms):
         mads.append(f"v_mad_u64_u32 %[acc], {sg[t % 3]}, {operand(x, xc)}, {operand(y, yc)}, %[acc]")
     addcs = [f"v_addc_co_u32 %[c2], vcc, 0, %[c2], {sg[t % 3]}" for t in range(n)]
+    if first:  # c2 is write-only here: the first carry add initialises it (saves a v_mov per column)
+        addcs[0] = f"v_addc_co_u32 %[c2], vcc, 0, 0, {sg[0]}"
     # schedule: M1 M2 M3 A1 M4 A2 ... ; pad for short columns
     seq = []
     if n == 1:
@@ -71,7 +73,8 @@ def emit_column_stmt(terms, first):
                 assert pos[("m", t + 3)] > pos[("a", t)]
         seq = [mads[t] if kind == "m" else addcs[t] for kind, t in tagged]
     body = "\\n\\t".join(seq)
-    outs = '[acc] "+v"(acc), [c2] "+v"(c2), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)'
+    c2c = '"=&v"' if first else '"+v"'
+    outs = f'[acc] "+v"(acc), [c2] {c2c}(c2), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2)'
     return f'  asm volatile("{body}"\n               : {outs}\n               : {", ".join(ops_in)}\n               : "vcc");\n'
 
 
@@ -83,7 +86,7 @@ def gen_field(name):
     out.append("template <>")
     out.append(f"AMSM_DEV Fe<{name}> fe_mul<{name}>(const Fe<{name}>& a, const Fe<{name}>& b) {{")
     out.append("  u64 acc = 0, s0, s1, s2;")
-    out.append("  u32 c2 = 0;")
+    out.append("  u32 c2;")
     out.append(f"  u32 m[{L}];")
     out.append(f"  Fe<{name}> r;")
     # modulus constants as SGPR operands (wave-uniform), skip 0 and handle p0 in epilogue
@@ -122,13 +125,11 @@ def gen_field(name):
                 out.append("    u32 nlo = hi + cy;")
                 out.append("    u32 nhi = c2 + (nlo < cy ? 1u : 0u);")
             out.append("    acc = ((u64)nhi << 32) | nlo;")
-            out.append("    c2 = 0;")
             out.append("  }")
         else:
             out.append(f"  r.v[{k - L}] = (u32)acc;")
             if k < 2 * L - 1:
                 out.append("  acc = ((u64)c2 << 32) | (u32)(acc >> 32);")
-                out.append("  c2 = 0;")
     out.append(f"  fe_cond_sub<{name}>(r, (u32)(acc >> 32));")
     out.append("  return r;")
     out.append("}")
