@@ -79,6 +79,15 @@ struct amsm_bases {
   u32* d_table = nullptr;
 };
 
+struct amsm_matrix {
+  int curve = 0;
+  int device = 0;
+  size_t n_rows = 0, nnz = 0;
+  u32* d_row_ptr = nullptr;
+  u32* d_col = nullptr;
+  u32* d_val = nullptr;
+};
+
 namespace {
 
 #define HIP_TRY(expr)                                                                                  \
@@ -1022,6 +1031,61 @@ int amsm_vec_combine(amsm_ctx* c, const void* const* d_vecs, const size_t* lens,
   TRY(bind_device(c));
   return DISPATCH(c, (vec_combine_impl<PallasFr>(c, d_vecs, lens, n_vecs, coeffs, d_hiding, hiding_len, d_out, n)),
                   (vec_combine_impl<Bls12381Fr>(c, d_vecs, lens, n_vecs, coeffs, d_hiding, hiding_len, d_out, n)));
+}
+
+int amsm_matrix_load(amsm_ctx* c, const uint32_t* row_ptr, const uint32_t* col_idx, const uint64_t* vals, size_t n_rows,
+                     size_t nnz, amsm_matrix** out) {
+  if (!c || !out || !row_ptr || (nnz && (!col_idx || !vals)) || n_rows >= (1ull << 32) || nnz >= (1ull << 32))
+    return AMSM_E_INVALID_ARG;
+  if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  amsm_matrix* m = new (std::nothrow) amsm_matrix();
+  if (!m) return AMSM_E_OOM;
+  m->curve = c->curve;
+  m->device = c->device;
+  m->n_rows = n_rows;
+  m->nnz = nnz;
+  bool ok = hipMalloc((void**)&m->d_row_ptr, (n_rows + 1) * 4) == hipSuccess &&
+            hipMalloc((void**)&m->d_col, std::max<size_t>(nnz, 1) * 4) == hipSuccess &&
+            hipMalloc((void**)&m->d_val, std::max<size_t>(nnz, 1) * 32) == hipSuccess;
+  ok = ok && hipMemcpyAsync(m->d_row_ptr, row_ptr, (n_rows + 1) * 4, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+  if (ok && nnz) {
+    ok = hipMemcpyAsync(m->d_col, col_idx, nnz * 4, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+         hipMemcpyAsync(m->d_val, vals, nnz * 32, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+  }
+  ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    amsm_matrix_free(m);
+    return AMSM_E_OOM;
+  }
+  *out = m;
+  return AMSM_OK;
+}
+size_t amsm_matrix_rows(const amsm_matrix* m) { return m ? m->n_rows : 0; }
+void amsm_matrix_free(amsm_matrix* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->d_row_ptr) (void)hipFree(m->d_row_ptr);
+  if (m->d_col) (void)hipFree(m->d_col);
+  if (m->d_val) (void)hipFree(m->d_val);
+  delete m;
+}
+int amsm_matrix_vec_mul(amsm_ctx* c, const amsm_matrix* m, const void* d_input, size_t n_input, const void* d_witness,
+                        size_t n_witness, void* d_out) {
+  if (!c || !m || m->curve != c->curve || m->device != c->device || (m->n_rows && !d_out) ||
+      (n_input && !d_input) || (n_witness && !d_witness) || n_input >= (1ull << 32) || n_witness >= (1ull << 32))
+    return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (!m->n_rows) return AMSM_OK;
+  if (c->curve == AMSM_PALLAS)
+    launch_spmv<PallasFr>(c->stream, m->d_row_ptr, m->d_col, m->d_val, (const u32*)d_input, (u32)n_input,
+                          (const u32*)d_witness, (u32)n_witness, (u32*)d_out, (u32)m->n_rows);
+  else
+    launch_spmv<Bls12381Fr>(c->stream, m->d_row_ptr, m->d_col, m->d_val, (const u32*)d_input, (u32)n_input,
+                            (const u32*)d_witness, (u32)n_witness, (u32*)d_out, (u32)m->n_rows);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
 }
 
 int amsm_hp_t_vecs(amsm_ctx* c, const void* const* d_a, const size_t* a_lens, const void* const* d_b,

@@ -29,6 +29,12 @@ void launch_bounds(hipStream_t st, const u32* keys_sorted, MsmGeom g, u32* start
     hipLaunchKernelGGL((k_vec_combine<FR>), dim3(cdiv_(a.n, 256)), dim3(256), 0, st, a, out);                        \
   }                                                                                                                  \
   template <>                                                                                                        \
+  void launch_spmv<FR>(hipStream_t st, const u32* row_ptr, const u32* col, const u32* val, const u32* input,         \
+                       u32 n_input, const u32* witness, u32 n_witness, u32* out, u32 n_rows) {                       \
+    hipLaunchKernelGGL((k_spmv<FR>), dim3(cdiv_(n_rows, 256)), dim3(256), 0, st, row_ptr, col, val, input, n_input,   \
+                       witness, n_witness, out, n_rows);                                                             \
+  }                                                                                                                  \
+  template <>                                                                                                        \
   void launch_hp_t_vecs<FR>(hipStream_t st, const TVecArgs& a, int n_inputs) {                                       \
     dim3 grid(cdiv_(a.len, 256)), block(256);                                                                        \
     switch (n_inputs) {                                                                                              \

@@ -41,6 +41,10 @@ void launch_vec_combine(hipStream_t st, const CombineArgs& a, u32* out);
 template <class Fr>
 void launch_hp_t_vecs(hipStream_t st, const TVecArgs& a, int n_inputs);
 
+template <class Fr>
+void launch_spmv(hipStream_t st, const u32* row_ptr, const u32* col, const u32* val, const u32* input, u32 n_input,
+                 const u32* witness, u32 n_witness, u32* out, u32 n_rows);
+
 void launch_bounds(hipStream_t st, const u32* keys_sorted, MsmGeom g, u32* start, u32* items);
 
 }  // namespace amsm

@@ -85,6 +85,31 @@ __global__ void __launch_bounds__(256) k_hp_t_vecs(TVecArgs a) {
   }
 }
 
+// Row-sparse R1CS matrix times (input || witness): `matrix_vec_mul` / `inner_prod`,
+// src/r1cs_nark_as/r1cs_nark/mod.rs:443-462 (K7).  CSR in HBM: row_ptr (rows+1), col (nnz), val (nnz x 8 u32,
+// Montgomery).  One lane per row; the reference's "skip the multiplication when the coefficient is one"
+// (:459) is arithmetic-neutral and kept (it saves a Montgomery multiplication for the common +-1 entries).
+template <class Fr>
+__global__ void __launch_bounds__(256)
+    k_spmv(const u32* __restrict__ row_ptr, const u32* __restrict__ col, const u32* __restrict__ val,
+           const u32* __restrict__ input, u32 n_input, const u32* __restrict__ witness, u32 n_witness,
+           u32* __restrict__ out, u32 n_rows) {
+  u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  Fe<Fr> acc = fe_zero<Fr>();
+  Fe<Fr> one = fe_one<Fr>();
+  for (u32 k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+    u32 i = col[k];
+    Fe<Fr> x;
+    if (i < n_input) x = fe_load<Fr>(input + (size_t)i * 8);
+    else if (i - n_input < n_witness) x = fe_load<Fr>(witness + (size_t)(i - n_input) * 8);
+    else x = fe_zero<Fr>();
+    Fe<Fr> cf = fe_load<Fr>(val + (size_t)k * 8);
+    acc = fe_add<Fr>(acc, fe_eq<Fr>(cf, one) ? x : fe_mul<Fr>(x, cf));
+  }
+  fe_store<Fr>(out + (size_t)r * 8, acc);
+}
+
 template <class Fr>
 __global__ void __launch_bounds__(256) k_vec_random(u32* __restrict__ out, u64 seed, u32 n, int mont) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;

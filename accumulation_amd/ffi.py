@@ -67,6 +67,10 @@ SIGNATURES = {
     "amsm_vec_random": (C.c_int, [_vp, C.c_uint64, _sz, C.c_int, _vp]),
     "amsm_vec_hadamard": (C.c_int, [_vp, _vp, _vp, _vp, _sz]),
     "amsm_vec_combine": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _vp, _sz, _vp, _sz]),
+    "amsm_matrix_load": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, C.POINTER(_vp)]),
+    "amsm_matrix_rows": (_sz, [_vp]),
+    "amsm_matrix_free": (None, [_vp]),
+    "amsm_matrix_vec_mul": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "amsm_hp_t_vecs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _sz,
                                  _vp, _sz, _vp, _sz, C.POINTER(_vp), _sz]),
 }

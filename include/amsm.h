@@ -166,6 +166,22 @@ int amsm_hp_t_vecs(amsm_ctx* ctx, const void* const* d_a, const size_t* a_lens, 
                    const size_t* b_lens, size_t n_inputs, const uint64_t* mu_mont, size_t n_mu, const void* d_hiding_a,
                    size_t hiding_a_len, const void* d_hiding_b, size_t hiding_b_len, void* const* d_t, size_t len);
 
+/* ---- R1CS matrices (row-sparse) for the NARK prover -------------------------------------------- */
+typedef struct amsm_matrix amsm_matrix;
+/* Replaces `Matrix<F> = Vec<Vec<(F, usize)>>` of `IndexProverKey{a,b,c}`
+ * (src/r1cs_nark_as/r1cs_nark/data_structures.rs:33-48), flattened to CSR by the adapter:
+ * row_ptr (n_rows+1), col_idx (nnz), vals_mont (nnz*4 u64, Montgomery).  Copied to HBM once per index. */
+int amsm_matrix_load(amsm_ctx* ctx, const uint32_t* row_ptr, const uint32_t* col_idx, const uint64_t* vals_mont,
+                     size_t n_rows, size_t nnz, amsm_matrix** out);
+size_t amsm_matrix_rows(const amsm_matrix* m);
+void amsm_matrix_free(amsm_matrix* m);
+/* out[r] = sum_k val[k] * (input || witness)[col[k]]  -- `matrix_vec_mul(matrix, input, witness)`,
+ * src/r1cs_nark_as/r1cs_nark/mod.rs:443-462; call sites :183-185,194-196, src/r1cs_nark_as/mod.rs:329-339.
+ * d_input / d_witness / d_out are device vectors of Montgomery Fr elements; indices beyond
+ * n_input + n_witness read as zero. */
+int amsm_matrix_vec_mul(amsm_ctx* ctx, const amsm_matrix* m, const void* d_input, size_t n_input,
+                        const void* d_witness, size_t n_witness, void* d_out);
+
 #ifdef __cplusplus
 }
 #endif

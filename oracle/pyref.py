@@ -428,3 +428,49 @@ def compute_t_vecs(c: Curve, a_vecs: Sequence[Sequence[int]], b_vecs: Sequence[S
             for j in range(n):
                 t[i + j][li] = (t[i + j][li] + ac[i] * bc[j]) % c.r
     return t
+
+
+# --------------------------------------------------------------------------------------
+# R1CS NARK prover restatement (src/r1cs_nark_as/r1cs_nark/mod.rs:127-332, 443-462), canonical ints.
+# --------------------------------------------------------------------------------------
+
+
+def matrix_vec_mul(c: Curve, matrix: Sequence[Sequence[Tuple[int, int]]], inp: Sequence[int],
+                   wit: Sequence[int]) -> List[int]:
+    """matrix[r] = [(coeff, index), ...];  z = inp || wit  (:443-462)."""
+    out = []
+    for row in matrix:
+        acc = 0
+        for coeff, i in row:
+            tmp = inp[i] if i < len(inp) else wit[i - len(inp)]
+            acc = (acc + tmp * coeff) % c.r
+        out.append(acc)
+    return out
+
+
+def nark_prove(c: Curve, A, B, C_, generators: Sequence[Point], hiding_generator: Point, inp: Sequence[int],
+               wit: Sequence[int], make_zk: bool, rnd: Optional[dict], gamma_fn) -> dict:
+    """Same data flow as R1CSNark::prove; `rnd` holds the prover's random field elements (canonical ints),
+    gamma_fn(first_msg) the injected Fiat-Shamir challenge."""
+    def commit(v, blinder):
+        return pedersen_commit(c, generators, hiding_generator, v, blinder)
+    z_a, z_b, z_c = (matrix_vec_mul(c, M, inp, wit) for M in (A, B, C_))
+    if not make_zk:
+        first = {"comm_a": commit(z_a, None), "comm_b": commit(z_b, None), "comm_c": commit(z_c, None), "randomness": None}
+        return {"first_msg": first, "blinded_witness": list(wit), "gamma": gamma_fn(first)}
+    zeros = [0] * len(inp)
+    r = rnd["r"]
+    r_a, r_b, r_c = (matrix_vec_mul(c, M, zeros, r) for M in (A, B, C_))
+    first = {
+        "comm_a": commit(z_a, rnd["a_blinder"]), "comm_b": commit(z_b, rnd["b_blinder"]),
+        "comm_c": commit(z_c, rnd["c_blinder"]),
+        "randomness": {
+            "comm_r_a": commit(r_a, rnd["r_a_blinder"]), "comm_r_b": commit(r_b, rnd["r_b_blinder"]),
+            "comm_r_c": commit(r_c, rnd["r_c_blinder"]),
+            "comm_1": commit([(x * y + u * v) % c.r for x, y, u, v in zip(z_a, r_b, z_b, r_a)], rnd["blinder_1"]),
+            "comm_2": commit([(x * y) % c.r for x, y in zip(r_a, r_b)], rnd["blinder_2"]),
+        },
+    }
+    gamma = gamma_fn(first)
+    blinded = [(w + gamma * ri) % c.r for w, ri in zip(wit, r)]
+    return {"first_msg": first, "blinded_witness": blinded, "gamma": gamma}
