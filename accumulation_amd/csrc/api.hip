@@ -602,6 +602,38 @@ int pedersen_impl(amsm_ctx* ctx, const amsm_bases* ck, const uint64_t* elems, si
   return AMSM_OK;
 }
 
+template <class Fq, class Fr>
+int pedersen_device_impl(amsm_ctx* ctx, const amsm_bases* ck, const void* d_elems, size_t n, const uint64_t* rand_mont,
+                         const uint64_t* hiding_xy, uint64_t* out_xy, uint8_t* out_inf) {
+  host::HXYZZ<Fq> acc;
+  TRY((msm_device_xyzz<Fq, Fr>(ctx, ck, 0, d_elems, n, 1, &acc)));
+  if (rand_mont && hiding_xy) {
+    host::HFe<Fr> r;
+    memcpy(r.v, rand_mont, 32);
+    r = host::h_from_mont<Fr>(r);
+    host::HXYZZ<Fq> h = host::hx_from_affine<Fq>(hiding_xy, false);
+    acc = host::hx_add<Fq>(acc, host::hx_mul<Fq>(h, r.v));
+  }
+  write_affine<Fq>(acc, out_xy, out_inf);
+  return AMSM_OK;
+}
+
+template <class Fq, class Fr>
+int host_lincomb_impl(const uint64_t* xy, const uint8_t* is_inf, const uint64_t* scalars_mont, size_t n,
+                      uint64_t* out_xy, uint8_t* out_inf) {
+  constexpr int N = host::HFe<Fq>::N;
+  host::HXYZZ<Fq> acc = host::hx_inf<Fq>();
+  for (size_t i = 0; i < n; i++) {
+    host::HFe<Fr> s;
+    memcpy(s.v, scalars_mont + 4 * i, 32);
+    s = host::h_from_mont<Fr>(s);
+    host::HXYZZ<Fq> p = host::hx_from_affine<Fq>(xy + i * 2 * N, is_inf && is_inf[i]);
+    acc = host::hx_add<Fq>(acc, host::hx_mul<Fq>(p, s.v));
+  }
+  write_affine<Fq>(acc, out_xy, out_inf);
+  return AMSM_OK;
+}
+
 template <class Fq>
 int partials_combine_impl(amsm_ctx* ctx, const void* d_partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
   size_t rec = xyzz_bytes<Fq>();
@@ -964,6 +996,37 @@ int amsm_pedersen_commit(amsm_ctx* c, const amsm_bases* ck, const uint64_t* elem
   TRY(bind_device(c));
   return DISPATCH(c, (pedersen_impl<PallasFq, PallasFr>(c, ck, elems, n, rand_mont, hiding_xy, out_xy, out_inf)),
                   (pedersen_impl<Bls12381Fq, Bls12381Fr>(c, ck, elems, n, rand_mont, hiding_xy, out_xy, out_inf)));
+}
+
+int amsm_pedersen_commit_device(amsm_ctx* c, const amsm_bases* ck, const void* d_elems, size_t n,
+                                const uint64_t* rand_mont, const uint64_t* hiding_xy, uint64_t* out_xy, uint8_t* out_inf) {
+  if (!c || !ck || !out_xy || (n && !d_elems) || ck->curve != c->curve || ck->device != c->device)
+    return AMSM_E_INVALID_ARG;
+  if ((rand_mont == nullptr) != (hiding_xy == nullptr)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c, (pedersen_device_impl<PallasFq, PallasFr>(c, ck, d_elems, n, rand_mont, hiding_xy, out_xy, out_inf)),
+                  (pedersen_device_impl<Bls12381Fq, Bls12381Fr>(c, ck, d_elems, n, rand_mont, hiding_xy, out_xy,
+                                                                out_inf)));
+}
+
+int amsm_host_lincomb(int curve, const uint64_t* xy, const uint8_t* is_inf, const uint64_t* scalars_mont, size_t n,
+                      uint64_t* out_xy, uint8_t* out_inf) {
+  if (!out_xy || (n && (!xy || !scalars_mont))) return AMSM_E_INVALID_ARG;
+  if (curve == AMSM_PALLAS) return host_lincomb_impl<PallasFq, PallasFr>(xy, is_inf, scalars_mont, n, out_xy, out_inf);
+  if (curve == AMSM_BLS12_381_G1)
+    return host_lincomb_impl<Bls12381Fq, Bls12381Fr>(xy, is_inf, scalars_mont, n, out_xy, out_inf);
+  return AMSM_E_INVALID_ARG;
+}
+
+int amsm_vec_fill(amsm_ctx* c, const uint64_t* value_mont, size_t n, void* d_out) {
+  if (!c || !value_mont || (n && !d_out) || n >= (1ull << 32)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (!n) return AMSM_OK;
+  u32 v[8];
+  memcpy(v, value_mont, 32);
+  launch_vec_fill(c->stream, (u32*)d_out, v, (u32)n);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
 }
 
 int amsm_dev_alloc(amsm_ctx* c, size_t bytes, void** d_ptr) {

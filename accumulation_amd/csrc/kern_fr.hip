@@ -11,6 +11,11 @@ void launch_bounds(hipStream_t st, const u32* keys_sorted, MsmGeom g, u32* start
   hipLaunchKernelGGL(k_bounds, dim3(cdiv_(g.B, 256)), dim3(256), 0, st, keys_sorted, g, start, items);
 }
 
+void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
+  hipLaunchKernelGGL(k_vec_fill, dim3(cdiv_(n, 256)), dim3(256), 0, st, out, make_uint4(v[0], v[1], v[2], v[3]),
+                     make_uint4(v[4], v[5], v[6], v[7]), n);
+}
+
 #define AMSM_FR_LAUNCHERS(FR)                                                                                        \
   template <>                                                                                                        \
   void launch_digits<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, u32* keys, u32* vals, u32* err) {   \
@@ -41,7 +46,11 @@ void launch_bounds(hipStream_t st, const u32* keys_sorted, MsmGeom g, u32* start
       case 1: hipLaunchKernelGGL((k_hp_t_vecs<FR, 1>), grid, block, 0, st, a); break;                                \
       case 2: hipLaunchKernelGGL((k_hp_t_vecs<FR, 2>), grid, block, 0, st, a); break;                                \
       case 3: hipLaunchKernelGGL((k_hp_t_vecs<FR, 3>), grid, block, 0, st, a); break;                                \
-      default: hipLaunchKernelGGL((k_hp_t_vecs<FR, 4>), grid, block, 0, st, a); break;                               \
+      case 4: hipLaunchKernelGGL((k_hp_t_vecs<FR, 4>), grid, block, 0, st, a); break;                                \
+      case 5: hipLaunchKernelGGL((k_hp_t_vecs<FR, 5>), grid, block, 0, st, a); break;                                \
+      case 6: hipLaunchKernelGGL((k_hp_t_vecs<FR, 6>), grid, block, 0, st, a); break;                                \
+      case 7: hipLaunchKernelGGL((k_hp_t_vecs<FR, 7>), grid, block, 0, st, a); break;                                \
+      default: hipLaunchKernelGGL((k_hp_t_vecs<FR, 8>), grid, block, 0, st, a); break;                               \
     }                                                                                                                \
   }
 

@@ -45,6 +45,7 @@ template <class Fr>
 void launch_spmv(hipStream_t st, const u32* row_ptr, const u32* col, const u32* val, const u32* input, u32 n_input,
                  const u32* witness, u32 n_witness, u32* out, u32 n_rows);
 
+void launch_vec_fill(hipStream_t st, u32* out, const u32 value[8], u32 n);
 void launch_bounds(hipStream_t st, const u32* keys_sorted, MsmGeom g, u32* start, u32* items);
 
 }  // namespace amsm

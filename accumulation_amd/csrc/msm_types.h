@@ -8,7 +8,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 constexpr int VEC_MAX = 8;        // max vectors combined in one launch (reference uses 2..4)
-constexpr int HP_MAX_INPUTS = 4;  // max inputs+accumulators of one hp_as t-vector launch
+constexpr int HP_MAX_INPUTS = 8;  // max inputs+accumulators of one hp_as t-vector launch (reference tests reach 6)
 
 struct MsmGeom {
   u32 n;             // pairs in this call

@@ -110,6 +110,15 @@ __global__ void __launch_bounds__(256)
   fe_store<Fr>(out + (size_t)r * 8, acc);
 }
 
+// out[i] = value  (the reference's `vec![F::rand(rng); len]` hiding vectors, src/hp_as/mod.rs:189-190)
+__global__ void __launch_bounds__(256) k_vec_fill(u32* __restrict__ out, uint4 lo, uint4 hi, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint4* q = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+  q[0] = lo;
+  q[1] = hi;
+}
+
 template <class Fr>
 __global__ void __launch_bounds__(256) k_vec_random(u32* __restrict__ out, u64 seed, u32 n, int mont) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;

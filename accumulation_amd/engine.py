@@ -75,6 +75,13 @@ class Context:
             ffi.check(self._lib.amsm_dev_upload(self._h, v.ptr, _ptr(limbs), limbs.nbytes), "amsm_dev_upload")
         return v
 
+    def fill(self, value_mont: np.ndarray, n: int) -> "FrVector":
+        """vec![value; n] on the device."""
+        v = FrVector(self, n)
+        val = np.ascontiguousarray(value_mont, dtype=np.uint64).reshape(4)
+        ffi.check(self._lib.amsm_vec_fill(self._h, _ptr(val), n, v.ptr), "amsm_vec_fill")
+        return v
+
     def random_vector(self, seed: int, n: int, mont: bool) -> "FrVector":
         v = FrVector(self, n)
         ffi.check(self._lib.amsm_vec_random(self._h, seed, n, 1 if mont else 0, v.ptr), "amsm_vec_random")
@@ -213,20 +220,21 @@ class PedersenCommitment:
     def commit(ck: CommitterKey, elems, randomizer: Optional[np.ndarray] = None) -> Tuple[np.ndarray, bool]:
         """commit(ck, &[F] (Montgomery), Option<F>) -> affine point."""
         ctx = ck.ctx
-        if isinstance(elems, FrVector):
-            out, inf = VariableBaseMSM.multi_scalar_mul(ck, elems, mont=True)
-            if randomizer is None:
-                return out, inf
-            elems = elems.download()
-        e = np.ascontiguousarray(elems, dtype=np.uint64).reshape(-1, 4)
-        out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
-        inf = C.c_uint8(0)
         r = None if randomizer is None else np.ascontiguousarray(randomizer, dtype=np.uint64)
         hg = None
         if r is not None:
             if ck.hiding_generator is None:
                 raise ValueError("committer key has no hiding generator")
             hg = np.ascontiguousarray(ck.hiding_generator, dtype=np.uint64)
+        if isinstance(elems, FrVector):
+            out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+            inf = C.c_uint8(0)
+            ffi.check(ctx._lib.amsm_pedersen_commit_device(ctx._h, ck._h, elems.ptr, elems.n, _ptr(r), _ptr(hg),
+                                                           _ptr(out), C.byref(inf)), "amsm_pedersen_commit_device")
+            return out, bool(inf.value)
+        e = np.ascontiguousarray(elems, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+        inf = C.c_uint8(0)
         ffi.check(ctx._lib.amsm_pedersen_commit(ctx._h, ck._h, _ptr(e), e.shape[0], _ptr(r), _ptr(hg), _ptr(out),
                                                 C.byref(inf)), "amsm_pedersen_commit")
         return out, bool(inf.value)

@@ -60,6 +60,9 @@ SIGNATURES = {
     "amsm_msm_partial_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp]),
     "amsm_partials_combine": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "amsm_pedersen_commit": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "amsm_pedersen_commit_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "amsm_host_lincomb": (C.c_int, [C.c_int, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "amsm_vec_fill": (C.c_int, [_vp, _vp, _sz, _vp]),
     "amsm_dev_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "amsm_dev_free": (C.c_int, [_vp, _vp]),
     "amsm_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),

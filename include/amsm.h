@@ -139,6 +139,18 @@ int amsm_pedersen_commit(amsm_ctx* ctx, const amsm_bases* ck, const uint64_t* el
                          const uint64_t* randomizer_mont, const uint64_t* hiding_xy_mont, uint64_t* out_xy_mont,
                          uint8_t* out_is_inf);
 
+/* Same with the committed vector already resident in HBM (Montgomery form). */
+int amsm_pedersen_commit_device(amsm_ctx* ctx, const amsm_bases* ck, const void* d_elems_mont, size_t n,
+                                const uint64_t* randomizer_mont, const uint64_t* hiding_xy_mont,
+                                uint64_t* out_xy_mont, uint8_t* out_is_inf);
+
+/* Host-side linear combination sum_i s_i * P_i of a HANDFUL of points (no GPU, no context): the O(#inputs)
+ * scalar-muls + `batch_normalization_into_affine` of `combine_commitments` /
+ * `compute_combined_hp_commitments` (src/hp_as/mod.rs:391-479) and their r1cs_nark_as / ipa_pc_as
+ * counterparts (these stay on the host).  scalars_mont: n*4 u64 Montgomery. */
+int amsm_host_lincomb(int curve, const uint64_t* xy_mont, const uint8_t* is_inf, const uint64_t* scalars_mont,
+                      size_t n, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+
 /* ---- device buffers for scalar-field vectors ------------------------------------------------- */
 int amsm_dev_alloc(amsm_ctx* ctx, size_t bytes, void** d_ptr);
 int amsm_dev_free(amsm_ctx* ctx, void* d_ptr);
@@ -147,6 +159,9 @@ int amsm_dev_download(amsm_ctx* ctx, void* h_dst, const void* d_src, size_t byte
 /* Fill d_out with n synthetic scalars of stream `seed` (oracle/pyref.py:rng_scalar), canonical
  * integers (mont == 0) or the Montgomery form of the same integers (mont != 0). */
 int amsm_vec_random(amsm_ctx* ctx, uint64_t seed, size_t n, int mont, void* d_out);
+
+/* out[i] = value for i < n  (`vec![x; len]`, src/hp_as/mod.rs:189-190).  value_mont: 4 u64. */
+int amsm_vec_fill(amsm_ctx* ctx, const uint64_t* value_mont, size_t n, void* d_out);
 
 /* ---- scalar-field (Fr) vector kernels; all operands Montgomery, n elements of 32 bytes -------- */
 /* out[i] = a[i]*b[i]                      -- `compute_hp`, src/hp_as/mod.rs:278-285 */
