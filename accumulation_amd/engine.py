@@ -35,9 +35,33 @@ class Context:
         self.curve = curve
         self.device = device
         self.fq_limbs = self._lib.amsm_ctx_fq_limbs(h)
+        # size-keyed free lists of device buffers: hipMalloc/hipFree synchronise the device, so FrVectors
+        # released by the scheme drivers are recycled instead (same idea as a caching tensor allocator)
+        self._pool = {}
+
+    def _alloc(self, nbytes: int):
+        lst = self._pool.get(nbytes)
+        if lst:
+            return lst.pop()
+        p = C.c_void_p()
+        ffi.check(self._lib.amsm_dev_alloc(self._h, nbytes, C.byref(p)), "amsm_dev_alloc")
+        return p
+
+    def _release(self, p, nbytes: int):
+        if self._h:
+            self._pool.setdefault(nbytes, []).append(p)
+
+    def empty_cache(self):
+        if self._h:
+            self.synchronize()
+            for lst in self._pool.values():
+                for p in lst:
+                    self._lib.amsm_dev_free(self._h, p)
+        self._pool = {}
 
     def close(self):
         if getattr(self, "_h", None):
+            self.empty_cache()
             self._lib.amsm_ctx_destroy(self._h)
             self._h = None
 
@@ -94,9 +118,8 @@ class FrVector:
     def __init__(self, ctx: Context, n: int):
         self.ctx = ctx
         self.n = n
-        p = C.c_void_p()
-        ffi.check(ctx._lib.amsm_dev_alloc(ctx._h, max(n, 1) * 32, C.byref(p)), "amsm_dev_alloc")
-        self.ptr = p
+        self._nbytes = max(n, 1) * 32
+        self.ptr = ctx._alloc(self._nbytes)
 
     def download(self) -> np.ndarray:
         out = np.empty((self.n, 4), dtype=np.uint64)
@@ -105,8 +128,10 @@ class FrVector:
         return out
 
     def free(self):
+        # stream-ordered reuse: every kernel of this engine runs on the context's stream (or is ordered after
+        # it), so a recycled buffer is never overwritten before its last reader has been enqueued
         if self.ptr is not None and self.ctx._h:
-            self.ctx._lib.amsm_dev_free(self.ctx._h, self.ptr)
+            self.ctx._release(self.ptr, self._nbytes)
         self.ptr = None
 
     def __del__(self):

@@ -175,7 +175,7 @@ def main() -> int:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args),
                 "kernel_ms": dom_ms,
                 "algorithmic_bytes_per_launch": n * bytes_per_pair,
             },
@@ -189,6 +189,22 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (tools/profile_round.sh -> profiles/*_pmc_accum_l0.json; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for 16-B-per-lane loads).  Only valid for the default workload; null otherwise."""
+    if args.log2n != 20 or args.curve != "pallas" or args.no_precompute:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_accum_l0.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["hbm_traffic_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(ctx, ck, scalars, curve_id, args, gpu_out, gpu_inf, batch_out, batch_inf):
