@@ -209,12 +209,12 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   g.nb = 1u << (c - 1);
   g.n_sets = bases->precomp ? 1u : (u32)W;
   g.B = g.n_sets * g.nb;
-  if ((unsigned long long)n * W >= (1ull << 31)) return AMSM_E_UNSUPPORTED;
+  if ((unsigned long long)n * W >= (1ull << 30)) return AMSM_E_UNSUPPORTED;  // entry words carry a 30-bit index
   g.E = (u32)(n * W);
   g.base_off = (u32)base_off;
   g.table_stride = (u32)bases->n;
   g.precomp = (u32)bases->precomp;
-  if ((unsigned long long)bases->n * (bases->precomp ? W : 1) >= (1ull << 31)) return AMSM_E_UNSUPPORTED;
+  if ((unsigned long long)bases->n * (bases->precomp ? W : 1) >= (1ull << 30)) return AMSM_E_UNSUPPORTED;
   // chunk length of accumulate L0: the grid should be a whole number of rounds of the resident wave
   // slots (4 waves/SIMD at ~122 VGPRs), so that no SIMD idles while a partial last round drains
   if (ctx->K0 > 0) {
@@ -228,6 +228,7 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
     unsigned long long k = (g.E + lanes * rounds - 1) / (lanes * rounds);
     g.K0 = (u32)std::min<unsigned long long>(std::max<unsigned long long>(k, 16ull), 32ull);
   }
+  g.K0 = (g.K0 + 3u) & ~3u;  // accumulate L0 reads entries in groups of 4
   g.K1 = (u32)ctx->K1;
   g.red_s = std::min<u32>((u32)ctx->red_s, g.nb);
   g.red_threads = g.nb / g.red_s;
@@ -259,8 +260,8 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   const u32 red_blocks = cdiv(g.red_threads, 256);
   TRY(ensure(sl->keys_a, (size_t)g.E * 4));
   TRY(ensure(sl->keys_b, (size_t)g.E * 4));
-  TRY(ensure(sl->vals_a, (size_t)g.E * 4));
-  TRY(ensure(sl->vals_b, (size_t)g.E * 4));
+  TRY(ensure(sl->vals_a, (size_t)g.E * 4 + 64));
+  TRY(ensure(sl->vals_b, (size_t)g.E * 4 + 64));  // read in groups of 4 entries
   TRY(ensure(sl->start, (size_t)(g.B + 2) * 4));
   TRY(ensure(sl->items, (size_t)(g.B + 2) * 4));
   TRY(ensure(sl->item_off, (size_t)(g.B + 2) * 4));
@@ -294,7 +295,7 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
                                       (unsigned)bits, st));
   }
   stage_mark(ctx, sl, ST_BOUNDS);
-  launch_bounds(st, (const u32*)keys_b, g, (u32*)sl->start.p, (u32*)sl->items.p);
+  launch_bounds(st, (const u32*)keys_b, vals_b, g, (u32*)sl->start.p, (u32*)sl->items.p);
   {
     size_t tmp = 0;
     HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, (u32*)sl->items.p, (u32*)sl->item_off.p, 0u, (size_t)(g.B + 1),
@@ -305,7 +306,7 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
                                     (size_t)(g.B + 1), rocprim::plus<u32>(), st));
   }
   stage_mark(ctx, sl, ST_ACCUM_L0);
-  launch_accum_l0<Fq>(st, (const u32*)bases->d_table, (const u32*)keys_b, (const u32*)vals_b, (const u32*)sl->start.p,
+  launch_accum_l0<Fq>(st, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)sl->start.p,
                       (const u32*)sl->item_off.p, g, (u32*)sl->partials.p);
   HIP_TRY(hipEventRecord(sl->l0_done, st));
   hipStream_t tl = sl->tail;
@@ -452,7 +453,7 @@ int bases_finish(amsm_ctx* ctx, amsm_bases* b, unsigned flags) {
   if (!pre) return AMSM_OK;
   int c = ctx->window_override ? ctx->window_override : choose_window(b->n, true);
   int W = windows_for(c);
-  if ((unsigned long long)b->n * W >= (1ull << 31)) return AMSM_OK;  // stay un-precomputed
+  if ((unsigned long long)b->n * W >= (1ull << 30)) return AMSM_OK;  // stay un-precomputed
   u32* table = nullptr;
   hipError_t e = hipMalloc((void**)&table, (size_t)b->n * W * affine_bytes<Fq>());
   if (e != hipSuccess) {

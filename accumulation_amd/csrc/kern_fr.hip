@@ -7,8 +7,8 @@ namespace amsm {
 
 static inline u32 cdiv_(u32 a, u32 b) { return (a + b - 1) / b; }
 
-void launch_bounds(hipStream_t st, const u32* keys_sorted, MsmGeom g, u32* start, u32* items) {
-  hipLaunchKernelGGL(k_bounds, dim3(cdiv_(g.B, 256)), dim3(256), 0, st, keys_sorted, g, start, items);
+void launch_bounds(hipStream_t st, const u32* keys_sorted, u32* vals_sorted, MsmGeom g, u32* start, u32* items) {
+  hipLaunchKernelGGL(k_bounds, dim3(cdiv_(g.B, 256)), dim3(256), 0, st, keys_sorted, vals_sorted, g, start, items);
 }
 
 void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {

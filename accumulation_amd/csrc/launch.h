@@ -10,7 +10,7 @@ namespace amsm {
 
 // ---- per-curve (Fq) launchers ------------------------------------------------------------------
 template <class Fq>
-void launch_accum_l0(hipStream_t st, const u32* table, const u32* keys_sorted, const u32* vals_sorted, const u32* start,
+void launch_accum_l0(hipStream_t st, const u32* table, const u32* vals_sorted, const u32* start,
                      const u32* item_off, MsmGeom g, u32* partials);
 template <class Fq>
 void launch_accum_l1(hipStream_t st, u32 lanes_per_bucket, const u32* partials, const u32* items, const u32* item_off, MsmGeom g,
@@ -46,6 +46,6 @@ void launch_spmv(hipStream_t st, const u32* row_ptr, const u32* col, const u32* 
                  const u32* witness, u32 n_witness, u32* out, u32 n_rows);
 
 void launch_vec_fill(hipStream_t st, u32* out, const u32 value[8], u32 n);
-void launch_bounds(hipStream_t st, const u32* keys_sorted, MsmGeom g, u32* start, u32* items);
+void launch_bounds(hipStream_t st, const u32* keys_sorted, u32* vals_sorted, MsmGeom g, u32* start, u32* items);
 
 }  // namespace amsm

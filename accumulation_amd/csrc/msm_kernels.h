@@ -37,40 +37,111 @@ namespace amsm {
 // lane flushes its running sum as one partial of the finished bucket.  The partials of bucket b are the
 // consecutive records item_off[b] + (chunk - first_chunk(b)); k_bounds counted them (items[b]).
 // ---------------------------------------------------------------------------------------------
+// Cooperative gather: the 64 points a wave needs for one iteration are fetched with LDS-DMA
+// (`global_load_lds_dwordx4`), 16 bytes per lane, lanes arranged so that a point's 64/96 bytes are read by
+// ADJACENT lanes of ONE wave-instruction: one memory request per point instead of one per 16-byte piece
+// (4-6x fewer L2/HBM requests than each lane loading its own point with dwordx4s; measured in DESIGN.md).
+// The LDS image is lane-linear (DMA writes base + lane*16): byte o of the wave's region belongs to point
+// o / PB, so lane l then reads its own point back with ds_read_b128s.  One region per wave, no barrier.
+template <class Fq>
+struct GatherLds {
+  static constexpr u32 PB = 2 * Fq::L * 4;           // bytes per affine point
+  static constexpr u32 WAVE_BYTES = 64 * PB;          // 4 KiB (Pallas) / 6 KiB (BLS12-381)
+  static constexpr u32 N_INSTR = WAVE_BYTES / 1024;   // DMA wave-instructions per gather
+};
+
+template <class Fq>
+AMSM_DEV void gather_issue(const u32* __restrict__ table, u32 idx_own, u32* lds_wave, u32 lane) {
+  using G = GatherLds<Fq>;
+#pragma unroll
+  for (u32 j = 0; j < G::N_INSTR; j++) {
+    u32 o = j * 1024u + lane * 16u;          // byte offset of this lane's 16 B inside the wave's LDS region
+    u32 pt = o / G::PB, piece = o % G::PB;   // which point of the wave, which 16-byte piece of it
+    u32 idx = __shfl(idx_own, pt, 64);       // that point's table index lives in lane `pt`
+    const char* src = reinterpret_cast<const char*>(table) + (size_t)idx * G::PB + piece;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(lds_wave) + j * 1024u),
+                                     16, 0, 0);
+  }
+}
+
+template <class Fq>
+AMSM_DEV Affine<Fq> gather_read(const u32* lds_wave, u32 lane) {
+  const u32* p = lds_wave + lane * (2 * Fq::L);
+  Affine<Fq> r;
+  r.x = fe_load<Fq>(p);
+  r.y = fe_load<Fq>(p + Fq::L);
+  return r;
+}
+
+// Entry word layout (u32): bit 31 = negate the point, bit 30 = last entry of its bucket (set by k_bounds
+// after the sort), bits 0..29 = index into the generator table.
+constexpr u32 ENTRY_NEG = 0x80000000u, ENTRY_LAST = 0x40000000u, ENTRY_IDX = 0x3fffffffu;
+
 template <class Fq>
 __global__ void __launch_bounds__(256)
-    k_accum_l0(const u32* __restrict__ table, const u32* __restrict__ keys_sorted, const u32* __restrict__ vals_sorted,
-               const u32* __restrict__ start, const u32* __restrict__ item_off, MsmGeom g, u32* __restrict__ partials) {
+    k_accum_l0(const u32* __restrict__ table, const u32* __restrict__ vals_sorted, const u32* __restrict__ start,
+               const u32* __restrict__ item_off, MsmGeom g, u32* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) u32 lds[4 * GatherLds<Fq>::WAVE_BYTES / 4];
+  const u32 lane = threadIdx.x & 63u;
+  u32* lds_wave = lds + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (GatherLds<Fq>::WAVE_BYTES / 4);
   u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   u32 e_valid = start[g.B];  // entries with a non-zero digit (key B = digit 0 sorts last)
-  u32 s = c * g.K0;
-  if (s >= e_valid) return;
+  u32 s = c * g.K0;          // K0 is a multiple of 4: every lane's chunk is a 16-byte aligned run of entries
   u32 e = min(s + g.K0, e_valid);
-  XYZZ<Fq> acc = xyzz_inf<Fq>();
-  // software pipeline: entry (key, value) two ahead, point one ahead (vals -> point loads are dependent);
-  // issued unconditionally (the tail re-reads its last entry) so hipcc keeps them in flight across the
-  // long mixed addition instead of branching around them
-  u32 v = vals_sorted[s];
-  u32 b_cur = keys_sorted[s];
-  u32 i1 = min(s + 1, e - 1);
-  u32 v1 = vals_sorted[i1], k1 = keys_sorted[i1];
-  Affine<Fq> pt = affine_load<Fq>(table, v & 0x7fffffffu);
-  for (u32 k = s; k < e; k++) {
-    u32 i2 = min(k + 2, e - 1);
-    u32 v2 = vals_sorted[i2], k2 = keys_sorted[i2];
-    Affine<Fq> ptn = affine_load<Fq>(table, v1 & 0x7fffffffu);
-    xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (v >> 31) != 0));
-    if (k1 != b_cur || k + 1 == e) {  // bucket finished inside this chunk (or chunk finished): flush
-      u32 slot = item_off[b_cur] + (c - start[b_cur] / g.K0);
-      xyzz_store<Fq>(partials, slot, acc);
-      acc = xyzz_inf<Fq>();
-      b_cur = k1;
+  // every lane runs all K0 iterations (the gather is cooperative); lanes past their range replay a valid
+  // group of entries and skip the arithmetic.  Entries are read 4 at a time (one dwordx4 per 4 mixed
+  // additions): 8x fewer requests than word-by-word reads of a stride-128-byte access pattern.
+  const u32 last_grp = ((g.E - 1) / 4) * 4;  // the arrays are padded to a multiple of 4 entries
+  const uint4* v4 = reinterpret_cast<const uint4*>(vals_sorted);
+  uint4 cur = v4[min(s, last_grp) / 4];
+  uint4 nxt = v4[min(s + 4, last_grp) / 4];
+  // bucket of the first entry: largest b with start[b] <= s
+  u32 b_cur = 0;
+  if (s < e) {
+    u32 lo = 0, hi = g.B;
+    while (lo < hi) {
+      u32 mid = (lo + hi + 1) >> 1;
+      if (start[mid] <= s) lo = mid; else hi = mid - 1;
     }
-    v = v1;
-    v1 = v2;
-    k1 = k2;
-    pt = ptn;
+    b_cur = lo;
   }
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  gather_issue<Fq>(table, cur.x & ENTRY_IDX, lds_wave, lane);
+  for (u32 grp = 0; grp < g.K0; grp += 4) {
+    uint4 nn = v4[min(s + grp + 8, last_grp) / 4];
+    u32 w[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      u32 k = s + grp + i;
+      // the DMA of this iteration's points was issued one mixed addition ago; hipcc does not track it, so
+      // wait explicitly, then pull the own point into registers before the region is refilled
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      Affine<Fq> pt = gather_read<Fq>(lds_wave, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      gather_issue<Fq>(table, w[i + 1] & ENTRY_IDX, lds_wave, lane);
+      if (k < e) {
+        u32 v = w[i];
+        xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (v & ENTRY_NEG) != 0));
+        if ((v & ENTRY_LAST) || k + 1 == e) {  // bucket (or chunk) finished: flush one partial
+          u32 slot = item_off[b_cur] + (c - start[b_cur] / g.K0);
+          xyzz_store<Fq>(partials, slot, acc);
+          acc = xyzz_inf<Fq>();
+          if (k + 1 < e) {  // next entry opens the next NON-EMPTY bucket: largest b with start[b] <= k+1
+            u32 lo = b_cur + 1, hi = g.B;
+            while (lo < hi) {
+              u32 mid = (lo + hi + 1) >> 1;
+              if (start[mid] <= k + 1) lo = mid; else hi = mid - 1;
+            }
+            b_cur = lo;
+          }
+        }
+      }
+    }
+    cur = nxt;
+    nxt = nn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before the LDS is released
 }
 
 // Butterfly reduction of one XYZZ per lane over aligned groups of WIDTH lanes (WIDTH = 64: whole wave) with

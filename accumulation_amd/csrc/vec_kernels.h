@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------------
 // bounds: start[b] = first sorted entry with key >= b (b = 0..B); items[b] = number of K0-sized chunks
 // of the sorted entry list that bucket b's run [start[b], start[b+1]) touches = number of partials
-// k_accum_l0 will write for it.
+// k_accum_l0 will write for it.  Also tags the last entry of every bucket (bit 30 of its value word).
 // ---------------------------------------------------------------------------------------------
 AMSM_DEV u32 lower_bound_u32(const u32* __restrict__ a, u32 n, u32 x) {
   u32 lo = 0, hi = n;
@@ -185,12 +185,14 @@ AMSM_DEV u32 lower_bound_u32(const u32* __restrict__ a, u32 n, u32 x) {
 }
 
 __global__ void __launch_bounds__(256)
-    k_bounds(const u32* __restrict__ keys_sorted, MsmGeom g, u32* __restrict__ start, u32* __restrict__ items) {
+    k_bounds(const u32* __restrict__ keys_sorted, u32* __restrict__ vals_sorted, MsmGeom g, u32* __restrict__ start,
+             u32* __restrict__ items) {
   u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= g.B) return;
   u32 lo = lower_bound_u32(keys_sorted, g.E, b);
   u32 hi = lower_bound_u32(keys_sorted, g.E, b + 1);
   start[b] = lo;
+  if (hi > lo) vals_sorted[hi - 1] |= 0x40000000u;  // ENTRY_LAST: accumulate L0 no longer needs the keys
   items[b] = hi > lo ? (hi - 1) / g.K0 - lo / g.K0 + 1 : 0u;
   if (b == g.B - 1) {
     start[g.B] = hi;
