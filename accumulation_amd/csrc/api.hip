@@ -282,20 +282,30 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
 
   HIP_TRY(hipMemsetAsync(sl->misc.p, 0, 64, st));
   stage_mark(ctx, sl, ST_DIGITS);
-  launch_digits<Fr>(st, (const u32*)d_scalars, scalars_mont, g, keys_a, vals_a, d_err);
+  const bool keys16 = g.B < 65536u;  // every key (incl. the "digit 0" key B) fits 16 bits
+  launch_digits<Fr>(st, (const u32*)d_scalars, scalars_mont, g, keys_a, keys16, vals_a, d_err);
   stage_mark(ctx, sl, ST_SORT);
   {
     int bits = 1;
     while ((1u << bits) <= g.B) bits++;
     size_t tmp = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)g.E, 0u, (unsigned)bits, st));
-    TRY(ensure(sl->sort_tmp, tmp));
-    tmp = sl->sort_tmp.bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(sl->sort_tmp.p, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)g.E, 0u,
-                                      (unsigned)bits, st));
+    if (keys16) {
+      uint16_t* ka = (uint16_t*)keys_a;
+      uint16_t* kb = (uint16_t*)keys_b;
+      HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, ka, kb, vals_a, vals_b, (size_t)g.E, 0u, (unsigned)bits, st));
+      TRY(ensure(sl->sort_tmp, tmp));
+      tmp = sl->sort_tmp.bytes;
+      HIP_TRY(rocprim::radix_sort_pairs(sl->sort_tmp.p, tmp, ka, kb, vals_a, vals_b, (size_t)g.E, 0u, (unsigned)bits, st));
+    } else {
+      HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)g.E, 0u, (unsigned)bits, st));
+      TRY(ensure(sl->sort_tmp, tmp));
+      tmp = sl->sort_tmp.bytes;
+      HIP_TRY(rocprim::radix_sort_pairs(sl->sort_tmp.p, tmp, keys_a, keys_b, vals_a, vals_b, (size_t)g.E, 0u,
+                                        (unsigned)bits, st));
+    }
   }
   stage_mark(ctx, sl, ST_BOUNDS);
-  launch_bounds(st, (const u32*)keys_b, vals_b, g, (u32*)sl->start.p, (u32*)sl->items.p);
+  launch_bounds(st, (const void*)keys_b, keys16, vals_b, g, (u32*)sl->start.p, (u32*)sl->items.p);
   {
     size_t tmp = 0;
     HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, (u32*)sl->items.p, (u32*)sl->item_off.p, 0u, (size_t)(g.B + 1),

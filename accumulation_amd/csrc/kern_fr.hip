@@ -7,8 +7,14 @@ namespace amsm {
 
 static inline u32 cdiv_(u32 a, u32 b) { return (a + b - 1) / b; }
 
-void launch_bounds(hipStream_t st, const u32* keys_sorted, u32* vals_sorted, MsmGeom g, u32* start, u32* items) {
-  hipLaunchKernelGGL(k_bounds, dim3(cdiv_(g.B, 256)), dim3(256), 0, st, keys_sorted, vals_sorted, g, start, items);
+void launch_bounds(hipStream_t st, const void* keys_sorted, bool keys16, u32* vals_sorted, MsmGeom g, u32* start,
+                   u32* items) {
+  if (keys16)
+    hipLaunchKernelGGL((k_bounds<uint16_t>), dim3(cdiv_(g.B, 256)), dim3(256), 0, st, (const uint16_t*)keys_sorted,
+                       vals_sorted, g, start, items);
+  else
+    hipLaunchKernelGGL((k_bounds<u32>), dim3(cdiv_(g.B, 256)), dim3(256), 0, st, (const u32*)keys_sorted, vals_sorted,
+                       g, start, items);
 }
 
 void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
@@ -18,8 +24,14 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
 
 #define AMSM_FR_LAUNCHERS(FR)                                                                                        \
   template <>                                                                                                        \
-  void launch_digits<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, u32* keys, u32* vals, u32* err) {   \
-    hipLaunchKernelGGL((k_digits<FR>), dim3(cdiv_(g.n, 256)), dim3(256), 0, st, scalars, mont, g, keys, vals, err);   \
+  void launch_digits<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, void* keys, bool keys16, u32* vals, \
+                         u32* err) {                                                                                 \
+    if (keys16)                                                                                                      \
+      hipLaunchKernelGGL((k_digits<FR, uint16_t>), dim3(cdiv_(g.n, 256)), dim3(256), 0, st, scalars, mont, g,         \
+                         (uint16_t*)keys, vals, err);                                                                \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_digits<FR, u32>), dim3(cdiv_(g.n, 256)), dim3(256), 0, st, scalars, mont, g, (u32*)keys,  \
+                         vals, err);                                                                                 \
   }                                                                                                                  \
   template <>                                                                                                        \
   void launch_vec_random<FR>(hipStream_t st, u32* out, u64 seed, u32 n, int mont) {                                  \

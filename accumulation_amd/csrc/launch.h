@@ -31,7 +31,7 @@ void launch_generate_bases(hipStream_t st, u32* table, u64 seed, u32 n, const u3
 
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>
-void launch_digits(hipStream_t st, const u32* scalars, int mont, MsmGeom g, u32* keys, u32* vals, u32* err);
+void launch_digits(hipStream_t st, const u32* scalars, int mont, MsmGeom g, void* keys, bool keys16, u32* vals, u32* err);
 template <class Fr>
 void launch_vec_random(hipStream_t st, u32* out, u64 seed, u32 n, int mont);
 template <class Fr>
@@ -46,6 +46,6 @@ void launch_spmv(hipStream_t st, const u32* row_ptr, const u32* col, const u32* 
                  const u32* witness, u32 n_witness, u32* out, u32 n_rows);
 
 void launch_vec_fill(hipStream_t st, u32* out, const u32 value[8], u32 n);
-void launch_bounds(hipStream_t st, const u32* keys_sorted, u32* vals_sorted, MsmGeom g, u32* start, u32* items);
+void launch_bounds(hipStream_t st, const void* keys_sorted, bool keys16, u32* vals_sorted, MsmGeom g, u32* start, u32* items);
 
 }  // namespace amsm
