@@ -59,4 +59,9 @@ class Sha256Sponge(CryptographicSponge):
         return int.from_bytes(out, "little") & ((1 << n_bits) - 1)
 
     def fork(self, domain: bytes) -> "Sha256Sponge":
+        """Domain-separated child sponge; fork(b"") is a plain clone of the current state."""
+        if not domain:
+            c = Sha256Sponge()
+            c._state, c._ctr = self._state, self._ctr
+            return c
         return Sha256Sponge(self._state + b"F" + domain)
