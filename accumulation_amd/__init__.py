@@ -5,4 +5,4 @@ is the thin host-side mirror of the reference interfaces used by tests, bench.py
 """
 from . import ffi  # noqa: F401
 from .engine import (CommitterKey, Context, FrVector, PedersenCommitment,  # noqa: F401
-                     VariableBaseMSM)
+                     PointVector, VariableBaseMSM)

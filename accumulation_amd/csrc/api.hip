@@ -1107,6 +1107,128 @@ int amsm_vec_combine(amsm_ctx* c, const void* const* d_vecs, const size_t* lens,
                   (vec_combine_impl<Bls12381Fr>(c, d_vecs, lens, n_vecs, coeffs, d_hiding, hiding_len, d_out, n)));
 }
 
+int amsm_bases_from_device(amsm_ctx* c, const void* d_xy, size_t n, unsigned flags, amsm_bases** out) {
+  if (!c || !out || (n && !d_xy) || n >= (1ull << 30)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  amsm_bases* b = new (std::nothrow) amsm_bases();
+  if (!b) return AMSM_E_OOM;
+  b->curve = c->curve;
+  b->device = c->device;
+  b->n = n;
+  size_t pb = (c->curve == AMSM_PALLAS) ? affine_bytes<PallasFq>() : affine_bytes<Bls12381Fq>();
+  if (hipMalloc((void**)&b->d_table, std::max<size_t>(n, 1) * pb) != hipSuccess) {
+    (void)hipGetLastError();
+    delete b;
+    return AMSM_E_OOM;
+  }
+  int s = AMSM_OK;
+  if (n) {
+    if (hipMemcpyAsync(b->d_table, d_xy, n * pb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+      s = AMSM_E_HIP;
+    if (s == AMSM_OK)
+      s = DISPATCH(c, (bases_finish<PallasFq, PallasFr>(c, b, flags ? flags : AMSM_BASES_NO_PRECOMPUTE)),
+                   (bases_finish<Bls12381Fq, Bls12381Fr>(c, b, flags ? flags : AMSM_BASES_NO_PRECOMPUTE)));
+  }
+  if (s != AMSM_OK) {
+    (void)hipFree(b->d_table);
+    delete b;
+    return s;
+  }
+  *out = b;
+  return AMSM_OK;
+}
+const void* amsm_bases_device_ptr(const amsm_bases* b) { return b ? b->d_table : nullptr; }
+
+int amsm_points_fold(amsm_ctx* c, const void* d_l, const void* d_r, size_t n, const uint64_t* x_mont, unsigned nbits,
+                     void* d_out) {
+  if (!c || !x_mont || (n && (!d_l || !d_r || !d_out)) || n >= (1ull << 32) || nbits > 256) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (!n) return AMSM_OK;
+  // canonical scalar to the device (tiny, stream-ordered through the context's misc buffer of slot 0)
+  u64 canon[4];
+  if (c->curve == AMSM_PALLAS) {
+    host::HFe<PallasFr> x;
+    memcpy(x.v, x_mont, 32);
+    x = host::h_from_mont<PallasFr>(x);
+    memcpy(canon, x.v, 32);
+  } else {
+    host::HFe<Bls12381Fr> x;
+    memcpy(x.v, x_mont, 32);
+    x = host::h_from_mont<Bls12381Fr>(x);
+    memcpy(canon, x.v, 32);
+  }
+  TRY(ensure(c->scalars, 64));
+  HIP_TRY(hipMemcpyAsync(c->scalars.p, canon, 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // canon is a stack buffer
+  if (c->curve == AMSM_PALLAS)
+    launch_points_fold<PallasFq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, (const u32*)c->scalars.p, nbits,
+                                 (u32*)d_out);
+  else
+    launch_points_fold<Bls12381Fq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, (const u32*)c->scalars.p, nbits,
+                                   (u32*)d_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the scalar buffer is reused by the next call
+  return AMSM_OK;
+}
+
+int amsm_vec_inner_product(amsm_ctx* c, const void* d_a, const void* d_b, size_t n, uint64_t* out_mont) {
+  if (!c || !out_mont || (n && (!d_a || !d_b)) || n >= (1ull << 32)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  memset(out_mont, 0, 32);
+  if (!n) return AMSM_OK;
+  u32 blocks = std::min<u32>(1024u, cdiv((u32)n, 256));
+  Slot* sl = &c->slot[0];
+  TRY(ensure(sl->red_out, (size_t)blocks * 32 + 4096));
+  TRY(ensure_pinned(sl, (size_t)blocks * 32));
+  if (c->curve == AMSM_PALLAS)
+    launch_vec_inner_product<PallasFr>(c->stream, (const u32*)d_a, (const u32*)d_b, (u32)n, blocks, (u32*)sl->red_out.p);
+  else
+    launch_vec_inner_product<Bls12381Fr>(c->stream, (const u32*)d_a, (const u32*)d_b, (u32)n, blocks,
+                                         (u32*)sl->red_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(sl->h_pinned, sl->red_out.p, (size_t)blocks * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const u64* h = (const u64*)sl->h_pinned;
+  if (c->curve == AMSM_PALLAS) {
+    host::HFe<PallasFr> acc = host::h_zero<PallasFr>(), t;
+    for (u32 i = 0; i < blocks; i++) {
+      memcpy(t.v, h + 4 * i, 32);
+      acc = host::h_add<PallasFr>(acc, t);
+    }
+    memcpy(out_mont, acc.v, 32);
+  } else {
+    host::HFe<Bls12381Fr> acc = host::h_zero<Bls12381Fr>(), t;
+    for (u32 i = 0; i < blocks; i++) {
+      memcpy(t.v, h + 4 * i, 32);
+      acc = host::h_add<Bls12381Fr>(acc, t);
+    }
+    memcpy(out_mont, acc.v, 32);
+  }
+  return AMSM_OK;
+}
+
+int amsm_vec_powers(amsm_ctx* c, const uint64_t* point_mont, size_t n, void* d_out) {
+  if (!c || !point_mont || (n && !d_out) || n >= (1ull << 32)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (!n) return AMSM_OK;
+  u32 pt[8];
+  memcpy(pt, point_mont, 32);
+  if (c->curve == AMSM_PALLAS) launch_vec_powers<PallasFr>(c->stream, pt, (u32)n, (u32*)d_out);
+  else launch_vec_powers<Bls12381Fr>(c->stream, pt, (u32)n, (u32*)d_out);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
+}
+
+int amsm_ipa_check_poly_coeffs(amsm_ctx* c, const uint64_t* xi_mont, size_t k, void* d_out) {
+  if (!c || !d_out || (k && !xi_mont) || k > 30) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (c->curve == AMSM_PALLAS) launch_check_poly_coeffs<PallasFr>(c->stream, (const u32*)xi_mont, (u32)k, (u32*)d_out);
+  else launch_check_poly_coeffs<Bls12381Fr>(c->stream, (const u32*)xi_mont, (u32)k, (u32*)d_out);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
+}
+
 int amsm_matrix_load(amsm_ctx* c, const uint32_t* row_ptr, const uint32_t* col_idx, const uint64_t* vals, size_t n_rows,
                      size_t nnz, amsm_matrix** out) {
   if (!c || !out || !row_ptr || (nnz && (!col_idx || !vals)) || n_rows >= (1ull << 32) || nnz >= (1ull << 32))

@@ -3,6 +3,8 @@
 #include "launch.h"
 #include "vec_kernels.h"
 
+#include <cstring>
+
 namespace amsm {
 
 static inline u32 cdiv_(u32 a, u32 b) { return (a + b - 1) / b; }
@@ -44,6 +46,26 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
   template <>                                                                                                        \
   void launch_vec_combine<FR>(hipStream_t st, const CombineArgs& a, u32* out) {                                      \
     hipLaunchKernelGGL((k_vec_combine<FR>), dim3(cdiv_(a.n, 256)), dim3(256), 0, st, a, out);                        \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  void launch_vec_powers<FR>(hipStream_t st, const u32 point[8], u32 n, u32* out) {                                  \
+    CombineArgs a;                                                                                                   \
+    memset(&a, 0, sizeof(a));                                                                                        \
+    memcpy(a.coeff[0], point, 32);                                                                                   \
+    a.n = n;                                                                                                         \
+    hipLaunchKernelGGL((k_vec_powers<FR>), dim3(cdiv_(n, 256)), dim3(256), 0, st, a, out);                           \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  void launch_vec_inner_product<FR>(hipStream_t st, const u32* a, const u32* b, u32 n, u32 blocks, u32* out) {       \
+    hipLaunchKernelGGL((k_vec_inner_product<FR>), dim3(blocks), dim3(256), 0, st, a, b, n, out);                     \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  void launch_check_poly_coeffs<FR>(hipStream_t st, const u32* xi, u32 k, u32* out) {                                \
+    CheckPolyArgs a;                                                                                                 \
+    memset(&a, 0, sizeof(a));                                                                                        \
+    memcpy(a.xi, xi, (size_t)k * 32);                                                                                \
+    a.k = k;                                                                                                         \
+    hipLaunchKernelGGL((k_check_poly_coeffs<FR>), dim3(cdiv_(1u << k, 256)), dim3(256), 0, st, a, out);              \
   }                                                                                                                  \
   template <>                                                                                                        \
   void launch_spmv<FR>(hipStream_t st, const u32* row_ptr, const u32* col, const u32* val, const u32* input,         \

@@ -29,6 +29,9 @@ void launch_apply_inf(hipStream_t st, u32* table, const uint8_t* is_inf, u32 n);
 template <class Fq>
 void launch_generate_bases(hipStream_t st, u32* table, u64 seed, u32 n, const u32* gen_xy_mont);
 
+template <class Fq>
+void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const u32* d_x_canon, u32 nbits, u32* out);
+
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>
 void launch_digits(hipStream_t st, const u32* scalars, int mont, MsmGeom g, void* keys, bool keys16, u32* vals, u32* err);
@@ -45,6 +48,12 @@ template <class Fr>
 void launch_spmv(hipStream_t st, const u32* row_ptr, const u32* col, const u32* val, const u32* input, u32 n_input,
                  const u32* witness, u32 n_witness, u32* out, u32 n_rows);
 
+template <class Fr>
+void launch_vec_powers(hipStream_t st, const u32 point_mont[8], u32 n, u32* out);
+template <class Fr>
+void launch_vec_inner_product(hipStream_t st, const u32* a, const u32* b, u32 n, u32 blocks, u32* out);
+template <class Fr>
+void launch_check_poly_coeffs(hipStream_t st, const u32* xi_mont, u32 k, u32* out);
 void launch_vec_fill(hipStream_t st, u32* out, const u32 value[8], u32 n);
 void launch_bounds(hipStream_t st, const void* keys_sorted, bool keys16, u32* vals_sorted, MsmGeom g, u32* start, u32* items);
 

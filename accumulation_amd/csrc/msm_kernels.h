@@ -313,6 +313,25 @@ __global__ void __launch_bounds__(256) k_precompute_level(u32* __restrict__ tabl
   affine_store<Fq>(table, (size_t)level * stride + i, r);
 }
 
+// out[i] = l[i] + x * r[i] for affine point vectors (the commitment-key fold `key_l += key_r * xi` of the IPA
+// opening, ark_poly_commit::ipa_pc ext, under src/ipa_pc_as/mod.rs:454): one lane per point, left-to-right
+// double-and-add over the `nbits` low bits of the canonical scalar x, then one inversion back to affine.
+template <class Fq>
+__global__ void __launch_bounds__(256)
+    k_points_fold(const u32* __restrict__ l, const u32* __restrict__ r, u32 n, const u32* __restrict__ x_canon,
+                  u32 nbits, u32* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<Fq> pr = affine_load<Fq>(r, i);
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  for (int bit = (int)nbits - 1; bit >= 0; bit--) {
+    acc = xyzz_dbl<Fq>(acc);
+    if ((x_canon[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd<Fq>(acc, pr);
+  }
+  xyzz_madd<Fq>(acc, affine_load<Fq>(l, i));
+  affine_store<Fq>(out, i, xyzz_to_affine<Fq>(acc));
+}
+
 // is_inf bytes -> (0,0) encoding on device
 template <class Fq>
 __global__ void __launch_bounds__(256) k_apply_inf(u32* __restrict__ table, const uint8_t* __restrict__ is_inf, u32 n) {

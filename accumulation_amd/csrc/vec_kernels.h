@@ -110,6 +110,66 @@ __global__ void __launch_bounds__(256)
   fe_store<Fr>(out + (size_t)r * 8, acc);
 }
 
+// ---- kernels for the inner-product-argument opening (ark_poly_commit::ipa_pc, ext; reached from
+// src/ipa_pc_as/mod.rs:400,418,454,836 -- SURVEY.md section 2.1 K8) --------------------------------------
+// out[i] = point^i (Montgomery), i < n: the evaluation vector z of `open`; square-and-multiply over the bits of i
+template <class Fr>
+__global__ void __launch_bounds__(256) k_vec_powers(CombineArgs a, u32* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  Fe<Fr> base, acc = fe_one<Fr>();
+#pragma unroll
+  for (int k = 0; k < 8; k++) base.v[k] = a.coeff[0][k];
+  for (u32 e = i; e != 0; e >>= 1) {
+    if (e & 1u) acc = fe_mul<Fr>(acc, base);
+    base = fe_sqr<Fr>(base);
+  }
+  fe_store<Fr>(out + (size_t)i * 8, acc);
+}
+
+// block partial sums of sum_i a[i]*b[i]; one Montgomery element per workgroup, folded on the host
+template <class Fr>
+__global__ void __launch_bounds__(256)
+    k_vec_inner_product(const u32* __restrict__ a, const u32* __restrict__ b, u32 n, u32* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u32 lds[256 * 8];
+  Fe<Fr> acc = fe_zero<Fr>();
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    acc = fe_add<Fr>(acc, fe_mul<Fr>(fe_load<Fr>(a + (size_t)i * 8), fe_load<Fr>(b + (size_t)i * 8)));
+  fe_store<Fr>(lds + threadIdx.x * 8, acc);
+  __syncthreads();
+  for (u32 s = 128; s >= 1; s >>= 1) {
+    if (threadIdx.x < s) {
+      Fe<Fr> x = fe_load<Fr>(lds + threadIdx.x * 8), y = fe_load<Fr>(lds + (threadIdx.x + s) * 8);
+      fe_store<Fr>(lds + threadIdx.x * 8, fe_add<Fr>(x, y));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fe_store<Fr>(out + (size_t)blockIdx.x * 8, fe_load<Fr>(lds));
+}
+
+// coefficients of the succinct-check polynomial h(X) = prod_{i=1..k} (1 + xi_i X^(2^(k-i)))
+// (`SuccinctCheckPolynomial::compute_coeffs`, ext; called at src/ipa_pc_as/mod.rs:400): coefficient p is the
+// product of the challenges xi_i whose bit (k-i) is set in p.  challenges in a.coeff[0..k) (k <= VEC_MAX*4).
+struct CheckPolyArgs {
+  u32 xi[32][8];
+  u32 k;
+};
+template <class Fr>
+__global__ void __launch_bounds__(256) k_check_poly_coeffs(CheckPolyArgs a, u32* __restrict__ out) {
+  u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (1u << a.k)) return;
+  Fe<Fr> acc = fe_one<Fr>();
+  for (u32 i = 1; i <= a.k; i++) {
+    if ((p >> (a.k - i)) & 1u) {
+      Fe<Fr> x;
+#pragma unroll
+      for (int q = 0; q < 8; q++) x.v[q] = a.xi[i - 1][q];
+      acc = fe_mul<Fr>(acc, x);
+    }
+  }
+  fe_store<Fr>(out + (size_t)p * 8, acc);
+}
+
 // out[i] = value  (the reference's `vec![F::rand(rng); len]` hiding vectors, src/hp_as/mod.rs:189-190)
 __global__ void __launch_bounds__(256) k_vec_fill(u32* __restrict__ out, uint4 lo, uint4 hi, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -121,6 +121,17 @@ class FrVector:
         self._nbytes = max(n, 1) * 32
         self.ptr = ctx._alloc(self._nbytes)
 
+    _view_of = None
+
+    def view(self, off: int, n: int) -> "FrVector":
+        """Non-owning window [off, off+n) of this vector (keeps the parent alive)."""
+        assert 0 <= off and off + n <= self.n
+        v = object.__new__(FrVector)
+        v.ctx, v.n, v._nbytes = self.ctx, n, 0
+        v.ptr = C.c_void_p(self.ptr.value + off * 32)
+        v._view_of = self
+        return v
+
     def download(self) -> np.ndarray:
         out = np.empty((self.n, 4), dtype=np.uint64)
         if self.n:
@@ -128,6 +139,10 @@ class FrVector:
         return out
 
     def free(self):
+        if self._view_of is not None:
+            self.ptr = None
+            self._view_of = None
+            return
         # stream-ordered reuse: every kernel of this engine runs on the context's stream (or is ordered after
         # it), so a recycled buffer is never overwritten before its last reader has been enqueued
         if self.ptr is not None and self.ctx._h:
@@ -142,6 +157,54 @@ class FrVector:
 
     def __len__(self):
         return self.n
+
+
+class PointVector:
+    """n affine points (x_mont | y_mont, (0,0) = identity) in device memory -- e.g. the folded commitment keys of
+    the IPA rounds."""
+
+    _view_of = None
+
+    def __init__(self, ctx: Context, n: int):
+        self.ctx, self.n = ctx, n
+        self.pb = 16 * ctx.fq_limbs
+        self._nbytes = max(n, 1) * self.pb
+        self.ptr = ctx._alloc(self._nbytes)
+
+    def view(self, off: int, n: int) -> "PointVector":
+        assert 0 <= off and off + n <= self.n
+        v = object.__new__(PointVector)
+        v.ctx, v.n, v.pb, v._nbytes = self.ctx, n, self.pb, 0
+        v.ptr = C.c_void_p(self.ptr.value + off * self.pb)
+        v._view_of = self
+        return v
+
+    @classmethod
+    def of_key(cls, ck: "CommitterKey", n: Optional[int] = None) -> "PointVector":
+        """Non-owning view of the first n generators of a key (level 0 of its table)."""
+        v = object.__new__(PointVector)
+        v.ctx, v.n, v.pb, v._nbytes = ck.ctx, (len(ck) if n is None else n), 16 * ck.ctx.fq_limbs, 0
+        v.ptr = C.c_void_p(ck.ctx._lib.amsm_bases_device_ptr(ck._h))
+        v._view_of = ck
+        return v
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.n, 2 * self.ctx.fq_limbs), dtype=np.uint64)
+        if self.n:
+            ffi.check(self.ctx._lib.amsm_dev_download(self.ctx._h, _ptr(out), self.ptr, out.nbytes), "amsm_dev_download")
+        return out
+
+    def free(self):
+        if self._view_of is None and self.ptr is not None and self.ctx._h:
+            self.ctx._release(self.ptr, self._nbytes)
+        self.ptr = None
+        self._view_of = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class CommitterKey:
@@ -161,6 +224,14 @@ class CommitterKey:
         h = C.c_void_p()
         ffi.check(ctx._lib.amsm_bases_load(ctx._h, _ptr(xy), _ptr(inf), xy.shape[0], flags, C.byref(h)), "amsm_bases_load")
         return cls(ctx, h, hiding_generator)
+
+    @classmethod
+    def from_device(cls, ctx: Context, points: "PointVector", flags: int = ffi.AMSM_BASES_NO_PRECOMPUTE) -> "CommitterKey":
+        """Key over a COPY of device-resident points (one-shot bases, e.g. IPA round keys)."""
+        h = C.c_void_p()
+        ffi.check(ctx._lib.amsm_bases_from_device(ctx._h, points.ptr, points.n, flags, C.byref(h)),
+                  "amsm_bases_from_device")
+        return cls(ctx, h)
 
     @classmethod
     def generate(cls, ctx: Context, seed: int, n: int, flags: int = ffi.AMSM_BASES_DEFAULT) -> "CommitterKey":

@@ -70,6 +70,12 @@ SIGNATURES = {
     "amsm_vec_random": (C.c_int, [_vp, C.c_uint64, _sz, C.c_int, _vp]),
     "amsm_vec_hadamard": (C.c_int, [_vp, _vp, _vp, _vp, _sz]),
     "amsm_vec_combine": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _vp, _sz, _vp, _sz]),
+    "amsm_bases_from_device": (C.c_int, [_vp, _vp, _sz, C.c_uint, C.POINTER(_vp)]),
+    "amsm_bases_device_ptr": (_vp, [_vp]),
+    "amsm_points_fold": (C.c_int, [_vp, _vp, _vp, _sz, _vp, C.c_uint, _vp]),
+    "amsm_vec_inner_product": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "amsm_vec_powers": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "amsm_ipa_check_poly_coeffs": (C.c_int, [_vp, _vp, _sz, _vp]),
     "amsm_matrix_load": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, C.POINTER(_vp)]),
     "amsm_matrix_rows": (_sz, [_vp]),
     "amsm_matrix_free": (None, [_vp]),

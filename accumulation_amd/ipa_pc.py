@@ -1,0 +1,279 @@
+"""Host-side mirror of the inner-product-argument polynomial commitment used by `ipa_pc_as`
+(`ark_poly_commit::ipa_pc::InnerProductArgPC`, branch accumulation-experimental -- NOT in the reference tree and
+not pinned, Cargo.toml:34).  Restated from the published construction (BCMS20 section 7 / Halo-style IPA) with
+the interface the reference calls (src/ipa_pc_as/mod.rs:155,198,400,418,454,525,836):
+
+  commit / cm_commit           one MSM over comm_key[..len]  (+ randomizer * s)
+  open                         log2(d+1) rounds: two half-size MSMs, two inner products, folds of the coefficient
+                               vector, the evaluation vector and the commitment key (K8 of SURVEY.md section 2.1)
+  succinct_check               O(log d) scalar-muls on the host, returns the SuccinctCheckPolynomial
+  check                        succinct_check + compute_coeffs (2^k expansion) + ONE (d+1)-point MSM
+  SuccinctCheckPolynomial      compute_coeffs (device) / evaluate (host, k multiplications)
+
+Every O(d) loop and every MSM runs on the GPU through the C ABI; challenges come from a caller-supplied sponge
+class (see sponge.py).  Self-consistent (prover <-> verifier); byte-level parity with ark-poly-commit is not
+checkable here (PARITY UNPINNED).  Single polynomial per call, no degree bounds -- all the
+accumulation scheme uses."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import ffi
+from .engine import CommitterKey as EngineKey, Context, FrVector, PointVector, VariableBaseMSM, _ptr
+from .hp_as import ASForHadamardProducts, _pt_eq, combine_vectors
+from .scalar_field import Fr
+from .sponge import CryptographicSponge, Sha256Sponge
+
+CHALLENGE_SIZE = 128
+_lincomb = ASForHadamardProducts._lincomb
+
+
+def _zero_pt(ctx):
+    return (np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64), True)
+
+
+@dataclass
+class CommitterKey:  # ipa_pc::CommitterKey{comm_key, h, s, max_degree}; VerifierKey is the same type
+    comm_key: EngineKey
+    h: tuple
+    s: tuple
+    max_degree: int
+
+    def supported_degree(self) -> int:
+        return len(self.comm_key) - 1
+
+    @property
+    def svk(self):
+        return SuccinctVerifierKey(self.h, self.s, self.supported_degree())
+
+
+@dataclass
+class SuccinctVerifierKey:
+    h: tuple
+    s: tuple
+    _supported_degree: int
+
+    def supported_degree(self) -> int:
+        return self._supported_degree
+
+
+@dataclass
+class Commitment:
+    comm: tuple
+    shifted_comm: Optional[tuple] = None
+
+    @staticmethod
+    def default(ctx):
+        return Commitment(_zero_pt(ctx), None)
+
+
+@dataclass
+class Proof:
+    l_vec: List[tuple]
+    r_vec: List[tuple]
+    final_comm_key: tuple
+    c: int
+    hiding_comm: Optional[tuple] = None
+    rand: Optional[int] = None
+
+
+class SuccinctCheckPolynomial:
+    def __init__(self, challenges: List[int]):
+        self.challenges = list(challenges)
+
+    def compute_coeffs(self, ctx: Context) -> FrVector:
+        fr = Fr(ctx.curve)
+        k = len(self.challenges)
+        out = ctx.vector(1 << k)
+        xi = fr.to_limbs_many(self.challenges)
+        ffi.check(ctx._lib.amsm_ipa_check_poly_coeffs(ctx._h, _ptr(xi) if k else None, k, out.ptr),
+                  "amsm_ipa_check_poly_coeffs")
+        return out
+
+    def evaluate(self, fr: Fr, point: int) -> int:
+        k = len(self.challenges)
+        prod = 1
+        for i, ch in enumerate(self.challenges, start=1):
+            elem = pow(point, 1 << (k - i), fr.r)
+            prod = prod * (1 + elem * ch) % fr.r
+        return prod
+
+    def to_bytes(self, fr: Fr) -> bytes:
+        return b"".join((c % fr.r).to_bytes(32, "little") for c in self.challenges)
+
+
+class InnerProductArgPC:
+    sponge_cls = Sha256Sponge  # S of the reference's generic parameter; any CryptographicSponge subclass
+
+    # ---- keys -------------------------------------------------------------------------------------
+    @classmethod
+    def setup(cls, ctx: Context, max_degree: int, seed: int = 0x1BA5EED) -> CommitterKey:
+        """UniversalParams: max_degree+1 generators + h + s (synthetic stream; ark-poly-commit hashes to the curve)."""
+        n = 1 << (max_degree + 1 - 1).bit_length()  # (max_degree + 1).next_power_of_two()
+        tmp = EngineKey.generate(ctx, seed, n + 2, ffi.AMSM_BASES_NO_PRECOMPUTE)
+        xy, _ = tmp.read()
+        tmp.free()
+        key = EngineKey.load(ctx, xy[:n], None, ffi.AMSM_BASES_DEFAULT)
+        cls._pp_xy = xy
+        return CommitterKey(key, (xy[n].copy(), False), (xy[n + 1].copy(), False), n - 1)
+
+    @classmethod
+    def trim(cls, pp: CommitterKey, supported_degree: int):
+        """-> (ck, vk) with (supported_degree+1).next_power_of_two() generators (prefix of the universal key)."""
+        ctx = pp.comm_key.ctx
+        n = 1 << (supported_degree + 1 - 1).bit_length()
+        assert n <= len(pp.comm_key)
+        if n == len(pp.comm_key):
+            ck = pp
+        else:
+            xy, _ = pp.comm_key.read(0, n)
+            ck = CommitterKey(EngineKey.load(ctx, xy, None, ffi.AMSM_BASES_DEFAULT), pp.h, pp.s, pp.max_degree)
+        return ck, ck
+
+    # ---- commit -----------------------------------------------------------------------------------
+    @staticmethod
+    def cm_commit(key: EngineKey, scalars: FrVector, hiding_generator=None, randomizer: Optional[int] = None):
+        """msm(key[..len], scalars) (+ randomizer * hiding_generator) -> affine"""
+        ctx = key.ctx
+        out = VariableBaseMSM.multi_scalar_mul(key, scalars, mont=True)
+        if randomizer is not None:
+            fr = Fr(ctx.curve)
+            out = _lincomb(ctx, [out, hiding_generator], [1, randomizer], fr)
+        return out
+
+    @classmethod
+    def commit(cls, ck: CommitterKey, polynomial: FrVector, hiding: bool = False, rng=None):
+        """-> (Commitment, rand).  hiding <=> LabeledPolynomial::hiding_bound().is_some()"""
+        rand = rng.field() if hiding else 0
+        comm = cls.cm_commit(ck.comm_key, polynomial, ck.s, rand if hiding else None)
+        return Commitment(comm, None), rand
+
+    # ---- challenges ---------------------------------------------------------------------------------
+    @classmethod
+    def _challenge(cls, fr: Fr, parts) -> int:
+        sp = cls.sponge_cls().fork(b"IPA-PC")
+        for p in parts:
+            if isinstance(p, tuple):
+                sp.absorb_point(p)
+            elif isinstance(p, bytes):
+                sp.absorb_bytes(p)
+            else:
+                sp.absorb_bytes((int(p) % fr.r).to_bytes(32, "little"))
+        return sp.squeeze_field_elements(1, CHALLENGE_SIZE)[0]
+
+    # ---- open ---------------------------------------------------------------------------------------
+    @classmethod
+    def open(cls, ck: CommitterKey, polynomial: FrVector, commitment: Commitment, point: int, rand: int = 0,
+             hiding: bool = False, rng=None) -> Proof:
+        """open_individual_opening_challenges for ONE polynomial with opening challenge 1."""
+        ctx = ck.comm_key.ctx
+        fr = Fr(ctx.curve)
+        d = ck.supported_degree()
+        n = d + 1
+        assert polynomial.n <= n
+        one = fr.to_limbs(1)
+        z = ctx.vector(n)
+        ffi.check(ctx._lib.amsm_vec_powers(ctx._h, _ptr(fr.to_limbs(point)), n, z.ptr), "amsm_vec_powers")
+        # coefficient vector padded to d+1
+        coeffs = combine_vectors(ctx, [polynomial], one.reshape(1, 4), ctx.fill(fr.to_limbs(0), n))
+        combined_comm = commitment.comm
+        combined_v = cls._inner_product(ctx, fr, coeffs, z)
+        hiding_comm = None
+        proof_rand = None
+        if hiding:
+            assert rng is not None
+            # random polynomial that vanishes at `point`
+            hp = ctx.upload(fr.to_limbs_many([rng.field() for _ in range(n)]))
+            hv = cls._inner_product(ctx, fr, hp, z)
+            hp = combine_vectors(ctx, [hp, ctx.upload(fr.to_limbs_many([(-hv) % fr.r]))], np.stack([one, one]))
+            hiding_rand = rng.field()
+            hiding_comm = cls.cm_commit(ck.comm_key, hp, ck.s, hiding_rand)
+            hch = cls._challenge(fr, [combined_comm, point, combined_v, hiding_comm])
+            coeffs = combine_vectors(ctx, [coeffs, hp], np.stack([one, fr.to_limbs(hch)]))
+            proof_rand = (rand + hch * hiding_rand) % fr.r
+            combined_comm = _lincomb(ctx, [combined_comm, hiding_comm, ck.s], [1, hch, (-proof_rand) % fr.r], fr)
+        round_challenge = cls._challenge(fr, [combined_comm, point, combined_v])
+        h_prime = _lincomb(ctx, [ck.h], [round_challenge], fr)
+        key = PointVector.of_key(ck.comm_key, n)
+        l_vec, r_vec = [], []
+        while n > 1:
+            half = n // 2
+            c_l, c_r = coeffs.view(0, half), coeffs.view(half, half)
+            z_l, z_r = z.view(0, half), z.view(half, half)
+            k_l, k_r = key.view(0, half), key.view(half, half)
+            kl_key = EngineKey.from_device(ctx, k_l)
+            kr_key = EngineKey.from_device(ctx, k_r)
+            l_pt = _lincomb(ctx, [cls.cm_commit(kl_key, c_r), h_prime], [1, cls._inner_product(ctx, fr, c_r, z_l)], fr)
+            r_pt = _lincomb(ctx, [cls.cm_commit(kr_key, c_l), h_prime], [1, cls._inner_product(ctx, fr, c_l, z_r)], fr)
+            kl_key.free()
+            kr_key.free()
+            l_vec.append(l_pt)
+            r_vec.append(r_pt)
+            round_challenge = cls._challenge(fr, [round_challenge.to_bytes(16, "little"), l_pt, r_pt])
+            inv = pow(round_challenge, -1, fr.r)
+            coeffs = combine_vectors(ctx, [c_l, c_r], np.stack([one, fr.to_limbs(inv)]))
+            z = combine_vectors(ctx, [z_l, z_r], np.stack([one, fr.to_limbs(round_challenge)]))
+            new_key = PointVector(ctx, half)
+            ffi.check(ctx._lib.amsm_points_fold(ctx._h, k_l.ptr, k_r.ptr, half, _ptr(fr.to_limbs(round_challenge)),
+                                                CHALLENGE_SIZE, new_key.ptr), "amsm_points_fold")
+            key = new_key
+            n = half
+        final_key = key.download()[0]
+        c = fr.from_limbs(coeffs.download()[0])
+        return Proof(l_vec, r_vec, (final_key, not final_key.any()), c, hiding_comm, proof_rand)
+
+    @staticmethod
+    def _inner_product(ctx, fr: Fr, a: FrVector, b: FrVector) -> int:
+        out = np.zeros(4, dtype=np.uint64)
+        ffi.check(ctx._lib.amsm_vec_inner_product(ctx._h, a.ptr, b.ptr, min(a.n, b.n), _ptr(out)), "amsm_vec_inner_product")
+        return fr.from_limbs(out)
+
+    # ---- succinct check / check ------------------------------------------------------------------------
+    @classmethod
+    def succinct_check(cls, ctx: Context, svk, commitment: Commitment, point: int, value: int, proof: Proof
+                       ) -> Optional[SuccinctCheckPolynomial]:
+        fr = Fr(ctx.curve)
+        d = svk.supported_degree()
+        log_d = (d + 1).bit_length() - 1
+        if commitment.shifted_comm is not None:
+            return None
+        if len(proof.l_vec) != len(proof.r_vec) or len(proof.l_vec) != log_d:
+            return None
+        if (proof.hiding_comm is None) != (proof.rand is None):
+            return None
+        combined_comm = commitment.comm
+        if proof.hiding_comm is not None:
+            hch = cls._challenge(fr, [combined_comm, point, value, proof.hiding_comm])
+            combined_comm = _lincomb(ctx, [combined_comm, proof.hiding_comm, svk.s], [1, hch, (-proof.rand) % fr.r], fr)
+        round_challenge = cls._challenge(fr, [combined_comm, point, value])
+        h_prime = _lincomb(ctx, [svk.h], [round_challenge], fr)
+        pts, scs = [combined_comm, h_prime], [1, value]
+        challenges = []
+        for l_pt, r_pt in zip(proof.l_vec, proof.r_vec):
+            round_challenge = cls._challenge(fr, [round_challenge.to_bytes(16, "little"), l_pt, r_pt])
+            if round_challenge == 0:
+                return None
+            challenges.append(round_challenge)
+            pts += [l_pt, r_pt]
+            scs += [pow(round_challenge, -1, fr.r), round_challenge]
+        round_commitment = _lincomb(ctx, pts, scs, fr)
+        check_poly = SuccinctCheckPolynomial(challenges)
+        v_prime = check_poly.evaluate(fr, point) * proof.c % fr.r
+        check_commitment = _lincomb(ctx, [proof.final_comm_key, h_prime], [proof.c, v_prime], fr)
+        if not _pt_eq(round_commitment, check_commitment):
+            return None
+        return check_poly
+
+    @classmethod
+    def check(cls, vk: CommitterKey, commitment: Commitment, point: int, value: int, proof: Proof) -> bool:
+        ctx = vk.comm_key.ctx
+        check_poly = cls.succinct_check(ctx, vk.svk, commitment, point, value, proof)
+        if check_poly is None:
+            return False
+        coeffs = check_poly.compute_coeffs(ctx)          # 2^k field multiplications on the device
+        final_key = cls.cm_commit(vk.comm_key, coeffs)   # THE (d+1)-point MSM of the decider
+        return _pt_eq(final_key, proof.final_comm_key)

@@ -181,6 +181,25 @@ int amsm_hp_t_vecs(amsm_ctx* ctx, const void* const* d_a, const size_t* a_lens, 
                    const size_t* b_lens, size_t n_inputs, const uint64_t* mu_mont, size_t n_mu, const void* d_hiding_a,
                    size_t hiding_a_len, const void* d_hiding_b, size_t hiding_b_len, void* const* d_t, size_t len);
 
+/* ---- inner-product-argument opening (ark_poly_commit::ipa_pc, ext) ------------ */
+/* Committer key living in device memory (the folded keys of the IPA rounds change every round, so they are
+ * never precomputed): wraps a COPY of n affine points (Montgomery x|y, (0,0) = identity) at d_xy. */
+int amsm_bases_from_device(amsm_ctx* ctx, const void* d_xy_mont, size_t n, unsigned flags, amsm_bases** out);
+/* Device pointer to generators [0, len) of a key (affine, Montgomery), valid while the key lives. */
+const void* amsm_bases_device_ptr(const amsm_bases* bases);
+/* d_out[i] = d_l[i] + x * d_r[i], i < n, affine in / affine out: the key fold `key_l += key_r * xi` of
+ * `open_individual_opening_challenges` (ext; under src/ipa_pc_as/mod.rs:454).  x_mont: 4 u64; nbits = number of
+ * significant bits of the canonical x (128 for the truncated round challenges, 255 in general). */
+int amsm_points_fold(amsm_ctx* ctx, const void* d_l, const void* d_r, size_t n, const uint64_t* x_mont,
+                     unsigned nbits, void* d_out);
+/* out_mont = sum_i a[i]*b[i]  (`inner_product` of the IPA rounds; polynomial evaluation as <coeffs, powers>). */
+int amsm_vec_inner_product(amsm_ctx* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* out_mont);
+/* d_out[i] = point^i, i < n  (the evaluation vector z of the opening). */
+int amsm_vec_powers(amsm_ctx* ctx, const uint64_t* point_mont, size_t n, void* d_out);
+/* d_out[p] (p < 2^k) = coefficients of prod_{i=1..k} (1 + xi_i X^(2^(k-i))):
+ * `SuccinctCheckPolynomial::compute_coeffs` (ext), call sites src/ipa_pc_as/mod.rs:400 and under :836. k <= 32. */
+int amsm_ipa_check_poly_coeffs(amsm_ctx* ctx, const uint64_t* xi_mont, size_t k, void* d_out);
+
 /* ---- R1CS matrices (row-sparse) for the NARK prover -------------------------------------------- */
 typedef struct amsm_matrix amsm_matrix;
 /* Replaces `Matrix<F> = Vec<Vec<(F, usize)>>` of `IndexProverKey{a,b,c}`

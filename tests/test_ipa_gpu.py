@@ -1,0 +1,167 @@
+"""GPU tests for the IPA polynomial-commitment path (ark_poly_commit::ipa_pc restated in
+accumulation_amd/ipa_pc.py) and the reference's accumulation-scheme test template for
+AtomicASForInnerProductArgPC (src/ipa_pc_as/mod.rs:890-1111: degree 11, zk and no-zk, six scenarios)."""
+import numpy as np
+import pytest
+
+from oracle import pyref as o
+from tests import helpers as h
+from tests.test_hp_as_scheme_gpu import SchemeRng
+
+pytestmark = pytest.mark.gpu
+
+NUM_ITERATIONS = 3
+DEGREE = 11  # src/ipa_pc_as/mod.rs:1017 ff. (trimmed up to 15 = next power of two - 1)
+
+
+@pytest.fixture(scope="module")
+def env():
+    from accumulation_amd import Context, ffi
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
+    ctx = Context(ffi.AMSM_PALLAS)
+    pp = IpaPC.setup(ctx, DEGREE, seed=0xABCDEF)
+    yield ctx, pp
+    ctx.close()
+
+
+def test_ipa_kernels_vs_oracle(env):
+    """points_fold, inner product, powers and compute_coeffs against the Python big-int oracle."""
+    import ctypes as C
+    from accumulation_amd import PointVector, ffi
+    from accumulation_amd.engine import _ptr
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC, SuccinctCheckPolynomial
+    from accumulation_amd.scalar_field import Fr
+    ctx, pp = env
+    c = o.PALLAS
+    fr = Fr(ctx.curve)
+    n = 37
+    a, b = o.rng_scalars(1, n), o.rng_scalars(2, n)
+    da, db = ctx.upload(h.fr_mont_np(c, a)), ctx.upload(h.fr_mont_np(c, b))
+    assert IpaPC._inner_product(ctx, fr, da, db) == sum(x * y for x, y in zip(a, b)) % c.r
+    pt = o.rng_scalar(3, 0) % c.r
+    z = ctx.vector(n)
+    ffi.check(ctx._lib.amsm_vec_powers(ctx._h, _ptr(fr.to_limbs(pt)), n, z.ptr), "powers")
+    assert h.fr_from_mont_np(c, z.download()) == [pow(pt, i, c.r) for i in range(n)]
+    xi = [o.rng_scalar(4, i) % (1 << 128) for i in range(4)]
+    got = h.fr_from_mont_np(c, SuccinctCheckPolynomial(xi).compute_coeffs(ctx).download())
+    exp = []
+    for p in range(16):
+        v = 1
+        for i in range(1, 5):
+            if (p >> (4 - i)) & 1:
+                v = v * xi[i - 1] % c.r
+        exp.append(v)
+    assert got == exp
+    # h(point) evaluated two ways
+    hv = sum(cf * pow(pt, i, c.r) for i, cf in enumerate(exp)) % c.r
+    assert SuccinctCheckPolynomial(xi).evaluate(fr, pt) == hv
+    # key fold l + x*r on points
+    pts = o.rng_points(c, 77, 12)
+    xy, _ = h.points_to_np(c, pts)
+    pv = PointVector(ctx, 12)
+    ffi.check(ctx._lib.amsm_dev_upload(ctx._h, pv.ptr, _ptr(xy), xy.nbytes), "upload")
+    out = PointVector(ctx, 6)
+    x = xi[0]
+    ffi.check(ctx._lib.amsm_points_fold(ctx._h, pv.view(0, 6).ptr, pv.view(6, 6).ptr, 6, _ptr(fr.to_limbs(x)), 128,
+                                        out.ptr), "fold")
+    got = out.download()
+    for i in range(6):
+        assert h.np_to_point(c, got[i], 0) == o.add(c, pts[i], o.mul(c, x, pts[6 + i]))
+
+
+@pytest.mark.parametrize("hiding", [False, True], ids=["plain", "hiding"])
+def test_ipa_commit_open_check(env, hiding):
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
+    from accumulation_amd.scalar_field import Fr
+    ctx, pp = env
+    c = o.PALLAS
+    fr = Fr(ctx.curve)
+    ck, vk = IpaPC.trim(pp, DEGREE)
+    assert ck.supported_degree() == 15
+    rng = SchemeRng(99)
+    coeffs = [rng.field() % c.r for _ in range(DEGREE + 1)]
+    poly = ctx.upload(fr.to_limbs_many(coeffs))
+    comm, rand = IpaPC.commit(ck, poly, hiding, rng)
+    # the commitment is the MSM the oracle computes
+    xy, _ = ck.comm_key.read()
+    gens = [h.np_to_point(c, xy[i], 0) for i in range(16)]
+    exp = o.msm_naive(c, gens[:12], coeffs)
+    if hiding:
+        exp = o.add(c, exp, o.mul(c, rand, h.np_to_point(c, ck.s[0], 0)))
+    assert h.np_to_point(c, *comm.comm) == exp
+    point = rng.field() % c.r
+    value = sum(cf * pow(point, i, c.r) for i, cf in enumerate(coeffs)) % c.r
+    proof = IpaPC.open(ck, poly, comm, point, rand, hiding, rng)
+    assert len(proof.l_vec) == 4
+    assert IpaPC.check(vk, comm, point, value, proof)
+    assert not IpaPC.check(vk, comm, point, (value + 1) % c.r, proof)
+    assert not IpaPC.check(vk, comm, (point + 1) % c.r, value, proof)
+
+
+def generate_inputs(env, pk, num_inputs, make_zk, rng):
+    """src/ipa_pc_as/mod.rs:930-1004: random polynomial, commit, random point, evaluate, open"""
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
+    from accumulation_amd.ipa_pc_as import InputInstance
+    from accumulation_amd.scalar_field import Fr
+    ctx, pp = env
+    fr = Fr(ctx.curve)
+    out = []
+    for _ in range(num_inputs):
+        coeffs = [rng.field() % fr.r for _ in range(DEGREE + 1)]
+        poly = ctx.upload(fr.to_limbs_many(coeffs))
+        comm, rand = IpaPC.commit(pk.ipa_ck, poly, make_zk, rng)
+        point = rng.field() % fr.r
+        value = sum(cf * pow(point, i, fr.r) for i, cf in enumerate(coeffs)) % fr.r
+        proof = IpaPC.open(pk.ipa_ck, poly, comm, point, rand, make_zk, rng)
+        out.append(InputInstance(comm, point, value, proof))
+    return out
+
+
+def run_template(env, num_inputs_per_iteration, make_zk, num_iterations=NUM_ITERATIONS):
+    from accumulation_amd.ipa_pc_as import AtomicASForInnerProductArgPC as AS
+    ctx, pp = env
+    pk, vk, dk = AS.index(pp, DEGREE)
+    rng = SchemeRng(4096)
+    total = num_iterations * sum(num_inputs_per_iteration)
+    inputs = generate_inputs(env, pk, total, make_zk, rng)
+    start = 0
+    for _ in range(num_iterations):
+        old = []
+        for k in num_inputs_per_iteration:
+            step = inputs[start:start + k]
+            start += k
+            acc, proof = AS.prove(pk, step, [a.instance for a in old], rng if make_zk else None, None)
+            assert AS.verify(ctx, vk, step, [a.instance for a in old], acc.instance, proof, None), "Verify failed"
+            old.append(acc)
+        assert AS.decide(dk, old[-1], None), "Decide failed"
+    return True
+
+
+@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
+class TestASForIpaPC:
+    def test_single_input_init(self, env, make_zk):
+        assert run_template(env, [1], make_zk)
+
+    def test_multiple_inputs_init(self, env, make_zk):
+        assert run_template(env, [3], make_zk)
+
+    def test_simple_accumulation(self, env, make_zk):
+        assert run_template(env, [1, 1], make_zk)
+
+    def test_multiple_inputs_accumulation(self, env, make_zk):
+        assert run_template(env, [1, 1, 2, 3], make_zk, num_iterations=2)
+
+    def test_accumulators_only(self, env, make_zk):
+        assert run_template(env, [1, 0, 0, 0], make_zk)
+
+    def test_no_inputs_init(self, env, make_zk):
+        assert run_template(env, [0], make_zk, num_iterations=1)
+
+
+def test_sponge_argument_is_refused(env):
+    from accumulation_amd.ipa_pc_as import AtomicASForInnerProductArgPC as AS
+    from accumulation_amd.sponge import Sha256Sponge
+    ctx, pp = env
+    pk, vk, dk = AS.index(pp, DEGREE)
+    with pytest.raises(NotImplementedError):  # src/ipa_pc_as/mod.rs:566-570
+        AS.prove(pk, [], [], None, Sha256Sponge())
