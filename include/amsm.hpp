@@ -1,0 +1,276 @@
+// amsm.hpp -- header-only C++17 host-side mirror of the reference interfaces on the MSM hot path, over the C
+// ABI of amsm.h.  The reference is compiled code (Rust); this is the compiled-language twin of the Python mirror
+// in accumulation_amd/engine.py + hp_as.py: same names, argument meaning and error behaviour as
+//   ark_ec::msm::VariableBaseMSM::multi_scalar_mul                       (ext)
+//   ark_poly_commit::trivial_pc::{PedersenCommitment, CommitterKey}      (ext, a2; src/hp_as/mod.rs:196,377,911)
+//   ASForHadamardProducts::{compute_hp, combine_vectors, scale_vector, compute_t_vecs,
+//                           compute_product_poly_comm} and the decider's three commitments
+//                                                                        (src/hp_as/mod.rs:278-512, 354-388, 894-925)
+// Errors: every non-zero ABI status is thrown as amsm::Error (the Rust adapter maps it to BoxedError).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "amsm.h"
+
+namespace amsm {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int s, const char* where) : std::runtime_error(std::string(where) + ": " + amsm_strerror(s)), status(s) {}
+};
+inline void check(int s, const char* where) {
+  if (s != AMSM_OK) throw Error(s, where);
+}
+
+// Affine point in the ABI's format: x_mont | y_mont (2*limbs u64) + infinity flag.
+struct Affine {
+  std::vector<uint64_t> xy;
+  bool infinity = true;
+  bool operator==(const Affine& o) const { return infinity == o.infinity && (infinity || xy == o.xy); }
+};
+using Fr = std::array<uint64_t, 4>;  // Montgomery limbs of one scalar-field element (raw ark-ff memory)
+
+class Context {
+ public:
+  explicit Context(int curve = AMSM_PALLAS, int device = 0, void* stream = nullptr) {
+    check(amsm_ctx_create(&h_, curve, device, stream), "amsm_ctx_create");
+  }
+  ~Context() { amsm_ctx_destroy(h_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  amsm_ctx* get() const { return h_; }
+  int fq_limbs() const { return amsm_ctx_fq_limbs(h_); }
+  void synchronize() { check(amsm_ctx_synchronize(h_), "amsm_ctx_synchronize"); }
+
+ private:
+  amsm_ctx* h_ = nullptr;
+};
+
+// `Vec<G::ScalarField>` resident in HBM.
+class FrVector {
+ public:
+  FrVector(Context& ctx, size_t n) : ctx_(&ctx), n_(n) {
+    check(amsm_dev_alloc(ctx.get(), n * 32, &p_), "amsm_dev_alloc");
+  }
+  FrVector(Context& ctx, const std::vector<Fr>& host) : FrVector(ctx, host.size()) {
+    if (n_) check(amsm_dev_upload(ctx.get(), p_, host.data(), n_ * 32), "amsm_dev_upload");
+  }
+  static FrVector random(Context& ctx, uint64_t seed, size_t n, bool mont) {
+    FrVector v(ctx, n);
+    check(amsm_vec_random(ctx.get(), seed, n, mont ? 1 : 0, v.p_), "amsm_vec_random");
+    return v;
+  }
+  ~FrVector() {
+    if (p_) amsm_dev_free(ctx_->get(), p_);
+  }
+  FrVector(FrVector&& o) noexcept : ctx_(o.ctx_), n_(o.n_), p_(o.p_) { o.p_ = nullptr; }
+  FrVector(const FrVector&) = delete;
+  FrVector& operator=(const FrVector&) = delete;
+  size_t len() const { return n_; }
+  const void* ptr() const { return p_; }
+  void* ptr() { return p_; }
+  std::vector<Fr> to_host() const {
+    std::vector<Fr> out(n_);
+    if (n_) check(amsm_dev_download(ctx_->get(), out.data(), p_, n_ * 32), "amsm_dev_download");
+    return out;
+  }
+  Context& ctx() const { return *ctx_; }
+
+ private:
+  Context* ctx_;
+  size_t n_;
+  void* p_ = nullptr;
+};
+
+// trivial_pc::CommitterKey{generators, hiding_generator}: generators live in HBM (precomputed window multiples).
+class CommitterKey {
+ public:
+  static CommitterKey load(Context& ctx, const std::vector<uint64_t>& xy_mont, const std::vector<uint8_t>* is_inf,
+                           unsigned flags = AMSM_BASES_DEFAULT) {
+    CommitterKey k(ctx);
+    size_t n = xy_mont.size() / (2 * (size_t)ctx.fq_limbs());
+    check(amsm_bases_load(ctx.get(), xy_mont.data(), is_inf ? is_inf->data() : nullptr, n, flags, &k.h_),
+          "amsm_bases_load");
+    return k;
+  }
+  ~CommitterKey() { amsm_bases_free(h_); }
+  CommitterKey(CommitterKey&& o) noexcept : ctx_(o.ctx_), h_(o.h_), hiding_generator(std::move(o.hiding_generator)) {
+    o.h_ = nullptr;
+  }
+  CommitterKey(const CommitterKey&) = delete;
+  size_t supported_num_elems() const { return amsm_bases_len(h_); }
+  const amsm_bases* get() const { return h_; }
+  Context& ctx() const { return *ctx_; }
+  std::vector<uint64_t> read(size_t off, size_t n) const {
+    std::vector<uint64_t> xy(n * 2 * (size_t)ctx_->fq_limbs());
+    check(amsm_bases_read(ctx_->get(), h_, off, n, xy.data(), nullptr), "amsm_bases_read");
+    return xy;
+  }
+  std::vector<uint64_t> hiding_generator;  // affine x|y (Montgomery), host side
+
+ private:
+  friend struct PedersenCommitment;
+  explicit CommitterKey(Context& ctx) : ctx_(&ctx) {}
+  Context* ctx_;
+  amsm_bases* h_ = nullptr;
+};
+
+struct VariableBaseMSM {
+  // multi_scalar_mul(&bases, &scalars): scalars = canonical BigInt limbs (`into_repr()`), n*4 u64 on the host.
+  static Affine multi_scalar_mul(const CommitterKey& bases, const std::vector<Fr>& scalars) {
+    Affine out;
+    out.xy.assign(2 * (size_t)bases.ctx().fq_limbs(), 0);
+    uint8_t inf = 0;
+    check(amsm_msm(bases.ctx().get(), bases.get(), 0, reinterpret_cast<const uint64_t*>(scalars.data()), scalars.size(),
+                   0, out.xy.data(), &inf),
+          "amsm_msm");
+    out.infinity = inf != 0;
+    return out;
+  }
+  // device-resident Montgomery scalars (the form the vector kernels produce)
+  static Affine multi_scalar_mul(const CommitterKey& bases, const FrVector& scalars_mont) {
+    Affine out;
+    out.xy.assign(2 * (size_t)bases.ctx().fq_limbs(), 0);
+    uint8_t inf = 0;
+    check(amsm_msm_device(bases.ctx().get(), bases.get(), 0, scalars_mont.ptr(), scalars_mont.len(), 1, out.xy.data(),
+                          &inf),
+          "amsm_msm_device");
+    out.infinity = inf != 0;
+    return out;
+  }
+};
+
+struct PedersenCommitment {
+  // setup(n): n generators + a hiding generator (synthetic stream; see amsm_bases_generate)
+  static CommitterKey setup(Context& ctx, size_t n, uint64_t seed = 0x5EED1001ull, unsigned flags = AMSM_BASES_DEFAULT) {
+    amsm_bases* tmp = nullptr;
+    check(amsm_bases_generate(ctx.get(), seed, n + 1, AMSM_BASES_NO_PRECOMPUTE, &tmp), "amsm_bases_generate");
+    size_t w = 2 * (size_t)ctx.fq_limbs();
+    std::vector<uint64_t> xy((n + 1) * w);
+    int s = amsm_bases_read(ctx.get(), tmp, 0, n + 1, xy.data(), nullptr);
+    amsm_bases_free(tmp);
+    check(s, "amsm_bases_read");
+    CommitterKey k(ctx);
+    check(amsm_bases_load(ctx.get(), xy.data(), nullptr, n, flags, &k.h_), "amsm_bases_load");
+    k.hiding_generator.assign(xy.begin() + (long)(n * w), xy.end());
+    return k;
+  }
+  // commit(ck, elems, randomizer): elems Montgomery; randomizer == nullptr <=> None
+  static Affine commit(const CommitterKey& ck, const FrVector& elems, const Fr* randomizer = nullptr) {
+    Affine out;
+    out.xy.assign(2 * (size_t)ck.ctx().fq_limbs(), 0);
+    uint8_t inf = 0;
+    if (randomizer && ck.hiding_generator.empty()) throw Error(AMSM_E_INVALID_ARG, "commit: key has no hiding generator");
+    check(amsm_pedersen_commit_device(ck.ctx().get(), ck.get(), elems.ptr(), elems.len(),
+                                      randomizer ? randomizer->data() : nullptr,
+                                      randomizer ? ck.hiding_generator.data() : nullptr, out.xy.data(), &inf),
+          "amsm_pedersen_commit_device");
+    out.infinity = inf != 0;
+    return out;
+  }
+};
+
+// The scalar-field vector loops of ASForHadamardProducts (src/hp_as/mod.rs).
+namespace hp_as {
+
+inline FrVector compute_hp(const FrVector& a, const FrVector& b) {  // :278-285 (zip truncates)
+  size_t n = a.len() < b.len() ? a.len() : b.len();
+  FrVector out(a.ctx(), n);
+  check(amsm_vec_hadamard(a.ctx().get(), a.ptr(), b.ptr(), out.ptr(), n), "amsm_vec_hadamard");
+  return out;
+}
+
+inline FrVector combine_vectors(Context& ctx, const std::vector<const FrVector*>& vectors, const std::vector<Fr>& challenges,
+                                const FrVector* hiding = nullptr) {  // :492-512
+  size_t n = hiding ? hiding->len() : 0;
+  std::vector<const void*> ptrs;
+  std::vector<size_t> lens;
+  for (auto* v : vectors) {
+    ptrs.push_back(v->ptr());
+    lens.push_back(v->len());
+    if (v->len() > n) n = v->len();
+  }
+  FrVector out(ctx, n);
+  check(amsm_vec_combine(ctx.get(), ptrs.data(), lens.data(), vectors.size(),
+                         reinterpret_cast<const uint64_t*>(challenges.data()), hiding ? hiding->ptr() : nullptr,
+                         hiding ? hiding->len() : 0, out.ptr(), n),
+        "amsm_vec_combine");
+  return out;
+}
+
+inline FrVector scale_vector(const FrVector& v, const Fr& coeff) {  // :482-489
+  return combine_vectors(v.ctx(), {&v}, {coeff});
+}
+
+// :288-349.  Returns the 2n-1 coefficient vectors; index n-1 (never committed, :373-375) is computed only when
+// `with_uncommitted` is set.
+inline std::vector<std::unique_ptr<FrVector>> compute_t_vecs(Context& ctx, const std::vector<const FrVector*>& a_vecs,
+                                                             const std::vector<const FrVector*>& b_vecs,
+                                                             const std::vector<Fr>& mu, size_t hp_vec_len,
+                                                             const FrVector* hiding_a = nullptr,
+                                                             const FrVector* hiding_b = nullptr,
+                                                             bool with_uncommitted = true) {
+  size_t n = a_vecs.size();
+  std::vector<const void*> pa, pb;
+  std::vector<size_t> la, lb;
+  for (size_t j = 0; j < n; j++) {
+    pa.push_back(a_vecs[j]->ptr());
+    la.push_back(a_vecs[j]->len());
+    pb.push_back(b_vecs[j]->ptr());
+    lb.push_back(b_vecs[j]->len());
+  }
+  std::vector<std::unique_ptr<FrVector>> out;
+  std::vector<void*> pt;
+  for (size_t k = 0; k + 1 < 2 * n; k++) {
+    if (k == n - 1 && !with_uncommitted) {
+      out.emplace_back(nullptr);
+      pt.push_back(nullptr);
+    } else {
+      out.emplace_back(new FrVector(ctx, hp_vec_len));
+      pt.push_back(out.back()->ptr());
+    }
+  }
+  check(amsm_hp_t_vecs(ctx.get(), pa.data(), la.data(), pb.data(), lb.data(), n,
+                       reinterpret_cast<const uint64_t*>(mu.data()), mu.size(), hiding_a ? hiding_a->ptr() : nullptr,
+                       hiding_a ? hiding_a->len() : 0, hiding_b ? hiding_b->ptr() : nullptr,
+                       hiding_b ? hiding_b->len() : 0, pt.data(), hp_vec_len),
+        "amsm_hp_t_vecs");
+  return out;
+}
+
+// :354-388: commitments to every t_vec except index n-1, as (low, high); one batched call (3 MSMs in flight).
+inline std::pair<std::vector<Affine>, std::vector<Affine>> compute_product_poly_comm(
+    const CommitterKey& ck, const std::vector<std::unique_ptr<FrVector>>& t_vecs) {
+  std::pair<std::vector<Affine>, std::vector<Affine>> out;
+  if (t_vecs.empty()) return out;
+  size_t n = (t_vecs.size() + 1) / 2;
+  std::vector<const void*> ptrs;
+  size_t len = 0;
+  for (size_t i = 0; i < t_vecs.size(); i++)
+    if (i != n - 1) {
+      ptrs.push_back(t_vecs[i]->ptr());
+      len = t_vecs[i]->len();
+    }
+  size_t w = 2 * (size_t)ck.ctx().fq_limbs();
+  std::vector<uint64_t> xy(ptrs.size() * w);
+  std::vector<uint8_t> inf(ptrs.size());
+  check(amsm_msm_batch_device(ck.ctx().get(), ck.get(), 0, ptrs.data(), ptrs.size(), len, 1, xy.data(), inf.data()),
+        "amsm_msm_batch_device");
+  for (size_t i = 0; i < ptrs.size(); i++) {
+    Affine p;
+    p.xy.assign(xy.begin() + (long)(i * w), xy.begin() + (long)((i + 1) * w));
+    p.infinity = inf[i] != 0;
+    (i < n - 1 ? out.first : out.second).push_back(std::move(p));
+  }
+  return out;
+}
+
+}  // namespace hp_as
+}  // namespace amsm
