@@ -258,3 +258,70 @@ def test_partials_roundtrip_single_rank(ctxs, cref):
         inf = C.c_uint8(0)
         ffi.check(ctx._lib.amsm_partials_combine(ctx._h, buf.ptr, 2, _ptr(out), C.byref(inf)), "combine")
         assert bool(inf.value) == rinf and np.array_equal(out, ref)
+
+
+def test_randomized_geometry_stress(ctxs, cref):
+    """Random (n, window, key kind, chunk length) combinations against the C oracle: exercises entry counts that are
+    not multiples of the group size, chunks that straddle many / few buckets, windows whose last digit is short."""
+    import os
+    from accumulation_amd import CommitterKey, VariableBaseMSM
+    c = o.PALLAS
+    ctx = ctxs[c.name]
+    xy_all = cref.rng_points(c.curve_id, 4242, 3000)
+    sc_all = cref.rng_scalars(4343, 3000)
+    try:
+        for t in range(24):
+            n = 1 + o.rng_word(99, 3 * t) % 2999
+            w = 2 + o.rng_word(99, 3 * t + 1) % 18
+            flags = 1 + o.rng_word(99, 3 * t + 2) % 2
+            ctx.set_window(w)
+            ck = CommitterKey.load(ctx, xy_all[:n], None, flags)
+            out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc_all[:n])
+            ref, rinf = cref.msm(c.curve_id, xy_all[:n], sc_all[:n], threads=2)
+            assert oinf == rinf and np.array_equal(out, ref), (n, w, flags)
+            ck.free()
+    finally:
+        ctx.set_window(0)
+
+
+@pytest.mark.parametrize("k0", ["4", "8", "20", "64"])
+def test_chunk_length_override(cref, k0):
+    """AMSM_K0 (entries per accumulate-L0 lane) only changes the work split, never the result."""
+    import os
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    c = o.PALLAS
+    old = os.environ.get("AMSM_K0")
+    os.environ["AMSM_K0"] = k0
+    try:
+        ctx = Context(c.curve_id)
+        n = 5000
+        xy = cref.rng_points(c.curve_id, 1, n)
+        sc = cref.rng_scalars(2, n)
+        ref, rinf = cref.msm(c.curve_id, xy, sc, threads=4)
+        for flags in (1, 2):
+            ck = CommitterKey.load(ctx, xy, None, flags)
+            out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
+            assert oinf == rinf and np.array_equal(out, ref), (k0, flags)
+            ck.free()
+        ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("AMSM_K0", None)
+        else:
+            os.environ["AMSM_K0"] = old
+
+
+def test_bls12_381_2_18_vs_c_oracle(ctxs, cref):
+    """BASELINE.json config 3 family (384-bit base field): 2^18 BLS12-381 G1 pairs, bit-exact vs the CPU restatement."""
+    from accumulation_amd import CommitterKey, VariableBaseMSM
+    c = o.BLS12_381_G1
+    ctx = ctxs[c.name]
+    n = 1 << 18
+    ck = CommitterKey.generate(ctx, 0x5EED1002, n)
+    assert ck.precomputed
+    dv = ctx.random_vector(0x5EED0003, n, mont=False)
+    out, oinf = VariableBaseMSM.multi_scalar_mul(ck, dv)
+    xy, _ = ck.read()
+    ref, rinf = cref.msm(c.curve_id, xy, dv.download(), threads=17)
+    assert oinf == rinf and np.array_equal(out, ref)
+    ck.free()

@@ -47,6 +47,97 @@ def bench_msm(curve, log2n, reps=12):
     ctx.close()
 
 
+def bench_degenerate(log2n):
+    """the reference's harness commits to vec![x; len], all-zero and all-one vectors."""
+    ctx = Context(ffi.AMSM_PALLAS)
+    fr = Fr(ctx.curve)
+    n = 1 << log2n
+    ck = CommitterKey.generate(ctx, 0x5EED1001, n, ffi.AMSM_BASES_PRECOMPUTE)
+    cases = {"uniform": ctx.random_vector(1, n, mont=True), "all_equal": ctx.fill(fr.to_limbs(0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF), n),
+             "all_zero": ctx.fill(fr.to_limbs(0), n), "all_one": ctx.fill(fr.to_limbs(1), n)}
+    for name, v in cases.items():
+        VariableBaseMSM.multi_scalar_mul(ck, v, mont=True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            VariableBaseMSM.multi_scalar_mul(ck, v, mont=True)
+        emit(kind="msm_distribution", log2n=log2n, scalars=name, ms_per_msm_sync=(time.perf_counter() - t0) / 3 * 1e3)
+    ck.free()
+    ctx.close()
+
+
+def bench_r1cs_nark_as(log2c, reps=2):
+    """cfg4: r1cs_nark_as over 2^log2c constraints (DummyCircuit of examples/scaling-nark.rs:21-56), no zk:
+    one accumulation = 1 input + 1 old accumulator => 2 SpMV + nested hp_as (2 MSMs) + witness combination."""
+    from accumulation_amd import r1cs_nark as nark
+    from accumulation_amd.r1cs_nark_as import ASForR1CSNark as NAS, Input, InputInstance
+    from accumulation_amd.sponge import Sha256Sponge
+    ctx = Context(ffi.AMSM_PALLAS)
+    fr = Fr(ctx.curve)
+    nc, n_in = 1 << log2c, 5
+    n_inst = n_in + 1
+    A = [[(1, n_inst)] for _ in range(nc - 1)] + [[]]
+    B = [[(1, n_inst + 1)] for _ in range(nc - 1)] + [[]]
+    Cm = [[(1, 1)] for _ in range(nc - 1)] + [[]]
+    t0 = time.time()
+    ipk = nark.index(ctx, A, B, Cm, n_inst, n_inst + 2)
+    t_index = time.time() - t0
+    pk, vk, dk = NAS.index(ipk)
+
+    def make_input(a, b):
+        inst = [1, a * b % fr.r] + [a] * (n_in - 1)
+        t1 = time.perf_counter()
+        proof = nark.prove(ipk, inst, ctx.upload(fr.to_limbs_many([a, b])), False, NAS._sponges(Sha256Sponge())[0], None)
+        return Input(InputInstance(inst, proof.first_msg), proof.second_msg), time.perf_counter() - t1
+
+    i0, _ = make_input(3, 5)
+    i1, t_nark = make_input(7, 11)
+    acc0, _ = NAS.prove(pk, [i0], [], None, None)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        acc, proof = NAS.prove(pk, [i1], [acc0], None, None)
+    dt = (time.perf_counter() - t0) / reps
+    ok = NAS.verify(ctx, vk, [i1.instance], [acc0.instance], acc.instance, proof, None)
+    t1 = time.perf_counter()
+    dec = NAS.decide(dk, acc, None)
+    emit(kind="r1cs_nark_as", log2_constraints=log2c, zk=False, accumulations_per_s=1 / dt, prove_ms=dt * 1e3,
+         nark_prove_ms=t_nark * 1e3, decide_ms=(time.perf_counter() - t1) * 1e3, index_s=round(t_index, 2),
+         verify_ok=bool(ok), decide_ok=bool(dec))
+    ctx.close()
+
+
+def bench_ipa(log2d, reps=1):
+    """cfg2: ipa_pc_as with d+1 = 2^log2d: decide = one (d+1)-point MSM; prove = succinct checks + one IPA opening."""
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
+    from accumulation_amd.ipa_pc_as import AtomicASForInnerProductArgPC as IAS, InputInstance as IpaInput
+    ctx = Context(ffi.AMSM_PALLAS)
+    fr = Fr(ctx.curve)
+    d = (1 << log2d) - 1
+    pp = IpaPC.setup(ctx, d)
+    pk, vk, dk = IAS.index(pp, d)
+    poly = ctx.random_vector(77, d + 1, mont=True)
+    comm, rand = IpaPC.commit(pk.ipa_ck, poly, False, None)
+    point = 0x123456789ABCDEF
+    z = ctx.vector(d + 1)
+    from accumulation_amd.engine import _ptr
+    ffi.check(ctx._lib.amsm_vec_powers(ctx._h, _ptr(fr.to_limbs(point)), d + 1, z.ptr), "powers")
+    value = IpaPC._inner_product(ctx, fr, poly, z)
+    t0 = time.perf_counter()
+    proof = IpaPC.open(pk.ipa_ck, poly, comm, point, rand, False, None)
+    t_open = time.perf_counter() - t0
+    inp = IpaInput(comm, point, value, proof)
+    t0 = time.perf_counter()
+    acc, pr = IAS.prove(pk, [inp], [], None, None)
+    t_prove = time.perf_counter() - t0
+    ok = IAS.verify(ctx, vk, [inp], [], acc.instance, pr, None)
+    t0 = time.perf_counter()
+    dec = IAS.decide(dk, acc, None)
+    t_dec = time.perf_counter() - t0
+    emit(kind="ipa_pc_as", log2_degree_plus_1=log2d, ipa_open_ms=t_open * 1e3, prove_ms=t_prove * 1e3,
+         accumulations_per_s=1 / t_prove, decide_ms=t_dec * 1e3, verify_ok=bool(ok), decide_ok=bool(dec))
+    ctx.close()
+
+
 def timed(ctx, fn, reps=20):
     fn()
     ctx.synchronize()
@@ -115,3 +206,6 @@ if __name__ == "__main__":
             bench_msm(ffi.AMSM_PALLAS, 22, reps=6)
     bench_vec(20 if quick else 22)
     bench_hp_as(18 if quick else 22)
+    bench_degenerate(16 if quick else 20)
+    bench_r1cs_nark_as(12 if quick else 18)
+    bench_ipa(10 if quick else 16)
