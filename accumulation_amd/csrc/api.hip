@@ -58,7 +58,7 @@ struct amsm_ctx {
   int window_override = 0;
   int K0 = 0;          // 0 = automatic (see make_geom)
   int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x 4 SIMDs x 4 waves
-  int K1 = 64;
+  int K1 = 1024;  // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew only)
   int red_s = 4;
   bool profiling = false;
   float stage_ms[ST_COUNT] = {};  // mean over the MSMs of the last call
@@ -244,7 +244,7 @@ void stage_mark(amsm_ctx* ctx, Slot* sl, int idx) {
 // but only worth it when buckets have several partials each
 u32 l1_lanes(const MsmGeom& g) {
   double avg = ((double)g.E / g.K0) / g.B;
-  return avg >= 48.0 ? 16u : (avg >= 3.0 ? 4u : 1u);
+  return avg >= 24.0 ? 16u : (avg >= 3.0 ? 4u : 1u);
 }
 
 // Enqueue the whole pipeline for one MSM on slot `sl` (asynchronous); leaves n_sets folded XYZZ records
