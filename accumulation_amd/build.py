@@ -41,7 +41,8 @@ def _compile(unit: str) -> str:
     src = os.path.join(CSRC, unit)
     obj = os.path.join(OBJ, unit.replace(".hip", ".o"))
     log = obj + ".log"
-    cmd = ["hipcc", *FLAGS, "-c", src, "-o", obj]
+    extra = os.environ.get("AMSM_EXTRA_FLAGS", "").split()  # e.g. -DAMSM_PALLAS_SAT (A/B of the Pallas field layout)
+    cmd = ["hipcc", *FLAGS, *extra, "-c", src, "-o", obj]
     with open(log, "w") as lf:
         rc = subprocess.call(cmd, stdout=lf, stderr=subprocess.STDOUT)
     if rc != 0:

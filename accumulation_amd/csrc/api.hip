@@ -76,7 +76,8 @@ struct amsm_bases {
   int precomp = 0;
   int c = 0;  // window bits fixed at creation when precomputed
   int W = 0;
-  u32* d_table = nullptr;
+  u32* d_table = nullptr;          // device-internal Montgomery radix (launch.h: device_internal_radix)
+  mutable u32* d_abi = nullptr;    // C-ABI-radix copy of generators [0, n), made on the first amsm_bases_device_ptr
 };
 
 struct amsm_matrix {
@@ -315,20 +316,27 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
     HIP_TRY(rocprim::exclusive_scan(sl->scan_tmp.p, tmp, (u32*)sl->items.p, (u32*)sl->item_off.p, 0u,
                                     (size_t)(g.B + 1), rocprim::plus<u32>(), st));
   }
+#define AMSM_DBG(name) do { if (getenv("AMSM_DEBUG")) { fprintf(stderr, "[amsm] %s ...", name); hipError_t e_ = hipDeviceSynchronize(); fprintf(stderr, " %s\n", hipGetErrorString(e_)); } } while (0)
+  AMSM_DBG("pre-l0");
   stage_mark(ctx, sl, ST_ACCUM_L0);
   launch_accum_l0<Fq>(st, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)sl->start.p,
                       (const u32*)sl->item_off.p, g, (u32*)sl->partials.p);
+  AMSM_DBG("l0");
   HIP_TRY(hipEventRecord(sl->l0_done, st));
   hipStream_t tl = sl->tail;
   HIP_TRY(hipStreamWaitEvent(tl, sl->l0_done, 0));
   if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_ACCUM_L12], tl);
   launch_accum_l1<Fq>(tl, l1_lanes(g), (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
                       g, (u32*)sl->buckets.p, d_heavy_count, (u32*)sl->heavy.p);
+  AMSM_DBG("l1");
   launch_accum_l2<Fq>(tl, (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
                       (const u32*)d_heavy_count, (const u32*)sl->heavy.p, (u32*)sl->buckets.p);
+  AMSM_DBG("l2");
   if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_REDUCE], tl);
   launch_bucket_reduce<Fq>(tl, red_blocks, (const u32*)sl->buckets.p, g, (u32*)sl->red_out.p);
+  AMSM_DBG("reduce");
   launch_fold<Fq>(tl, g.n_sets, (const u32*)sl->red_out.p, red_blocks, (u32*)sl->fold_out.p);
+  AMSM_DBG("fold");
   if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_COUNT], tl);
   HIP_TRY(hipGetLastError());
   u32* h = (u32*)sl->h_pinned;
@@ -514,6 +522,7 @@ int bases_load_impl(amsm_ctx* ctx, const uint64_t* xy, const uint8_t* is_inf, si
         }
         launch_apply_inf<Fq>(ctx->stream, b->d_table, (const uint8_t*)ctx->scalars.p, (u32)n);
       }
+      launch_points_import<Fq>(ctx->stream, b->d_table, b->d_table, (u32)n);  // C-ABI radix -> device radix
       if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
         s = AMSM_E_HIP;
         break;
@@ -562,8 +571,13 @@ template <class Fq>
 int bases_read_impl(amsm_ctx* ctx, const amsm_bases* b, size_t off, size_t n, uint64_t* xy, uint8_t* is_inf) {
   if (off > b->n || n > b->n - off) return AMSM_E_INVALID_ARG;
   if (!n) return AMSM_OK;
-  HIP_TRY(hipMemcpyAsync(xy, (const char*)b->d_table + off * affine_bytes<Fq>(), n * affine_bytes<Fq>(),
-                         hipMemcpyDeviceToHost, ctx->stream));
+  const char* src = (const char*)b->d_table + off * affine_bytes<Fq>();
+  if (device_internal_radix<Fq>()) {  // back to the C-ABI radix through a scratch buffer
+    TRY(ensure(ctx->scalars, n * affine_bytes<Fq>()));
+    launch_points_export<Fq>(ctx->stream, (const u32*)src, (u32*)ctx->scalars.p, (u32)n);
+    src = (const char*)ctx->scalars.p;
+  }
+  HIP_TRY(hipMemcpyAsync(xy, src, n * affine_bytes<Fq>(), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (is_inf) {
     constexpr int N = 2 * Fq::L / 2;
@@ -923,6 +937,7 @@ void amsm_bases_free(amsm_bases* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   if (b->d_table) (void)hipFree(b->d_table);
+  if (b->d_abi) (void)hipFree(b->d_abi);
   delete b;
 }
 
@@ -1123,9 +1138,12 @@ int amsm_bases_from_device(amsm_ctx* c, const void* d_xy, size_t n, unsigned fla
   }
   int s = AMSM_OK;
   if (n) {
-    if (hipMemcpyAsync(b->d_table, d_xy, n * pb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
-      s = AMSM_E_HIP;
+    if (hipMemcpyAsync(b->d_table, d_xy, n * pb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) s = AMSM_E_HIP;
+    if (s == AMSM_OK) {
+      if (c->curve == AMSM_PALLAS) launch_points_import<PallasFq>(c->stream, b->d_table, b->d_table, (u32)n);
+      else launch_points_import<Bls12381Fq>(c->stream, b->d_table, b->d_table, (u32)n);
+      if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) s = AMSM_E_HIP;
+    }
     if (s == AMSM_OK)
       s = DISPATCH(c, (bases_finish<PallasFq, PallasFr>(c, b, flags ? flags : AMSM_BASES_NO_PRECOMPUTE)),
                    (bases_finish<Bls12381Fq, Bls12381Fr>(c, b, flags ? flags : AMSM_BASES_NO_PRECOMPUTE)));
@@ -1138,7 +1156,29 @@ int amsm_bases_from_device(amsm_ctx* c, const void* d_xy, size_t n, unsigned fla
   *out = b;
   return AMSM_OK;
 }
-const void* amsm_bases_device_ptr(const amsm_bases* b) { return b ? b->d_table : nullptr; }
+const void* amsm_bases_device_ptr(const amsm_bases* b) {
+  if (!b) return nullptr;
+  bool internal = b->curve == AMSM_PALLAS ? device_internal_radix<PallasFq>() : device_internal_radix<Bls12381Fq>();
+  if (!internal) return b->d_table;
+  if (!b->d_abi && b->n) {  // the table is in the device radix: hand out a C-ABI-radix copy of level 0
+    size_t pb = (b->curve == AMSM_PALLAS) ? affine_bytes<PallasFq>() : affine_bytes<Bls12381Fq>();
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(b->device) != hipSuccess) return nullptr;
+    u32* p = nullptr;
+    bool ok = hipMalloc((void**)&p, b->n * pb) == hipSuccess;
+    if (ok) {
+      if (b->curve == AMSM_PALLAS) launch_points_export<PallasFq>(nullptr, b->d_table, p, (u32)b->n);
+      else launch_points_export<Bls12381Fq>(nullptr, b->d_table, p, (u32)b->n);
+      ok = hipStreamSynchronize(nullptr) == hipSuccess && hipGetLastError() == hipSuccess;
+      if (!ok) (void)hipFree(p);
+    } else {
+      (void)hipGetLastError();
+    }
+    (void)hipSetDevice(prev);
+    if (ok) b->d_abi = p;
+  }
+  return b->n ? b->d_abi : b->d_table;
+}
 
 int amsm_points_fold(amsm_ctx* c, const void* d_l, const void* d_r, size_t n, const uint64_t* x_mont, unsigned nbits,
                      void* d_out) {

@@ -7,6 +7,13 @@
 // because the bucket-accumulation hot loop is multiplier-bound on gfx950 and XYZZ mixed addition is
 // 8M+2S.  Intermediate projective values are never compared with the reference -- only the
 // canonical affine result is.
+//
+// The formulas are written once, in the bound-aware primitives of fp.h.  On a saturated field every value is
+// canonical and the K's are ignored.  On an unsaturated field (fpu.h; Pallas Fq, cap = 2^261 ~ 128 p) values are
+// only bounded; the invariant of a point held in registers or memory is
+//        X, Y < 8p      ZZ, ZZZ < 2p      (affine / loaded coordinates: canonical, < p)
+// and the comments `[< k p]` give the bound of each intermediate: a product of A < a p and B < b p is
+// < (1 + a b / 128) p, a difference `x - y (+K p)` needs y < K p and is < (x + K) p.
 #pragma once
 #include "fp.h"
 
@@ -57,32 +64,36 @@ AMSM_DEV XYZZ<P> xyzz_from_affine(const Affine<P>& p) {
 template <class P>
 AMSM_DEV XYZZ<P> xyzz_dbl(const XYZZ<P>& p) {
   if (xyzz_is_inf<P>(p)) return p;
-  Fe<P> u = fe_dbl<P>(p.y);
-  Fe<P> v = fe_sqr<P>(u);
-  Fe<P> w = fe_mul<P>(u, v);
-  Fe<P> s = fe_mul<P>(p.x, v);
-  Fe<P> xx = fe_sqr<P>(p.x);
-  Fe<P> m = fe_add<P>(fe_dbl<P>(xx), xx);
+  Fe<P> u = fe_dbl<P>(p.y);                                  // [< 16p]
+  Fe<P> v = fe_sqr<P>(u);                                    // [< 3p]
+  Fe<P> w = fe_mul<P>(u, v);                                 // [< 1.4p]
+  Fe<P> s = fe_mul<P>(p.x, v);                               // [< 1.2p]
+  Fe<P> xx = fe_sqr<P>(p.x);                                 // [< 1.5p]
+  Fe<P> m = fe_triple<P>(xx);                                // [< 4.5p]
+  Fe<P> zero = fe_zero<P>();
   XYZZ<P> r;
-  r.x = fe_sub<P>(fe_sub<P>(fe_sqr<P>(m), s), s);
-  r.y = fe_sub<P>(fe_mul<P>(m, fe_sub<P>(s, r.x)), fe_mul<P>(w, p.y));
-  r.zz = fe_mul<P>(v, p.zz);
-  r.zzz = fe_mul<P>(w, p.zzz);
+  r.x = fe_sub_bcc_k<P, 4>(fe_sqr<P>(m), zero, s);           // m^2 [< 1.2p] - 2s (+4p)  [< 5.2p]
+  Fe<P> t = fe_sub_k<P, 8>(s, r.x);                          // [< 9.2p]
+  r.y = fe_sub_k<P, 2>(fe_mul<P>(m, t), fe_mul<P>(w, p.y));  // [< 1.4p] - [< 1.1p] (+2p)  [< 3.4p]
+  r.zz = fe_mul<P>(v, p.zz);                                 // [< 1.1p]
+  r.zzz = fe_mul<P>(w, p.zzz);                               // [< 1.1p]
   return r;
 }
 
 // mdbl-2008-s-1 with a = 0 (affine input): 3M + 3S
 template <class P>
-AMSM_DEV XYZZ<P> xyzz_dbl_affine(const Affine<P>& p) {
-  Fe<P> u = fe_dbl<P>(p.y);
-  Fe<P> v = fe_sqr<P>(u);
-  Fe<P> w = fe_mul<P>(u, v);
-  Fe<P> s = fe_mul<P>(p.x, v);
-  Fe<P> xx = fe_sqr<P>(p.x);
-  Fe<P> m = fe_add<P>(fe_dbl<P>(xx), xx);
+AMSM_DEV XYZZ<P> xyzz_dbl_affine(const Affine<P>& p) {  // p.x, p.y < 2p, tight
+  Fe<P> u = fe_dbl<P>(p.y);                                  // [< 4p]
+  Fe<P> v = fe_sqr<P>(u);                                    // [< 1.2p]
+  Fe<P> w = fe_mul<P>(u, v);                                 // [< 1.1p]
+  Fe<P> s = fe_mul<P>(p.x, v);                               // [< 1.1p]
+  Fe<P> xx = fe_sqr<P>(p.x);                                 // [< 1.1p]
+  Fe<P> m = fe_triple<P>(xx);                                // [< 3.3p]
+  Fe<P> zero = fe_zero<P>();
   XYZZ<P> r;
-  r.x = fe_sub<P>(fe_sub<P>(fe_sqr<P>(m), s), s);
-  r.y = fe_sub<P>(fe_mul<P>(m, fe_sub<P>(s, r.x)), fe_mul<P>(w, p.y));
+  r.x = fe_sub_bcc_k<P, 4>(fe_sqr<P>(m), zero, s);           // [< 5.2p]
+  Fe<P> t = fe_sub_k<P, 8>(s, r.x);                          // [< 9.1p]
+  r.y = fe_sub_k<P, 2>(fe_mul<P>(m, t), fe_mul<P>(w, p.y));  // [< 3.3p]
   r.zz = v;
   r.zzz = w;
   return r;
@@ -91,37 +102,44 @@ AMSM_DEV XYZZ<P> xyzz_dbl_affine(const Affine<P>& p) {
 // madd-2008-s: acc += q (q affine, not infinity unless encoded (0,0)); 8M + 2S on the generic path.
 // Exceptional cases (acc = inf, q = inf, q = +-acc) are handled exactly: duplicate bases and
 // bases summing to zero do occur in the reference's degenerate inputs.
+// q = (x, y or -y): x canonical; `qy` is y or fe_neg_lazy(y) (lazy limbs on an unsaturated field, value <= 2p), which
+// is why the negation is taken by the caller through affine_neg_if and q.y is only used as a multiplication
+// operand (or through fe_tight).
 template <class P>
 AMSM_DEV void xyzz_madd(XYZZ<P>& acc, const Affine<P>& q) {
   if (affine_is_inf<P>(q)) return;
   if (xyzz_is_inf<P>(acc)) {
     acc.x = q.x;
-    acc.y = q.y;
+    acc.y = fe_tight<P>(q.y);
     acc.zz = fe_one<P>();
     acc.zzz = fe_one<P>();
     return;
   }
-  Fe<P> u2 = fe_mul<P>(q.x, acc.zz);
-  Fe<P> s2 = fe_mul<P>(q.y, acc.zzz);
-  Fe<P> p = fe_sub<P>(u2, acc.x);
-  Fe<P> r = fe_sub<P>(s2, acc.y);
-  if (fe_is_zero<P>(p)) {
-    if (fe_is_zero<P>(r)) {
-      acc = xyzz_dbl_affine<P>(q);
+  Fe<P> u2 = fe_mul<P>(q.x, acc.zz);    // [< 1.1p]
+  Fe<P> s2 = fe_mul<P>(q.y, acc.zzz);   // [< 1.1p]
+  Fe<P> p = fe_sub_k<P, 8>(u2, acc.x);  // [< 9.1p]
+  Fe<P> r = fe_sub_k<P, 8>(s2, acc.y);  // [< 9.1p]
+  if (fe_is_zero_mod<P, 16>(p)) {
+    if (fe_is_zero_mod<P, 16>(r)) {
+      Affine<P> qt;
+      qt.x = q.x;
+      qt.y = fe_tight<P>(q.y);
+      acc = xyzz_dbl_affine<P>(qt);
     } else {
       acc = xyzz_inf<P>();
     }
     return;
   }
-  Fe<P> pp = fe_sqr<P>(p);
-  Fe<P> ppp = fe_mul<P>(p, pp);
-  Fe<P> qq = fe_mul<P>(acc.x, pp);
-  Fe<P> x3 = fe_sub<P>(fe_sub<P>(fe_sub<P>(fe_sqr<P>(r), ppp), qq), qq);
-  Fe<P> y3 = fe_sub<P>(fe_mul<P>(r, fe_sub<P>(qq, x3)), fe_mul<P>(acc.y, ppp));
+  Fe<P> pp = fe_sqr<P>(p);                                // [< 1.7p]
+  Fe<P> ppp = fe_mul<P>(p, pp);                           // [< 1.2p]
+  Fe<P> qq = fe_mul<P>(acc.x, pp);                        // [< 1.2p]
+  Fe<P> x3 = fe_sub_bcc_k<P, 4>(fe_sqr<P>(r), ppp, qq);   // r^2 [< 1.7p] - ppp - 2qq [< 3.6p] (+4p)  [< 5.7p]
+  Fe<P> t = fe_sub_k<P, 8>(qq, x3);                       // [< 9.2p]
+  Fe<P> y3 = fe_sub_k<P, 2>(fe_mul<P>(r, t), fe_mul<P>(acc.y, ppp));  // [< 1.7p] - [< 1.1p] (+2p)  [< 3.7p]
   acc.x = x3;
   acc.y = y3;
-  acc.zz = fe_mul<P>(acc.zz, pp);
-  acc.zzz = fe_mul<P>(acc.zzz, ppp);
+  acc.zz = fe_mul<P>(acc.zz, pp);     // [< 1.1p]
+  acc.zzz = fe_mul<P>(acc.zzz, ppp);  // [< 1.1p]
 }
 
 // add-2008-s: acc += q (both XYZZ); 12M + 2S on the generic path.
@@ -132,36 +150,38 @@ AMSM_DEV void xyzz_add(XYZZ<P>& acc, const XYZZ<P>& q) {
     acc = q;
     return;
   }
-  Fe<P> u1 = fe_mul<P>(acc.x, q.zz);
-  Fe<P> u2 = fe_mul<P>(q.x, acc.zz);
-  Fe<P> s1 = fe_mul<P>(acc.y, q.zzz);
-  Fe<P> s2 = fe_mul<P>(q.y, acc.zzz);
-  Fe<P> p = fe_sub<P>(u2, u1);
-  Fe<P> r = fe_sub<P>(s2, s1);
-  if (fe_is_zero<P>(p)) {
-    if (fe_is_zero<P>(r)) {
+  Fe<P> u1 = fe_mul<P>(acc.x, q.zz);   // [< 1.2p]
+  Fe<P> u2 = fe_mul<P>(q.x, acc.zz);   // [< 1.2p]
+  Fe<P> s1 = fe_mul<P>(acc.y, q.zzz);  // [< 1.2p]
+  Fe<P> s2 = fe_mul<P>(q.y, acc.zzz);  // [< 1.2p]
+  Fe<P> p = fe_sub_k<P, 2>(u2, u1);    // [< 3.2p]
+  Fe<P> r = fe_sub_k<P, 2>(s2, s1);    // [< 3.2p]
+  if (fe_is_zero_mod<P, 4>(p)) {
+    if (fe_is_zero_mod<P, 4>(r)) {
       acc = xyzz_dbl<P>(acc);
     } else {
       acc = xyzz_inf<P>();
     }
     return;
   }
-  Fe<P> pp = fe_sqr<P>(p);
-  Fe<P> ppp = fe_mul<P>(p, pp);
-  Fe<P> qq = fe_mul<P>(u1, pp);
-  Fe<P> x3 = fe_sub<P>(fe_sub<P>(fe_sub<P>(fe_sqr<P>(r), ppp), qq), qq);
-  Fe<P> y3 = fe_sub<P>(fe_mul<P>(r, fe_sub<P>(qq, x3)), fe_mul<P>(s1, ppp));
+  Fe<P> pp = fe_sqr<P>(p);                               // [< 1.1p]
+  Fe<P> ppp = fe_mul<P>(p, pp);                          // [< 1.1p]
+  Fe<P> qq = fe_mul<P>(u1, pp);                          // [< 1.1p]
+  Fe<P> x3 = fe_sub_bcc_k<P, 4>(fe_sqr<P>(r), ppp, qq);  // [< 1.1p] - [< 3.3p] (+4p)  [< 5.1p]
+  Fe<P> t = fe_sub_k<P, 8>(qq, x3);                      // [< 9.1p]
+  Fe<P> y3 = fe_sub_k<P, 2>(fe_mul<P>(r, t), fe_mul<P>(s1, ppp));  // [< 1.3p] - [< 1.1p] (+2p)  [< 3.3p]
   acc.x = x3;
   acc.y = y3;
-  acc.zz = fe_mul<P>(fe_mul<P>(acc.zz, q.zz), pp);
-  acc.zzz = fe_mul<P>(fe_mul<P>(acc.zzz, q.zzz), ppp);
+  acc.zz = fe_mul<P>(fe_mul<P>(acc.zz, q.zz), pp);       // [< 1.1p]
+  acc.zzz = fe_mul<P>(fe_mul<P>(acc.zzz, q.zzz), ppp);   // [< 1.1p]
 }
 
 template <class P>
 AMSM_DEV Affine<P> affine_neg_if(const Affine<P>& p, bool negate) {
   Affine<P> r;
   r.x = p.x;
-  Fe<P> ny = fe_neg<P>(p.y);
+  Fe<P> ny = fe_neg_lazy<P>(p.y);
+  negate = negate && !fe_is_zero<P>(p.y);  // keeps the (0, 0) encoding of infinity (the lazy -0 is 2p, not 0)
 #pragma unroll
   for (int i = 0; i < P::L; i++) r.y.v[i] = negate ? ny.v[i] : p.y.v[i];
   return r;
@@ -183,41 +203,56 @@ AMSM_DEV Affine<P> xyzz_to_affine(const XYZZ<P>& p) {
   return r;
 }
 
-// Loads/stores.  Affine = 2*L u32 contiguous (x|y); XYZZ = 4*L u32 contiguous.
+// Loads/stores.  Affine = 2*W u32 contiguous (x|y); XYZZ = 4*W u32 contiguous (canonical values).
+template <class P>
+AMSM_DEV Affine<P> affine_import(const Affine<P>& a) {  // C-ABI Montgomery radix -> internal
+  Affine<P> r;
+  r.x = fe_import<P>(a.x);
+  r.y = fe_import<P>(a.y);
+  return r;
+}
+template <class P>
+AMSM_DEV Affine<P> affine_export(const Affine<P>& a) {  // internal -> C-ABI radix, canonical
+  Affine<P> r;
+  r.x = fe_export<P>(a.x);
+  r.y = fe_export<P>(a.y);
+  return r;
+}
+
 template <class P>
 AMSM_DEV Affine<P> affine_load(const u32* __restrict__ base, size_t idx) {
-  const u32* p = base + idx * (2 * P::L);
+  const u32* p = base + idx * (2 * P::W);
   Affine<P> r;
   r.x = fe_load<P>(p);
-  r.y = fe_load<P>(p + P::L);
+  r.y = fe_load<P>(p + P::W);
   return r;
 }
 
 template <class P>
 AMSM_DEV void affine_store(u32* __restrict__ base, size_t idx, const Affine<P>& a) {
-  u32* p = base + idx * (2 * P::L);
+  u32* p = base + idx * (2 * P::W);
   fe_store<P>(p, a.x);
-  fe_store<P>(p + P::L, a.y);
+  fe_store<P>(p + P::W, a.y);
 }
 
 template <class P>
 AMSM_DEV XYZZ<P> xyzz_load(const u32* __restrict__ base, size_t idx) {
-  const u32* p = base + idx * (4 * P::L);
+  const u32* p = base + idx * (4 * P::W);
   XYZZ<P> r;
   r.x = fe_load<P>(p);
-  r.y = fe_load<P>(p + P::L);
-  r.zz = fe_load<P>(p + 2 * P::L);
-  r.zzz = fe_load<P>(p + 3 * P::L);
+  r.y = fe_load<P>(p + P::W);
+  r.zz = fe_load<P>(p + 2 * P::W);
+  r.zzz = fe_load<P>(p + 3 * P::W);
   return r;
 }
 
 template <class P>
 AMSM_DEV void xyzz_store(u32* __restrict__ base, size_t idx, const XYZZ<P>& a) {
-  u32* p = base + idx * (4 * P::L);
+  u32* p = base + idx * (4 * P::W);
   fe_store<P>(p, a.x);
-  fe_store<P>(p + P::L, a.y);
-  fe_store<P>(p + 2 * P::L, a.zz);
-  fe_store<P>(p + 3 * P::L, a.zzz);
+  fe_store<P>(p + P::W, a.y);
+  fe_store<P>(p + 2 * P::W, a.zz);
+  fe_store<P>(p + 3 * P::W, a.zzz);
 }
 
 }  // namespace amsm

@@ -33,7 +33,9 @@ typedef uint64_t u64;
   }
 
 struct PallasFq {  // base field of Pallas (coordinates); 255 bits
-  static constexpr int L = 8;
+  static constexpr int L = 8;  // register limbs
+  static constexpr int W = 8;  // 32-bit words in memory
+  static constexpr bool UNSAT = false;
   static constexpr u32 INV = 0xffffffffu;  // -p^-1 mod 2^32
   AMSM_TABLE(mod, 8, 0x00000001u, 0x992d30edu, 0x094cf91bu, 0x224698fcu, 0x00000000u, 0x00000000u, 0x00000000u, 0x40000000u)
   AMSM_TABLE(one, 8, 0xfffffffdu, 0x34786d38u, 0xe41914adu, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu)
@@ -41,7 +43,9 @@ struct PallasFq {  // base field of Pallas (coordinates); 255 bits
 };
 
 struct PallasFr {  // scalar field of Pallas; 255 bits
-  static constexpr int L = 8;
+  static constexpr int L = 8;  // register limbs
+  static constexpr int W = 8;  // 32-bit words in memory
+  static constexpr bool UNSAT = false;
   static constexpr u32 INV = 0xffffffffu;
   AMSM_TABLE(mod, 8, 0x00000001u, 0x8c46eb21u, 0x0994a8ddu, 0x224698fcu, 0x00000000u, 0x00000000u, 0x00000000u, 0x40000000u)
   AMSM_TABLE(one, 8, 0xfffffffdu, 0x5b2b3e9cu, 0xe3420567u, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu)
@@ -49,7 +53,9 @@ struct PallasFr {  // scalar field of Pallas; 255 bits
 };
 
 struct Bls12381Fq {  // base field of BLS12-381; 381 bits
-  static constexpr int L = 12;
+  static constexpr int L = 12;  // register limbs
+  static constexpr int W = 12;  // 32-bit words in memory
+  static constexpr bool UNSAT = false;
   static constexpr u32 INV = 0xfffcfffdu;
   AMSM_TABLE(mod, 12, 0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u, 0xf38512bfu, 0x64774b84u,
              0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau)
@@ -60,7 +66,9 @@ struct Bls12381Fq {  // base field of BLS12-381; 381 bits
 };
 
 struct Bls12381Fr {  // scalar field of BLS12-381; 255 bits
-  static constexpr int L = 8;
+  static constexpr int L = 8;  // register limbs
+  static constexpr int W = 8;  // 32-bit words in memory
+  static constexpr bool UNSAT = false;
   static constexpr u32 INV = 0xffffffffu;
   AMSM_TABLE(mod, 8, 0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u)
   AMSM_TABLE(one, 8, 0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau, 0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u)
@@ -74,6 +82,23 @@ template <class P>
 struct Fe {
   u32 v[P::L];
 };
+
+}  // namespace amsm
+#include "fpu.h"  // unsaturated-limb packs (PallasFqU) and their u_* primitives
+namespace amsm {
+
+// Field the DEVICE kernels compute in for a given ABI field: Pallas Fq runs on 9 x 29-bit unsaturated limbs
+// (internal Montgomery radix 2^261, fpu.h); -DAMSM_PALLAS_SAT keeps the saturated 8 x 32-bit asm schedule (A/B).
+template <class Fq>
+struct DevField {
+  using type = Fq;
+};
+#ifndef AMSM_PALLAS_SAT
+template <>
+struct DevField<PallasFq> {
+  using type = PallasFqU;
+};
+#endif
 
 template <class P>
 AMSM_DEV Fe<P> fe_zero() {
@@ -112,6 +137,7 @@ AMSM_DEV bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
 // r = a - m if a >= m else a   (a < 2m, possibly with a carry word `hi` in {0,1})
 template <class P>
 AMSM_DEV void fe_cond_sub(Fe<P>& a, u32 hi = 0) {
+  static_assert(!P::UNSAT, "saturated fields only");
   u32 d[P::L];
   u32 br = 0;
 #pragma unroll
@@ -123,6 +149,7 @@ AMSM_DEV void fe_cond_sub(Fe<P>& a, u32 hi = 0) {
 
 template <class P>
 AMSM_DEV Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+  static_assert(!P::UNSAT, "unsaturated fields use the bound-aware fe_*_k primitives");
   Fe<P> r;
   u32 c = 0;
 #pragma unroll
@@ -133,6 +160,7 @@ AMSM_DEV Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
 
 template <class P>
 AMSM_DEV Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+  static_assert(!P::UNSAT, "unsaturated fields use the bound-aware fe_*_k primitives");
   Fe<P> r;
   u32 br = 0;
 #pragma unroll
@@ -147,6 +175,7 @@ AMSM_DEV Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
 
 template <class P>
 AMSM_DEV Fe<P> fe_neg(const Fe<P>& a) {
+  static_assert(!P::UNSAT, "unsaturated fields use fe_neg_lazy");
   if (fe_is_zero<P>(a)) return a;
   Fe<P> r;
   u32 br = 0;
@@ -155,10 +184,6 @@ AMSM_DEV Fe<P> fe_neg(const Fe<P>& a) {
   return r;
 }
 
-template <class P>
-AMSM_DEV Fe<P> fe_dbl(const Fe<P>& a) {
-  return fe_add<P>(a, a);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Montgomery multiplication, CIOS (coarsely integrated operand scanning), r = a*b/R mod m.
@@ -208,7 +233,8 @@ AMSM_DEV Fe<P> fe_mul_ref(const Fe<P>& a, const Fe<P>& b) {
 // bit-identical and ~2x fewer VALU instructions.  -DAMSM_NO_ASM_MUL keeps the portable loop (A/B, debug).
 template <class P>
 AMSM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
-  return fe_mul_ref<P>(a, b);
+  if constexpr (P::UNSAT) return u_mul<P>(a, b);
+  else return fe_mul_ref<P>(a, b);
 }
 
 }  // namespace amsm
@@ -219,7 +245,78 @@ namespace amsm {
 
 template <class P>
 AMSM_DEV Fe<P> fe_sqr(const Fe<P>& a) {
-  return fe_mul<P>(a, a);
+  if constexpr (P::UNSAT) return u_sqr<P>(a);
+  else return fe_mul<P>(a, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bound-aware primitives the group law (ec.h) is written in.  On a saturated field they are the plain modular
+// operations (every value canonical); on an unsaturated field (fpu.h) values are only bounded and the K's say how
+// many multiples of p keep a difference positive -- the callers' comments carry the bounds.
+// ------------------------------------------------------------------------------------------------
+template <class P, u32 K>
+AMSM_DEV Fe<P> fe_sub_k(const Fe<P>& a, const Fe<P>& b) {  // a - b   (unsat: + K p, needs b < K p)
+  if constexpr (P::UNSAT) return u_sub_k<P, K>(a, b);
+  else return fe_sub<P>(a, b);
+}
+template <class P, u32 K>
+AMSM_DEV Fe<P> fe_sub_bcc_k(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c) {  // a - b - 2c   (unsat: + K p)
+  if constexpr (P::UNSAT) return u_sub_bcc_k<P, K>(a, b, c);
+  else return fe_sub<P>(fe_sub<P>(fe_sub<P>(a, b), c), c);
+}
+template <class P>
+AMSM_DEV Fe<P> fe_dbl(const Fe<P>& a) {
+  if constexpr (P::UNSAT) return u_times<P, 2>(a);
+  else return fe_add<P>(a, a);
+}
+template <class P>
+AMSM_DEV Fe<P> fe_triple(const Fe<P>& a) {
+  if constexpr (P::UNSAT) return u_times<P, 3>(a);
+  else return fe_add<P>(fe_add<P>(a, a), a);
+}
+// -y for a canonical y.  unsat: 2p - y with lazy limbs -- only valid as a multiplication operand or through fe_tight
+template <class P>
+AMSM_DEV Fe<P> fe_neg_lazy(const Fe<P>& y) {
+  if constexpr (P::UNSAT) return u_neg_lazy<P>(y);
+  else return fe_neg<P>(y);
+}
+template <class P>
+AMSM_DEV Fe<P> fe_tight(const Fe<P>& a) {  // lazy -> tight (no-op on saturated fields)
+  Fe<P> r = a;
+  if constexpr (P::UNSAT) u_carry<P>(r);
+  return r;
+}
+// a == 0 mod p, for a value < KMAX p (KMAX a power of two)
+template <class P, u32 KMAX>
+AMSM_DEV bool fe_is_zero_mod(const Fe<P>& a) {
+  if constexpr (P::UNSAT) return u_is_zero_mod<P, KMAX>(a);
+  else return fe_is_zero<P>(a);
+}
+// C-ABI Montgomery radix (2^(32 W)) <-> the device's internal radix (identity on saturated fields).
+// fe_import: any value < 2^(32 W) in, < 2p out.  fe_export: value < 8p in, canonical out.
+template <class P>
+AMSM_DEV Fe<P> fe_import(const Fe<P>& a) {
+  if constexpr (P::UNSAT) {
+    Fe<P> k;
+#pragma unroll
+    for (int i = 0; i < P::L; i++) k.v[i] = P::k_import(i);
+    return u_mul<P>(a, k);
+  } else {
+    return a;
+  }
+}
+template <class P>
+AMSM_DEV Fe<P> fe_export(const Fe<P>& a) {
+  if constexpr (P::UNSAT) {
+    Fe<P> k;
+#pragma unroll
+    for (int i = 0; i < P::L; i++) k.v[i] = P::k_export(i);
+    Fe<P> r = u_mul<P>(a, k);
+    u_canon<P, 2>(r);
+    return r;
+  } else {
+    return a;
+  }
 }
 
 // Montgomery -> canonical integer (ark-ff `into_repr`, visible at
@@ -239,47 +336,79 @@ AMSM_DEV Fe<P> fe_to_mont(const Fe<P>& a) {
   return fe_mul<P>(a, r2);
 }
 
+template <class P, bool U = P::UNSAT>
+struct SatOf {
+  using type = P;
+};
+template <class P>
+struct SatOf<P, true> {
+  using type = typename P::Sat;
+};
+
 // a^(m-2): Fermat inversion (only used off the hot path: key precomputation, tests).
 template <class P>
 AMSM_DEV Fe<P> fe_inv(const Fe<P>& a) {
-  // exponent m-2, scanned MSB->LSB
-  u32 e[P::L];
+  // exponent m-2 (32-bit words of the modulus), scanned MSB->LSB
+  using E = typename SatOf<P>::type;
+  u32 e[E::L];
   u64 br = 2;
 #pragma unroll
-  for (int i = 0; i < P::L; i++) {
-    u64 x = (u64)P::mod(i) - br;
+  for (int i = 0; i < E::L; i++) {
+    u64 x = (u64)E::mod(i) - br;
     e[i] = (u32)x;
     br = (x >> 32) & 1;
   }
   Fe<P> r = fe_one<P>();
-  for (int i = P::L * 32 - 1; i >= 0; i--) {
+  for (int i = E::L * 32 - 1; i >= 0; i--) {
     r = fe_sqr<P>(r);
     if ((e[i >> 5] >> (i & 31)) & 1) r = fe_mul<P>(r, a);
   }
   return r;
 }
 
-// 16-byte vector load/store of an element (coalesced dwordx4 per lane; Guideline 13).
+// 16-byte vector load/store of an element (coalesced dwordx4 per lane; Guideline 13).  Memory is W packed words;
+// an unsaturated field unpacks to / canonicalises and packs from its register limbs here.
 template <class P>
-AMSM_DEV Fe<P> fe_load(const u32* __restrict__ p) {
-  Fe<P> r;
-  const uint4* q = reinterpret_cast<const uint4*>(p);
+AMSM_DEV Fe<P> fe_from_words(const u32* w) {  // W memory words (already in registers) -> element
+  if constexpr (P::UNSAT) {
+    return u_unpack<P>(w);
+  } else {
+    Fe<P> r;
 #pragma unroll
-  for (int i = 0; i < P::L / 4; i++) {
-    uint4 x = q[i];
-    r.v[4 * i + 0] = x.x;
-    r.v[4 * i + 1] = x.y;
-    r.v[4 * i + 2] = x.z;
-    r.v[4 * i + 3] = x.w;
+    for (int i = 0; i < P::L; i++) r.v[i] = w[i];
+    return r;
   }
-  return r;
 }
 
 template <class P>
-AMSM_DEV void fe_store(u32* __restrict__ p, const Fe<P>& a) {
+AMSM_DEV Fe<P> fe_load(const u32* __restrict__ p) {
+  u32 w[P::W];
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < P::W / 4; i++) {
+    uint4 x = q[i];
+    w[4 * i + 0] = x.x;
+    w[4 * i + 1] = x.y;
+    w[4 * i + 2] = x.z;
+    w[4 * i + 3] = x.w;
+  }
+  return fe_from_words<P>(w);
+}
+
+template <class P>
+AMSM_DEV void fe_store(u32* __restrict__ p, const Fe<P>& a) {  // unsat: a tight, value < 8p; stored canonical
+  u32 w[P::W];
+  if constexpr (P::UNSAT) {
+    Fe<P> c = a;
+    u_canon<P, 8>(c);
+    u_pack<P>(c, w);
+  } else {
+#pragma unroll
+    for (int i = 0; i < P::L; i++) w[i] = a.v[i];
+  }
   uint4* q = reinterpret_cast<uint4*>(p);
 #pragma unroll
-  for (int i = 0; i < P::L / 4; i++) q[i] = make_uint4(a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
+  for (int i = 0; i < P::W / 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 
 }  // namespace amsm

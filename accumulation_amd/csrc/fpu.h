@@ -1,0 +1,287 @@
+// Unsaturated-limb Montgomery arithmetic for the base field of the MSM hot loop (gfx950).
+//
+// gfx950 has no carry-in on v_mad_u64_u32 and a VALU carry write costs wait states, so the saturated 8 x 32-bit
+// schedule (fp_mul_gfx950.h) pays one v_addc per product.  Here an element is L limbs of B bits (Pallas Fq: 9 x 29,
+// R' = 2^261): every column sum of a product fits a 64-bit accumulator, so a multiplication is one v_mad_u64_u32
+// per limb product and NO carry handling (measured 17-21 % faster, tools/fp29_proto.hip), squarings need 45
+// instead of 81 products, and additions / subtractions are carry-free limb-wise adds followed by one
+// carry-propagation pass.
+//
+// Representation rules (every function states what it needs and gives):
+//   * "tight"  : limbs 0..L-2 < 2^B, value < 2^(B*L).  Everything held in registers between operations is tight.
+//   * "lazy"   : limbs < 2^(B+1), only allowed as ONE operand of a multiplication.
+//   * values are only bounded, not reduced: a multiplication gives  out < p + A*B / 2^(B*L)  and the group-law
+//     formulas in ec.h carry the bound of every intermediate in comments (cap = 2^261 ~ 128 p for Pallas).
+//   * memory holds canonical values (< p), packed into W 32-bit words, in the INTERNAL Montgomery radix R'.  The
+//     C ABI's radix is R = 2^(32 W); fe_import / fe_export convert (one multiplication by a constant) at the
+//     edges (key load / read, the final fold of an MSM, amsm_points_fold), see DESIGN.md.
+//
+// Included from fp.h (after Fe<>), not on its own.
+#pragma once
+
+namespace amsm {
+
+struct PallasFq;  // the saturated pack (fp.h) this field shadows
+
+struct PallasFqU {
+  using Sat = PallasFq;
+  static constexpr int L = 9;  // register limbs
+  static constexpr int W = 8;  // 32-bit words in memory
+  static constexpr int B = 29;
+  static constexpr bool UNSAT = true;
+  static constexpr u32 NINV = 0x1fffffffu;  // -p^-1 mod 2^B
+  // p, R' mod p, R'^2 / R mod p (ABI -> internal), R mod p (internal -> ABI); radix 2^29, checked in tests/test_oracle.py
+  AMSM_TABLE(mod, 9, 0x00000001u, 0x09698768u, 0x133e46e6u, 0x0d31f812u, 0x00000224u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00400000u)
+  AMSM_TABLE(one, 9, 0x1fffff81u, 0x14a5d367u, 0x141ad3c0u, 0x1435eec5u, 0x1ffeefefu, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x003fffffu)
+  AMSM_TABLE(k_import, 9, 0x1ffff001u, 0x10f30767u, 0x0ecfe231u, 0x0db0ce73u, 0x1fddbb8bu, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x003fffffu)
+  AMSM_TABLE(k_export, 9, 0x1ffffffdu, 0x03c369c7u, 0x06452b4du, 0x186a17c8u, 0x1ffff992u, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x003fffffu)
+};
+
+template <class P>
+AMSM_HD constexpr u32 u_mask() {
+  return (1u << P::B) - 1u;
+}
+
+// K*p as tight limbs (compile-time)
+template <class P, u32 K>
+struct UKp {
+  u32 v[P::L];
+  AMSM_HD constexpr UKp() : v{} {
+    u64 carry = 0;
+    for (int j = 0; j < P::L; j++) {
+      u64 t = (u64)K * P::mod(j) + carry;
+      if (j < P::L - 1) {
+        v[j] = (u32)t & u_mask<P>();
+        carry = t >> P::B;
+      } else {
+        v[j] = (u32)t;
+      }
+    }
+  }
+};
+
+// K*p in a redundant form whose limbs 0..L-2 are all >= S*(2^B - 1): a + UKpBp - (sum of S tight values) never
+// borrows below the top limb (compile-time)
+template <class P, u32 K, u32 S>
+struct UKpBp {
+  u32 v[P::L];
+  AMSM_HD constexpr UKpBp() : v{} {
+    UKp<P, K> t;
+    for (int j = 0; j < P::L; j++) {
+      if (j == 0) v[j] = t.v[j] + (S << P::B);
+      else if (j < P::L - 1) v[j] = t.v[j] + (S << P::B) - S;
+      else v[j] = t.v[j] - S;
+    }
+  }
+};
+
+// carry propagation: limbs < 2^32 (true value in [0, 2^(B*L))) -> tight.  The top limb may have wrapped mod 2^32
+// during limb-wise arithmetic; it is exact again after the carries arrive.
+template <class P>
+AMSM_DEV void u_carry(Fe<P>& a) {
+#pragma unroll
+  for (int i = 0; i < P::L - 1; i++) {
+    a.v[i + 1] += a.v[i] >> P::B;
+    a.v[i] &= u_mask<P>();
+  }
+}
+
+// Montgomery product a*b / 2^(B*L) mod p.  Needs: limbs of a < 2^(B+1), limbs of b < 2^B (or the reverse).
+// Gives: tight, value < p + a*b / 2^(B*L).
+template <class P>
+AMSM_DEV Fe<P> u_mul(const Fe<P>& a, const Fe<P>& b) {
+  constexpr int L = P::L;
+  constexpr u32 M = u_mask<P>();
+  u64 acc = 0;
+  u32 m[L];
+  Fe<P> r;
+#pragma unroll
+  for (int k = 0; k < 2 * L; k++) {
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (j >= 0 && j < L) acc += (u64)a.v[i] * b.v[j];
+    }
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (i < k && j >= 1 && j < L && P::mod(j < 0 || j >= L ? 0 : j) != 0) acc += (u64)m[i] * P::mod(j < 0 || j >= L ? 0 : j);
+    }
+    if (k < L) {
+      u32 lo = (u32)acc & M;
+      m[k] = (P::NINV == M) ? ((0u - lo) & M) : ((lo * P::NINV) & M);
+      acc += (u64)m[k] * P::mod(0);
+      acc >>= P::B;
+    } else {
+      r.v[k - L] = (k == 2 * L - 1) ? (u32)acc : ((u32)acc & M);
+      acc >>= P::B;
+    }
+  }
+  return r;
+}
+
+// a^2 / 2^(B*L): the cross products are taken once against doubled limbs (45 instead of 81 products for L = 9).
+// Needs: a tight.  Gives: tight, value < p + a^2 / 2^(B*L).
+template <class P>
+AMSM_DEV Fe<P> u_sqr(const Fe<P>& a) {
+  constexpr int L = P::L;
+  constexpr u32 M = u_mask<P>();
+  u32 a2[L];
+#pragma unroll
+  for (int i = 0; i < L; i++) a2[i] = a.v[i] << 1;
+  u64 acc = 0;
+  u32 m[L];
+  Fe<P> r;
+#pragma unroll
+  for (int k = 0; k < 2 * L; k++) {
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (j >= 0 && j < L) {
+        if (i < j) acc += (u64)a2[i] * a.v[j];
+        else if (i == j) acc += (u64)a.v[i] * a.v[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (i < k && j >= 1 && j < L && P::mod(j < 0 || j >= L ? 0 : j) != 0) acc += (u64)m[i] * P::mod(j < 0 || j >= L ? 0 : j);
+    }
+    if (k < L) {
+      u32 lo = (u32)acc & M;
+      m[k] = (P::NINV == M) ? ((0u - lo) & M) : ((lo * P::NINV) & M);
+      acc += (u64)m[k] * P::mod(0);
+      acc >>= P::B;
+    } else {
+      r.v[k - L] = (k == 2 * L - 1) ? (u32)acc : ((u32)acc & M);
+      acc >>= P::B;
+    }
+  }
+  return r;
+}
+
+// a + K*p - b.  Needs: a, b tight, b < K*p.  Gives: tight, value = a - b + K*p.
+template <class P, u32 K>
+AMSM_DEV Fe<P> u_sub_k(const Fe<P>& a, const Fe<P>& b) {
+  constexpr UKpBp<P, K, 1> c{};
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.v[i] = a.v[i] + c.v[i] - b.v[i];
+  u_carry<P>(r);
+  return r;
+}
+
+// a + K*p - b - 2c.  Needs: a, b, c tight, b + 2c < K*p.  Gives: tight, value = a - b - 2c + K*p.
+template <class P, u32 K>
+AMSM_DEV Fe<P> u_sub_bcc_k(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c) {
+  constexpr UKpBp<P, K, 3> kp{};
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.v[i] = a.v[i] + kp.v[i] - b.v[i] - 2u * c.v[i];
+  u_carry<P>(r);
+  return r;
+}
+
+// small multiples.  Needs: a tight.  Gives: tight, value = MULT*a (MULT <= 4).
+template <class P, u32 MULT>
+AMSM_DEV Fe<P> u_times(const Fe<P>& a) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.v[i] = MULT * a.v[i];
+  u_carry<P>(r);
+  return r;
+}
+
+// 2p - y for a canonical y (< p).  Gives: LAZY limbs (< 2^(B+1)), value in (p, 2p]: multiplication operand only.
+template <class P>
+AMSM_DEV Fe<P> u_neg_lazy(const Fe<P>& y) {
+  constexpr UKpBp<P, 2, 1> c{};
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.v[i] = c.v[i] - y.v[i];
+  return r;
+}
+
+// conditional subtraction of K*p, K*p/2, ..., p: a tight with value < 2*K*p  ->  canonical (< p) for K a power of 2
+template <class P, u32 K>
+AMSM_DEV void u_canon_steps(Fe<P>& a) {
+  constexpr UKp<P, K> kp{};
+  constexpr u32 M = u_mask<P>();
+  u32 d[P::L];
+  u32 br = 0;
+#pragma unroll
+  for (int i = 0; i < P::L - 1; i++) {
+    u32 x = a.v[i] - kp.v[i] - br;
+    br = x >> 31;
+    d[i] = x & M;
+  }
+  u32 x = a.v[P::L - 1] - kp.v[P::L - 1] - br;
+  bool lt = (int)x < 0;
+  d[P::L - 1] = x;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) a.v[i] = lt ? a.v[i] : d[i];
+  if constexpr (K > 1) u_canon_steps<P, K / 2>(a);
+}
+
+// a tight, value < KMAX*p (KMAX a power of two) -> canonical
+template <class P, u32 KMAX>
+AMSM_DEV void u_canon(Fe<P>& a) {
+  static_assert((KMAX & (KMAX - 1)) == 0 && KMAX >= 2, "KMAX must be a power of two");
+  u_canon_steps<P, KMAX / 2>(a);
+}
+
+// is a == 0 (mod p)?  a tight, value < KMAX*p.  The low limb of k*p filters all but ~KMAX/2^B of the non-zero
+// values; the exact test behind it canonicalises.
+template <class P, u32 KMAX>
+AMSM_DEV bool u_is_zero_mod(const Fe<P>& a) {
+  constexpr u32 M = u_mask<P>();
+  bool maybe = false;
+  if constexpr (P::mod(0) == 1) {
+    maybe = a.v[0] < KMAX;
+  } else {
+#pragma unroll
+    for (u32 k = 0; k < KMAX; k++) maybe |= a.v[0] == ((k * P::mod(0)) & M);
+  }
+  if (!maybe) return false;
+  Fe<P> c = a;
+  u_canon<P, KMAX>(c);
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) o |= c.v[i];
+  return o == 0;
+}
+
+// memory (W packed 32-bit words, value < 2^(32 W)) <-> register limbs
+template <class P>
+AMSM_DEV Fe<P> u_unpack(const u32* w) {
+  constexpr u32 M = u_mask<P>();
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) {
+    int o = i * P::B, j = o >> 5, sh = o & 31;
+    u32 lo = j < P::W ? w[j] : 0u;
+    u32 hi = (j + 1) < P::W ? w[j + 1] : 0u;
+    u32 x = sh ? (u32)((((u64)hi << 32) | lo) >> sh) : lo;
+    r.v[i] = (i < P::L - 1) ? (x & M) : x;
+  }
+  return r;
+}
+
+template <class P>
+AMSM_DEV void u_pack(const Fe<P>& a, u32* w) {  // a tight, value < 2^(32 W)
+#pragma unroll
+  for (int j = 0; j < P::W; j++) {
+    // word j = bits [32j, 32j+32): limbs i0 .. i0+2 overlap it
+    int i0 = (32 * j) / P::B;
+    u32 x = 0;
+#pragma unroll
+    for (int i = i0; i < i0 + 3 && i < P::L; i++) {
+      int s = i * P::B - 32 * j;  // bit position of limb i inside the word (may be negative)
+      if (s <= -32 || s >= 32) continue;
+      x |= s >= 0 ? (a.v[i] << s) : (a.v[i] >> (-s));
+    }
+    w[j] = x;
+  }
+}
+
+}  // namespace amsm

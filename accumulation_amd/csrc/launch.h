@@ -29,6 +29,16 @@ void launch_apply_inf(hipStream_t st, u32* table, const uint8_t* is_inf, u32 n);
 template <class Fq>
 void launch_generate_bases(hipStream_t st, u32* table, u64 seed, u32 n, const u32* gen_xy_mont);
 
+// The device may keep points in an internal Montgomery radix (fpu.h): key tables, partials and buckets are in it,
+// everything the C ABI exposes is not.  import/export convert a point array (src may equal dst); they do
+// nothing when device_internal_radix<Fq>() is false.
+template <class Fq>
+bool device_internal_radix();
+template <class Fq>
+void launch_points_import(hipStream_t st, const u32* src, u32* dst, u32 n);
+template <class Fq>
+void launch_points_export(hipStream_t st, const u32* src, u32* dst, u32 n);
+
 template <class Fq>
 void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const u32* d_x_canon, u32 nbits, u32* out);
 

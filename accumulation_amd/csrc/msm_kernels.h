@@ -45,7 +45,7 @@ namespace amsm {
 // o / PB, so lane l then reads its own point back with ds_read_b128s.  One region per wave, no barrier.
 template <class Fq>
 struct GatherLds {
-  static constexpr u32 PB = 2 * Fq::L * 4;           // bytes per affine point
+  static constexpr u32 PB = 2 * Fq::W * 4;           // bytes per affine point
   static constexpr u32 WAVE_BYTES = 64 * PB;          // 4 KiB (Pallas) / 6 KiB (BLS12-381)
   static constexpr u32 N_INSTR = WAVE_BYTES / 1024;   // DMA wave-instructions per gather
 };
@@ -67,10 +67,10 @@ AMSM_DEV void gather_issue(const u32* __restrict__ table, u32 idx_own, u32* lds_
 
 template <class Fq>
 AMSM_DEV Affine<Fq> gather_read(const u32* lds_wave, u32 lane) {
-  const u32* p = lds_wave + lane * (2 * Fq::L);
+  const u32* p = lds_wave + lane * (2 * Fq::W);
   Affine<Fq> r;
   r.x = fe_load<Fq>(p);
-  r.y = fe_load<Fq>(p + Fq::L);
+  r.y = fe_load<Fq>(p + Fq::W);
   return r;
 }
 
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256)
 }
 
 // Workgroup (256 lanes = 4 waves) reduction: wave shuffles, then 4 records through LDS.
-// lds must hold 4 XYZZ records (4 * 4*L u32).  Result valid in lane 0 of the workgroup.
+// lds must hold 4 XYZZ records (4 * 4*W u32).  Result valid in lane 0 of the workgroup.
 template <class Fq>
 AMSM_DEV void block_reduce_xyzz(XYZZ<Fq>& acc, u32* lds) {
   wave_reduce_xyzz<Fq>(acc);
@@ -226,7 +226,7 @@ template <class Fq>
 __global__ void __launch_bounds__(256)
     k_accum_l2(const u32* __restrict__ partials, const u32* __restrict__ items, const u32* __restrict__ item_off,
                const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list, u32* __restrict__ buckets) {
-  __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::L];
+  __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
   u32 nh = *heavy_count;
   for (u32 h = blockIdx.x; h < nh; h += gridDim.x) {
     u32 b = heavy_list[h];
@@ -262,7 +262,7 @@ AMSM_DEV XYZZ<Fq> xyzz_mul_small(const XYZZ<Fq>& p, u32 k) {
 template <class Fq>
 __global__ void __launch_bounds__(256)
     k_bucket_reduce(const u32* __restrict__ buckets, MsmGeom g, u32* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::L];
+  __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
   u32 set = blockIdx.y;
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   XYZZ<Fq> total = xyzz_inf<Fq>();
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)set * gridDim.x + blockIdx.x, total);
 }
 
-// fold: wave b sums records [b*n, (b+1)*n) (lane-strided + shuffle butterfly) and writes out[b].
+// fold: wave b sums records [b*n, (b+1)*n) (lane-strided + shuffle butterfly) and writes out[b] (C-ABI radix).
 template <class Fq>
 __global__ void __launch_bounds__(64) k_fold(const u32* __restrict__ in, u32 n, u32* __restrict__ out) {
   XYZZ<Fq> acc = xyzz_inf<Fq>();
@@ -290,7 +290,15 @@ __global__ void __launch_bounds__(64) k_fold(const u32* __restrict__ in, u32 n, 
     xyzz_add<Fq>(acc, p);
   }
   wave_reduce_xyzz<Fq>(acc);
-  if (threadIdx.x == 0) xyzz_store<Fq>(out, blockIdx.x, acc);
+  if (threadIdx.x == 0) {
+    // the folded record leaves the device: C-ABI Montgomery radix from here on (identity on saturated fields)
+    XYZZ<Fq> e;
+    e.x = fe_export<Fq>(acc.x);
+    e.y = fe_export<Fq>(acc.y);
+    e.zz = fe_export<Fq>(acc.zz);
+    e.zzz = fe_export<Fq>(acc.zzz);
+    xyzz_store<Fq>(out, blockIdx.x, e);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -322,14 +330,15 @@ __global__ void __launch_bounds__(256)
                   u32 nbits, u32* __restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Affine<Fq> pr = affine_load<Fq>(r, i);
+  // l, r, out are caller-visible device buffers: C-ABI Montgomery radix in and out
+  Affine<Fq> pr = affine_import<Fq>(affine_load<Fq>(r, i));
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   for (int bit = (int)nbits - 1; bit >= 0; bit--) {
     acc = xyzz_dbl<Fq>(acc);
     if ((x_canon[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd<Fq>(acc, pr);
   }
-  xyzz_madd<Fq>(acc, affine_load<Fq>(l, i));
-  affine_store<Fq>(out, i, xyzz_to_affine<Fq>(acc));
+  xyzz_madd<Fq>(acc, affine_import<Fq>(affine_load<Fq>(l, i)));
+  affine_store<Fq>(out, i, affine_export<Fq>(xyzz_to_affine<Fq>(acc)));
 }
 
 // is_inf bytes -> (0,0) encoding on device
@@ -345,12 +354,34 @@ __global__ void __launch_bounds__(256) k_apply_inf(u32* __restrict__ table, cons
   }
 }
 
-// G_i = k_i * G, k_i = rng_scalar(seed, i); generator (gx, gy) passed in Montgomery form.
+// C-ABI radix <-> internal radix of a point array (key load / key read; not launched for saturated fields)
 template <class Fq>
-__global__ void __launch_bounds__(256)
-    k_generate_bases(u32* __restrict__ table, u64 seed, u32 n, Affine<Fq> gen) {
+__global__ void __launch_bounds__(256) k_points_import(const u32* __restrict__ src, u32* __restrict__ dst, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  affine_store<Fq>(dst, i, affine_import<Fq>(affine_load<Fq>(src, i)));
+}
+template <class Fq>
+__global__ void __launch_bounds__(256) k_points_export(const u32* __restrict__ src, u32* __restrict__ dst, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine_store<Fq>(dst, i, affine_export<Fq>(affine_load<Fq>(src, i)));
+}
+
+template <class Fq>
+struct AffineWords {  // an affine point as kernel-argument words (C-ABI Montgomery form)
+  u32 w[2 * Fq::W];
+};
+
+// G_i = k_i * G, k_i = rng_scalar(seed, i); generator (gx, gy) passed in (C-ABI) Montgomery form.
+template <class Fq>
+__global__ void __launch_bounds__(256)
+    k_generate_bases(u32* __restrict__ table, u64 seed, u32 n, AffineWords<Fq> gw) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<Fq> gen;
+  gen.x = fe_import<Fq>(fe_from_words<Fq>(gw.w));
+  gen.y = fe_import<Fq>(fe_from_words<Fq>(gw.w + Fq::W));
   u32 k[8];
   rng_scalar(seed, i, k);
   XYZZ<Fq> acc = xyzz_inf<Fq>();

@@ -260,6 +260,9 @@ __global__ void __launch_bounds__(256)
   if (b == g.B - 1) {
     start[g.B] = hi;
     items[g.B] = 0;
+    // accumulate L0 reads entries in groups of 4 and prefetches the point of every entry it reads: the up to 3
+    // entries past E must hold a valid table index (the sort only wrote E of them)
+    for (u32 k = g.E; k < ((g.E + 3u) & ~3u); k++) vals_sorted[k] = 0;
   }
 }
 

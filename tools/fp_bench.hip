@@ -8,37 +8,43 @@
 using namespace amsm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-template <class P, int MODE>
-__global__ void __launch_bounds__(256) kern(u32* out, int iters) {
+template <class P, int MODE, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW) kern(u32* out, int iters) {
   Fe<P> x, y;
   for (int i = 0; i < P::L; i++) { x.v[i] = threadIdx.x * 2654435761u + i * 40503u + blockIdx.x; y.v[i] = threadIdx.x * 97u + i * 7919u + 12345u; }
   x.v[P::L - 1] &= 0x0fffffffu; y.v[P::L - 1] &= 0x0fffffffu;
-  if (MODE == 0) {  // dependent multiplication chain
+  if constexpr (P::UNSAT) {  // tight limbs, value < 2^254
+    for (int i = 0; i < P::L; i++) { x.v[i] &= u_mask<P>(); y.v[i] &= u_mask<P>(); }
+    x.v[P::L - 1] &= 0x003fffffu; y.v[P::L - 1] &= 0x003fffffu;
+  }
+  if constexpr (MODE == 0) {  // dependent multiplication chain
     for (int i = 0; i < iters; i++) x = fe_mul<P>(x, y);
-  } else if (MODE == 1) {  // portable reference multiplication
+  } else if constexpr (MODE == 1) {  // portable reference multiplication
     for (int i = 0; i < iters; i++) x = fe_mul_ref<P>(x, y);
-  } else if (MODE == 2) {  // add/sub chain
+  } else if constexpr (MODE == 2) {  // add/sub chain
     for (int i = 0; i < iters; i++) { x = fe_add<P>(x, y); y = fe_sub<P>(y, x); }
-  } else if (MODE == 3) {  // mixed addition chain
+  } else if constexpr (MODE == 3) {  // mixed addition chain
     XYZZ<P> acc; acc.x = x; acc.y = y; acc.zz = fe_one<P>(); acc.zzz = fe_one<P>();
     Affine<P> q; q.x = y; q.y = x;
     for (int i = 0; i < iters; i++) { xyzz_madd<P>(acc, q); q.x.v[0] += 1; }
-    x = fe_add<P>(fe_add<P>(acc.x, acc.y), fe_add<P>(acc.zz, acc.zzz));
+    for (int i = 0; i < P::L; i++) x.v[i] = acc.x.v[i] ^ acc.y.v[i] ^ acc.zz.v[i] ^ acc.zzz.v[i];
+  } else if constexpr (MODE == 4) {  // squaring chain
+    for (int i = 0; i < iters; i++) x = fe_sqr<P>(x);
   }
   u32 o = 0;
   for (int i = 0; i < P::L; i++) o ^= x.v[i] ^ y.v[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = o;
 }
 
-template <class P, int MODE>
+template <class P, int MODE, int MINW = 1>
 int run(const char* name, int waves_per_simd, int iters, double ops_per_iter, u32* d_out) {
   int blocks = 256 * waves_per_simd;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  kern<P, MODE><<<blocks, 256>>>(d_out, iters);
+  kern<P, MODE, MINW><<<blocks, 256>>>(d_out, iters);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  kern<P, MODE><<<blocks, 256>>>(d_out, iters);
+  kern<P, MODE, MINW><<<blocks, 256>>>(d_out, iters);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -57,6 +63,10 @@ int main() {
     run<PallasFq, 1>("pallas fe_mul_ref (hipcc)", w, 2000, 1, d_out);
     run<PallasFq, 2>("pallas fe_add+fe_sub", w, 4000, 2, d_out);
     run<PallasFq, 3>("pallas xyzz_madd", w, 400, 1, d_out);
+    run<PallasFqU, 0>("pallas 9x29 fe_mul", w, 2000, 1, d_out);
+    run<PallasFqU, 4>("pallas 9x29 fe_sqr", w, 2000, 1, d_out);
+    run<PallasFqU, 3>("pallas 9x29 xyzz_madd", w, 400, 1, d_out);
+    run<PallasFqU, 3, 4>("pallas 9x29 xyzz_madd (<=128 VGPR)", w, 400, 1, d_out);
     run<Bls12381Fq, 0>("bls12-381 fe_mul (asm)", w, 1000, 1, d_out);
     run<Bls12381Fq, 3>("bls12-381 xyzz_madd", w, 200, 1, d_out);
   }
