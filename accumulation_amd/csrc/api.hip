@@ -57,7 +57,7 @@ struct amsm_ctx {
   hipStream_t stream = nullptr;  // == slot[0].stream
   int window_override = 0;
   int K0 = 0;          // 0 = automatic (see make_geom)
-  int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x 4 SIMDs x 4 waves
+  int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x resident 256-lane blocks per CU x 4
   int K1 = 1024;  // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew only)
   int red_s = 4;
   bool profiling = false;
@@ -217,17 +217,22 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   g.precomp = (u32)bases->precomp;
   if ((unsigned long long)bases->n * (bases->precomp ? W : 1) >= (1ull << 30)) return AMSM_E_UNSUPPORTED;
   // chunk length of accumulate L0: the grid should be a whole number of rounds of the resident wave
-  // slots (4 waves/SIMD at ~122 VGPRs), so that no SIMD idles while a partial last round drains
+  // slots (queried from the kernel's occupancy), so that no SIMD idles while a partial last round drains
   if (ctx->K0 > 0) {
     g.K0 = (u32)ctx->K0;
   } else {
-    unsigned long long lanes = (unsigned long long)ctx->wave_slots * 64ull;
-    // <= 32 entries per lane per round: measured best on MI355X (2^20 Pallas: 2 rounds of 32 beat 1 round of 64
-    // once consecutive MSMs of a batch overlap, because the other MSM's sort/tail kernels get wave slots at
-    // the round boundary)
-    unsigned long long rounds = (g.E + lanes * 32ull - 1) / (lanes * 32ull);
-    unsigned long long k = (g.E + lanes * rounds - 1) / (lanes * rounds);
-    g.K0 = (u32)std::min<unsigned long long>(std::max<unsigned long long>(k, 16ull), 32ull);
+    // every lane runs K0 mixed additions; the grid executes in ceil(blocks / resident blocks) rounds, so the cost
+    // is rounds * K0: pick the multiple of 4 that wastes the least of the last round (smaller K0 on ties: more
+    // partials but finer interleaving with the other MSMs of a batch)
+    unsigned long long slot_blocks = std::max(1, ctx->wave_slots / 4), best = ~0ull;
+    for (unsigned long long k = 16; k <= 64; k += 4) {
+      unsigned long long blocks = ((g.E + k - 1) / k + 255) / 256;
+      unsigned long long cost = ((blocks + slot_blocks - 1) / slot_blocks) * k;
+      if (cost < best) {
+        best = cost;
+        g.K0 = (u32)k;
+      }
+    }
   }
   g.K0 = (g.K0 + 3u) & ~3u;  // accumulate L0 reads entries in groups of 4
   g.K1 = (u32)ctx->K1;
@@ -247,6 +252,16 @@ u32 l1_lanes(const MsmGeom& g) {
   double avg = ((double)g.E / g.K0) / g.B;
   return avg >= 24.0 ? 16u : (avg >= 3.0 ? 4u : 1u);
 }
+
+// AMSM_DEBUG=1: synchronise after every stage of the pipeline and report it on stderr (finds the faulting kernel)
+#define AMSM_DBG(name)                                    \
+  do {                                                    \
+    if (getenv("AMSM_DEBUG")) {                           \
+      fprintf(stderr, "[amsm] %s ...", name);             \
+      hipError_t e_ = hipDeviceSynchronize();             \
+      fprintf(stderr, " %s\n", hipGetErrorString(e_));    \
+    }                                                     \
+  } while (0)
 
 // Enqueue the whole pipeline for one MSM on slot `sl` (asynchronous); leaves n_sets folded XYZZ records
 // in sl->fold_out and queues their D2H into sl->h_pinned.
@@ -316,7 +331,6 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
     HIP_TRY(rocprim::exclusive_scan(sl->scan_tmp.p, tmp, (u32*)sl->items.p, (u32*)sl->item_off.p, 0u,
                                     (size_t)(g.B + 1), rocprim::plus<u32>(), st));
   }
-#define AMSM_DBG(name) do { if (getenv("AMSM_DEBUG")) { fprintf(stderr, "[amsm] %s ...", name); hipError_t e_ = hipDeviceSynchronize(); fprintf(stderr, " %s\n", hipGetErrorString(e_)); } } while (0)
   AMSM_DBG("pre-l0");
   stage_mark(ctx, sl, ST_ACCUM_L0);
   launch_accum_l0<Fq>(st, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)sl->start.p,
@@ -846,8 +860,10 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   }
   {
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
-      c->wave_slots = prop.multiProcessorCount * 4 * 4;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
+      int per_cu = curve == AMSM_PALLAS ? accum_l0_blocks_per_cu<PallasFq>() : accum_l0_blocks_per_cu<Bls12381Fq>();
+      c->wave_slots = prop.multiProcessorCount * std::max(1, per_cu) * 4;
+    }
   }
   if (const char* e = getenv("AMSM_K0")) c->K0 = std::max(0, atoi(e));
   if (const char* e = getenv("AMSM_K1")) c->K1 = std::max(1, atoi(e));

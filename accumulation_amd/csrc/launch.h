@@ -13,6 +13,8 @@ template <class Fq>
 void launch_accum_l0(hipStream_t st, const u32* table, const u32* vals_sorted, const u32* start,
                      const u32* item_off, MsmGeom g, u32* partials);
 template <class Fq>
+int accum_l0_blocks_per_cu();  // resident 256-lane workgroups of accumulate L0 per CU (occupancy query)
+template <class Fq>
 void launch_accum_l1(hipStream_t st, u32 lanes_per_bucket, const u32* partials, const u32* items, const u32* item_off, MsmGeom g,
                      u32* buckets, u32* heavy_count, u32* heavy_list);
 template <class Fq>

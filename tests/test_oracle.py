@@ -62,6 +62,34 @@ def test_device_field_tables_match_oracle():
         assert inv == (-pow(m, -1, 1 << 32)) % (1 << 32)
 
 
+def test_device_unsaturated_field_tables_match_oracle():
+    """The 9 x 29-bit tables of the unsaturated Pallas base field (csrc/fpu.h): modulus, R' = 2^261, and the two
+    constants that convert between the C-ABI Montgomery radix 2^256 and R'."""
+    src = open(os.path.join(os.path.dirname(__file__), "..", "accumulation_amd", "csrc", "fpu.h")).read()
+    blk = src[src.index("struct PallasFqU {"):]
+    blk = blk[:blk.index("};")]
+    L = int(re.search(r"int L = (\d+);", blk).group(1))
+    B = int(re.search(r"int B = (\d+);", blk).group(1))
+    W = int(re.search(r"int W = (\d+);", blk).group(1))
+    m = o.PALLAS.p
+
+    def tab(t):
+        mm = re.search(r"AMSM_TABLE\(" + t + r", \d+, ([^)]*)\)", blk, re.S)
+        vals = [int(x.strip().rstrip("u"), 16) for x in mm.group(1).replace("\n", " ").split(",")]
+        assert len(vals) == L and all(v < (1 << B) for v in vals)
+        return sum(v << (B * i) for i, v in enumerate(vals))
+
+    R_abi, R_dev = 1 << (32 * W), 1 << (B * L)
+    assert tab("mod") == m
+    assert tab("one") == R_dev % m
+    assert tab("k_import") == R_dev * R_dev * pow(R_abi, -1, m) % m   # mont_mul(x R_abi, k) = x R_dev
+    assert tab("k_export") == R_abi % m                               # mont_mul(x R_dev, k) = x R_abi
+    ninv = int(re.search(r"NINV = (0x[0-9a-f]+)u", blk).group(1), 16)
+    assert ninv == (-pow(m, -1, 1 << B)) % (1 << B)
+    # headroom the bound comments in ec.h rely on: 2^(B L) >= 127 p
+    assert R_dev // m >= 127
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_python_oracle_matches_golden(c):
     g = h.load_golden()["curves"][c.name]

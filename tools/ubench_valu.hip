@@ -90,6 +90,34 @@ __global__ void __launch_bounds__(256) kern(uint32_t* out, uint32_t seed, unsign
 #define X(i) asm volatile("v_mul_lo_u32 %0, %1, %2\n\tv_mul_hi_u32 %0, %0, %2" : "+v"(x##i) : "v"(a), "v"(b));
       REP8(X)
 #undef X
+    } else if (OP == 11) { // 64-bit right shift
+#define X(i) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(r##i));
+      REP8(X)
+#undef X
+    } else if (OP == 12) { // 64-bit shift-add
+#define X(i) asm volatile("v_lshl_add_u64 %0, %1, 22, %0" : "+v"(r##i) : "v"(r7));
+      REP8(X)
+#undef X
+    } else if (OP == 13) { // funnel shift
+#define X(i) asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(x##i) : "v"(a));
+      REP8(X)
+#undef X
+    } else if (OP == 14) { // 64-bit left shift
+#define X(i) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(r##i));
+      REP8(X)
+#undef X
+    } else if (OP == 15) { // v_add3_u32
+#define X(i) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x##i) : "v"(a), "v"(b));
+      REP8(X)
+#undef X
+    } else if (OP == 16) { // v_and_b32 with literal
+#define X(i) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(x##i));
+      REP8(X)
+#undef X
+    } else if (OP == 17) { // v_mad_u64_u32 with SGPR multiplier
+#define X(i) asm volatile("v_mad_u64_u32 %0, s[10:11], %1, s20, %0" : "+v"(r##i) : "v"(a) : "s10", "s11");
+      REP8(X)
+#undef X
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -147,6 +175,13 @@ int main() {
     run<8>({"256-bit add (compiler carry chain)", 8}, w, d_out, d_clk);
     run<9>({"v_mad_u64_u32 dependent chain", 8}, w, d_out, d_clk);
     run<10>({"v_mul_lo+v_mul_hi pair", 16}, w, d_out, d_clk);
+    run<11>({"v_lshrrev_b64", 8}, w, d_out, d_clk);
+    run<12>({"v_lshl_add_u64", 8}, w, d_out, d_clk);
+    run<13>({"v_alignbit_b32", 8}, w, d_out, d_clk);
+    run<14>({"v_lshlrev_b64", 8}, w, d_out, d_clk);
+    run<15>({"v_add3_u32", 8}, w, d_out, d_clk);
+    run<16>({"v_and_b32 literal", 8}, w, d_out, d_clk);
+    run<17>({"v_mad_u64_u32 sgpr operand", 8}, w, d_out, d_clk);
   }
   return 0;
 }
