@@ -39,8 +39,8 @@ SEED_POINTS = 0x5EED1001
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n")
     ap.add_argument("--curve", default="pallas", choices=["pallas", "bls12_381_g1"])
     ap.add_argument("--no-precompute", action="store_true")
