@@ -35,12 +35,8 @@ struct DevBuf {
 // MSM i+1 on the other slot's stream.
 constexpr int N_SLOTS = 3;  // MSMs of one batch in flight
 
-struct Slot {
-  hipStream_t stream = nullptr;  // head: digits, sort, bounds, accumulate L0 (throughput-bound)
-  hipStream_t tail = nullptr;    // tail: fold partials, bucket reduce, D2H (latency-bound) -- high priority, so
-                                 // its few waves are dispatched ahead of the next MSM's not-yet-resident L0 blocks
-  bool own_stream = false;
-  hipEvent_t l0_done = nullptr;
+struct Slot {  // buffers and events of one MSM in flight (the streams belong to the context: one per pipeline stage)
+  hipEvent_t l0_done = nullptr, prep_done = nullptr;
   hipEvent_t ev[ST_COUNT + 1] = {};
   hipEvent_t done = nullptr;
   DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
@@ -54,7 +50,13 @@ struct Slot {
 struct amsm_ctx {
   int curve = 0;
   int device = 0;
-  hipStream_t stream = nullptr;  // == slot[0].stream
+  // One stream per pipeline STAGE, shared by all MSMs in flight (in-order per stage, so consecutive MSMs pipeline:
+  // prep(k+1) and tail(k-1) run beside accumulate L0 of MSM k).  One stream per MSM instead made the overlap depend on
+  // which hardware queues the runtime happened to map the streams to (measured 610-700 Mpairs/s for the same code).
+  hipStream_t stream = nullptr;  // main: the caller's stream -- accumulate L0 and every non-MSM kernel
+  hipStream_t s_prep = nullptr;  // digits, sort, bounds, scan (memory-bound)
+  hipStream_t s_tail = nullptr;  // fold partials, bucket reduce, fold, D2H (latency-bound)
+  bool own_stream = false;
   int window_override = 0;
   int K0 = 0;          // 0 = automatic (see make_geom)
   int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x resident 256-lane blocks per CU x 4
@@ -221,18 +223,13 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   if (ctx->K0 > 0) {
     g.K0 = (u32)ctx->K0;
   } else {
-    // every lane runs K0 mixed additions; the grid executes in ceil(blocks / resident blocks) rounds, so the cost
-    // is rounds * K0: pick the multiple of 4 that wastes the least of the last round (smaller K0 on ties: more
-    // partials but finer interleaving with the other MSMs of a batch)
-    unsigned long long slot_blocks = std::max(1, ctx->wave_slots / 4), best = ~0ull;
-    for (unsigned long long k = 16; k <= 64; k += 4) {
-      unsigned long long blocks = ((g.E + k - 1) / k + 255) / 256;
-      unsigned long long cost = ((blocks + slot_blocks - 1) / slot_blocks) * k;
-      if (cost < best) {
-        best = cost;
-        g.K0 = (u32)k;
-      }
-    }
+    // <= 32 entries per lane per round of resident waves, rounds equalised: measured best on MI355X for batches of
+    // MSMs (tools/ab_pipeline.py, 2^20 Pallas: K0 = 32 -> 703, 24 -> 700, 44 -> 695, 64 -> 690, 16 -> 634
+    // Mpairs/s): shorter chunks let the other MSMs' prep / tail kernels in sooner, longer ones halve the partials
+    unsigned long long lanes = (unsigned long long)ctx->wave_slots * 64ull;
+    unsigned long long rounds = (g.E + lanes * 32ull - 1) / (lanes * 32ull);
+    unsigned long long k = (g.E + lanes * rounds - 1) / (lanes * rounds);
+    g.K0 = (u32)std::min<unsigned long long>(std::max<unsigned long long>(k, 16ull), 32ull);
   }
   g.K0 = (g.K0 + 3u) & ~3u;  // accumulate L0 reads entries in groups of 4
   g.K1 = (u32)ctx->K1;
@@ -242,8 +239,8 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   return AMSM_OK;
 }
 
-void stage_mark(amsm_ctx* ctx, Slot* sl, int idx) {
-  if (ctx->profiling) (void)hipEventRecord(sl->ev[idx], sl->stream);
+void stage_mark(amsm_ctx* ctx, Slot* sl, int idx, hipStream_t st) {
+  if (ctx->profiling) (void)hipEventRecord(sl->ev[idx], st);
 }
 
 // lanes cooperating on one bucket in accumulate L1 (tree over partials): more lanes = lower latency,
@@ -263,6 +260,15 @@ u32 l1_lanes(const MsmGeom& g) {
     }                                                     \
   } while (0)
 
+// Work already queued on the caller's stream (e.g. the kernels that produced the scalars) must be
+// visible to the prep stream.  Called ONCE per API call, before its MSMs are enqueued -- never between the MSMs of
+// a batch: an event recorded on the caller's stream there would sit behind the previous MSM's accumulate L0.
+int prep_fork(amsm_ctx* ctx) {
+  HIP_TRY(hipEventRecord(ctx->fork, ctx->stream));
+  HIP_TRY(hipStreamWaitEvent(ctx->s_prep, ctx->fork, 0));
+  return AMSM_OK;
+}
+
 // Enqueue the whole pipeline for one MSM on slot `sl` (asynchronous); leaves n_sets folded XYZZ records
 // in sl->fold_out and queues their D2H into sl->h_pinned.
 template <class Fq, class Fr>
@@ -271,7 +277,8 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   MsmGeom g;
   TRY(make_geom(ctx, bases, base_off, n, &g));
   sl->geom = g;
-  hipStream_t st = sl->stream;
+  hipStream_t st = ctx->s_prep;  // digits / sort / bounds
+  hipStream_t sm = ctx->stream;  // accumulate L0
   const u32 max_items = g.E / g.K0 + g.B + 1;
   const u32 red_blocks = cdiv(g.red_threads, 256);
   TRY(ensure(sl->keys_a, (size_t)g.E * 4));
@@ -297,10 +304,10 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   u32* vals_b = (u32*)sl->vals_b.p;
 
   HIP_TRY(hipMemsetAsync(sl->misc.p, 0, 64, st));
-  stage_mark(ctx, sl, ST_DIGITS);
+  stage_mark(ctx, sl, ST_DIGITS, st);
   const bool keys16 = g.B < 65536u;  // every key (incl. the "digit 0" key B) fits 16 bits
   launch_digits<Fr>(st, (const u32*)d_scalars, scalars_mont, g, keys_a, keys16, vals_a, d_err);
-  stage_mark(ctx, sl, ST_SORT);
+  stage_mark(ctx, sl, ST_SORT, st);
   {
     int bits = 1;
     while ((1u << bits) <= g.B) bits++;
@@ -320,7 +327,7 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
                                         (unsigned)bits, st));
     }
   }
-  stage_mark(ctx, sl, ST_BOUNDS);
+  stage_mark(ctx, sl, ST_BOUNDS, st);
   launch_bounds(st, (const void*)keys_b, keys16, vals_b, g, (u32*)sl->start.p, (u32*)sl->items.p);
   {
     size_t tmp = 0;
@@ -332,12 +339,14 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
                                     (size_t)(g.B + 1), rocprim::plus<u32>(), st));
   }
   AMSM_DBG("pre-l0");
-  stage_mark(ctx, sl, ST_ACCUM_L0);
-  launch_accum_l0<Fq>(st, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)sl->start.p,
+  HIP_TRY(hipEventRecord(sl->prep_done, st));
+  HIP_TRY(hipStreamWaitEvent(sm, sl->prep_done, 0));
+  stage_mark(ctx, sl, ST_ACCUM_L0, sm);
+  launch_accum_l0<Fq>(sm, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)sl->start.p,
                       (const u32*)sl->item_off.p, g, (u32*)sl->partials.p);
   AMSM_DBG("l0");
-  HIP_TRY(hipEventRecord(sl->l0_done, st));
-  hipStream_t tl = sl->tail;
+  HIP_TRY(hipEventRecord(sl->l0_done, sm));
+  hipStream_t tl = ctx->s_tail;
   HIP_TRY(hipStreamWaitEvent(tl, sl->l0_done, 0));
   if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_ACCUM_L12], tl);
   launch_accum_l1<Fq>(tl, l1_lanes(g), (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
@@ -407,6 +416,7 @@ int msm_device_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, con
     return AMSM_OK;
   }
   stage_begin(ctx);
+  TRY(prep_fork(ctx));
   TRY((msm_enqueue<Fq, Fr>(ctx, &ctx->slot[0], bases, base_off, d_scalars, n, scalars_mont)));
   int rc = msm_collect<Fq>(ctx, &ctx->slot[0], out);
   stage_end(ctx);
@@ -422,10 +432,7 @@ int msm_batch_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, cons
   out->assign(n_vecs, host::hx_inf<Fq>());
   if (n == 0 || n_vecs == 0) return AMSM_OK;
   stage_begin(ctx);
-  // work already queued on the caller's stream (e.g. the kernels that produced the scalars) must be
-  // visible to the second stream
-  HIP_TRY(hipEventRecord(ctx->fork, ctx->slot[0].stream));
-  for (int k = 1; k < N_SLOTS; k++) HIP_TRY(hipStreamWaitEvent(ctx->slot[k].stream, ctx->fork, 0));
+  TRY(prep_fork(ctx));
   int rc = AMSM_OK;
   for (size_t v = 0; v < n_vecs && rc == AMSM_OK; v++) {
     Slot* sl = &ctx->slot[v % N_SLOTS];
@@ -713,12 +720,13 @@ int msm_partial_impl(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, co
   if (n == 0) return upload_xyzz<Fq>(ctx, host::hx_inf<Fq>(), d_out);
   Slot* sl = &ctx->slot[0];
   stage_begin(ctx);
+  TRY(prep_fork(ctx));
   TRY((msm_enqueue<Fq, Fr>(ctx, sl, bases, base_off, d_scalars, n, mont)));
   if (sl->geom.n_sets == 1) {
     // single folded record: it stays on the device (copied record-to-record); the host only waits for
     // the range flag
-    HIP_TRY(hipMemcpyAsync(d_out, sl->fold_out.p, xyzz_bytes<Fq>(), hipMemcpyDeviceToDevice, sl->tail));
-    HIP_TRY(hipEventRecord(sl->done, sl->tail));
+    HIP_TRY(hipMemcpyAsync(d_out, sl->fold_out.p, xyzz_bytes<Fq>(), hipMemcpyDeviceToDevice, ctx->s_tail));
+    HIP_TRY(hipEventRecord(sl->done, ctx->s_tail));
     host::HXYZZ<Fq> unused;
     int rc = msm_collect<Fq>(ctx, sl, &unused);
     stage_end(ctx);
@@ -832,25 +840,24 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   c->device = device_id;
   bool ok = true;
   if (stream) {
-    c->slot[0].stream = (hipStream_t)stream;
+    c->stream = (hipStream_t)stream;
   } else {
-    ok = ok && hipStreamCreateWithFlags(&c->slot[0].stream, hipStreamNonBlocking) == hipSuccess;
-    c->slot[0].own_stream = ok;
+    ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    c->own_stream = ok;
   }
-  int prio_lo = 0, prio_hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  for (int k = 0; k < N_SLOTS && ok; k++) {
-    if (k > 0) {
-      ok = ok && hipStreamCreateWithFlags(&c->slot[k].stream, hipStreamNonBlocking) == hipSuccess;
-      c->slot[k].own_stream = ok;
-    }
-    ok = ok && hipStreamCreateWithPriority(&c->slot[k].tail, hipStreamNonBlocking, prio_hi) == hipSuccess;
+  {
+    // prep and tail run beside another MSM's accumulate L0, which fills every wave slot: high priority lets their
+    // kernels take the slots L0 frees first
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    ok = ok && hipStreamCreateWithPriority(&c->s_prep, hipStreamNonBlocking, prio_hi) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&c->s_tail, hipStreamNonBlocking, prio_hi) == hipSuccess;
   }
-  c->stream = c->slot[0].stream;
   for (int k = 0; k < N_SLOTS && ok; k++) {
     for (int i = 0; i <= ST_COUNT && ok; i++) ok = hipEventCreate(&c->slot[k].ev[i]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->slot[k].l0_done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->slot[k].prep_done, hipEventDisableTiming) == hipSuccess;
   }
   ok = ok && hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -876,10 +883,11 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
 void amsm_ctx_destroy(amsm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->s_prep) (void)hipStreamSynchronize(c->s_prep);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->s_tail) (void)hipStreamSynchronize(c->s_tail);
   for (int k = 0; k < N_SLOTS; k++) {
     Slot* sl = &c->slot[k];
-    if (sl->stream) (void)hipStreamSynchronize(sl->stream);
-    if (sl->tail) (void)hipStreamSynchronize(sl->tail);
     DevBuf* bufs[] = {&sl->keys_a, &sl->keys_b, &sl->vals_a, &sl->vals_b, &sl->start, &sl->items, &sl->item_off,
                       &sl->partials, &sl->buckets, &sl->red_out, &sl->fold_out, &sl->heavy, &sl->misc, &sl->sort_tmp,
                       &sl->scan_tmp};
@@ -890,10 +898,12 @@ void amsm_ctx_destroy(amsm_ctx* c) {
       if (sl->ev[i]) (void)hipEventDestroy(sl->ev[i]);
     if (sl->done) (void)hipEventDestroy(sl->done);
     if (sl->l0_done) (void)hipEventDestroy(sl->l0_done);
-    if (sl->tail) (void)hipStreamDestroy(sl->tail);
-    if (sl->own_stream && sl->stream) (void)hipStreamDestroy(sl->stream);
+    if (sl->prep_done) (void)hipEventDestroy(sl->prep_done);
   }
   if (c->fork) (void)hipEventDestroy(c->fork);
+  if (c->s_prep) (void)hipStreamDestroy(c->s_prep);
+  if (c->s_tail) (void)hipStreamDestroy(c->s_tail);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   if (c->scalars.p) (void)hipFree(c->scalars.p);
   delete c;
 }
@@ -908,10 +918,9 @@ int amsm_ctx_set_window(amsm_ctx* c, int bits) {
 int amsm_ctx_synchronize(amsm_ctx* c) {
   if (!c) return AMSM_E_INVALID_ARG;
   TRY(bind_device(c));
-  for (int k = 0; k < N_SLOTS; k++) {
-    HIP_TRY(hipStreamSynchronize(c->slot[k].stream));
-    HIP_TRY(hipStreamSynchronize(c->slot[k].tail));
-  }
+  HIP_TRY(hipStreamSynchronize(c->s_prep));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipStreamSynchronize(c->s_tail));
   return AMSM_OK;
 }
 int amsm_ctx_set_profiling(amsm_ctx* c, int on) {
