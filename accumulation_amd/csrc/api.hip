@@ -696,6 +696,49 @@ int partials_combine_impl(amsm_ctx* ctx, const void* d_partials, size_t count, u
   return AMSM_OK;
 }
 
+// groups of `count` consecutive records -> one affine point per group (one D2H copy, one batched normalisation)
+template <class Fq>
+int partials_combine_batch_impl(amsm_ctx* ctx, const void* d_partials, size_t n_groups, size_t count, uint64_t* out_xy,
+                                uint8_t* out_inf) {
+  size_t rec = xyzz_bytes<Fq>();
+  Slot* sl = &ctx->slot[0];
+  size_t total = n_groups * count;
+  TRY(ensure_pinned(sl, total * rec + 64));
+  if (total) {
+    HIP_TRY(hipMemcpyAsync(sl->h_pinned, d_partials, total * rec, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  std::vector<host::HXYZZ<Fq>> pts(n_groups, host::hx_inf<Fq>());
+  for (size_t g = 0; g < n_groups; g++)
+    for (size_t i = 0; i < count; i++)
+      pts[g] = host::hx_add<Fq>(pts[g], host::hx_from_device<Fq>((const u32*)sl->h_pinned + (g * count + i) * (rec / 4)));
+  write_affine_batch<Fq>(pts, out_xy, out_inf);
+  return AMSM_OK;
+}
+
+// n_vecs MSMs (pipelined like msm_batch_xyzz) -> n_vecs consecutive device records at d_out
+template <class Fq, class Fr>
+int msm_partial_batch_impl(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* const* d_scalars,
+                           size_t n_vecs, size_t n, int mont, void* d_out) {
+  std::vector<host::HXYZZ<Fq>> r;
+  TRY((msm_batch_xyzz<Fq, Fr>(ctx, bases, base_off, d_scalars, n_vecs, n, mont, &r)));
+  if (!n_vecs) return AMSM_OK;
+  size_t rec = xyzz_bytes<Fq>();
+  Slot* sl = &ctx->slot[0];
+  TRY(ensure_pinned(sl, n_vecs * rec + 64));
+  u32* h = (u32*)sl->h_pinned;
+  for (size_t v = 0; v < n_vecs; v++) {
+    u32* o = h + v * (rec / 4);
+    memcpy(o, r[v].x.v, rec / 4);
+    memcpy(o + Fq::L, r[v].y.v, rec / 4);
+    memcpy(o + 2 * Fq::L, r[v].zz.v, rec / 4);
+    memcpy(o + 3 * Fq::L, r[v].zzz.v, rec / 4);
+  }
+  HIP_TRY(hipMemcpyAsync(d_out, h, n_vecs * rec, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return AMSM_OK;
+}
+
 // store a host XYZZ as a device record
 template <class Fq>
 int upload_xyzz(amsm_ctx* ctx, const host::HXYZZ<Fq>& p, void* d_out) {
@@ -1030,6 +1073,25 @@ int amsm_msm_partial_device(amsm_ctx* c, const amsm_bases* b, size_t off, const 
   TRY(bind_device(c));
   return DISPATCH(c, (msm_partial_impl<PallasFq, PallasFr>(c, b, off, d_scalars, n, mont, d_out)),
                   (msm_partial_impl<Bls12381Fq, Bls12381Fr>(c, b, off, d_scalars, n, mont, d_out)));
+}
+
+int amsm_msm_partial_batch_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* const* d_scalars, size_t n_vecs,
+                                  size_t n, int mont, void* d_out) {
+  if (!c || !b || (n_vecs && (!d_scalars || !d_out)) || b->curve != c->curve || b->device != c->device)
+    return AMSM_E_INVALID_ARG;
+  for (size_t v = 0; v < n_vecs; v++)
+    if (n && !d_scalars[v]) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c, (msm_partial_batch_impl<PallasFq, PallasFr>(c, b, off, d_scalars, n_vecs, n, mont, d_out)),
+                  (msm_partial_batch_impl<Bls12381Fq, Bls12381Fr>(c, b, off, d_scalars, n_vecs, n, mont, d_out)));
+}
+
+int amsm_partials_combine_batch(amsm_ctx* c, const void* d_partials, size_t n_groups, size_t count, uint64_t* out_xy,
+                                uint8_t* out_inf) {
+  if (!c || (n_groups && !out_xy) || (n_groups && count && !d_partials)) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c, (partials_combine_batch_impl<PallasFq>(c, d_partials, n_groups, count, out_xy, out_inf)),
+                  (partials_combine_batch_impl<Bls12381Fq>(c, d_partials, n_groups, count, out_xy, out_inf)));
 }
 
 int amsm_partials_combine(amsm_ctx* c, const void* d_partials, size_t count, uint64_t* out_xy, uint8_t* out_inf) {

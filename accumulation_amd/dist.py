@@ -49,6 +49,29 @@ class HipEngine:
                                                       C.byref(inf)), "amsm_partials_combine")
         return out, bool(inf.value)
 
+    def partial_batch(self, vecs, mont: bool):
+        """vecs: FrVectors of equal length (this rank's slices of len(vecs) MSMs, pipelined on the device).
+        Returns a uint8 CUDA tensor of len(vecs) consecutive records."""
+        import torch
+        from . import ffi
+        k = len(vecs)
+        out = torch.zeros(max(k, 1) * self.record_bytes, dtype=torch.uint8, device=f"cuda:{self.ctx.device}")
+        ptrs = (C.c_void_p * max(k, 1))(*[v.ptr for v in vecs])
+        ffi.check(self.ctx._lib.amsm_msm_partial_batch_device(self.ctx._h, self.ck._h, 0, ptrs, k, vecs[0].n if k else 0,
+                                                              1 if mont else 0, C.c_void_p(out.data_ptr())),
+                  "amsm_msm_partial_batch_device")
+        return out[: k * self.record_bytes]
+
+    def combine_batch(self, grouped, n_groups: int, count: int):
+        """grouped: n_groups groups of `count` consecutive records.  Returns (n_groups x 2L u64, n_groups bools)."""
+        from . import ffi
+        from .engine import _ptr
+        out = np.zeros((max(n_groups, 1), 2 * self.ctx.fq_limbs), dtype=np.uint64)
+        inf = np.zeros((max(n_groups, 1),), dtype=np.uint8)
+        ffi.check(self.ctx._lib.amsm_partials_combine_batch(self.ctx._h, C.c_void_p(grouped.data_ptr()), n_groups, count,
+                                                            _ptr(out), _ptr(inf)), "amsm_partials_combine_batch")
+        return out[:n_groups], inf[:n_groups].astype(bool)
+
 
 class ShardedMSM:
     """msm(local_scalars) -> the affine result of the WHOLE (all ranks) MSM, identical on every rank."""
@@ -71,3 +94,32 @@ class ShardedMSM:
             self._gathered = torch.empty(part.numel() * self.world, dtype=torch.uint8, device=part.device)
         dist.all_gather_into_tensor(self._gathered, part, group=self.group)
         return self.engine.combine(self._gathered, self.world)
+
+    def msm_batch(self, local_vecs, mont: bool = True):
+        """len(local_vecs) whole-job MSMs with ONE exchange: every rank runs its slices back to back (pipelined on
+        the device), the ranks all-gather all their records at once, and every rank folds group j = the ranks'
+        records of MSM j.  Returns (k x 2L u64 array, k bools), identical on every rank."""
+        import torch
+        import torch.distributed as dist
+        k = len(local_vecs)
+        rec = self.engine.record_bytes
+        if hasattr(self.engine, "partial_batch"):
+            parts = self.engine.partial_batch(local_vecs, mont)
+        else:  # engines without a batched entry point: one record at a time
+            parts = torch.cat([self.engine.partial(v, mont).clone() for v in local_vecs]) if k else \
+                torch.zeros(0, dtype=torch.uint8)
+        if self.world > 1:
+            gathered = torch.empty(self.world * k * rec, dtype=torch.uint8, device=parts.device)
+            dist.all_gather_into_tensor(gathered, parts.contiguous(), group=self.group)
+            # [rank][msm][record] -> [msm][rank][record]
+            grouped = gathered.view(self.world, k, rec).permute(1, 0, 2).contiguous().view(-1)
+        else:
+            grouped = parts
+        if hasattr(self.engine, "combine_batch"):
+            return self.engine.combine_batch(grouped, k, self.world)
+        outs, infs = [], []
+        for j in range(k):
+            o_, i_ = self.engine.combine(grouped[j * self.world * rec:(j + 1) * self.world * rec], self.world)
+            outs.append(o_)
+            infs.append(i_)
+        return np.array(outs, dtype=np.uint64), np.array(infs, dtype=bool)

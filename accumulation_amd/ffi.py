@@ -59,6 +59,8 @@ SIGNATURES = {
     "amsm_partial_bytes": (_sz, [_vp]),
     "amsm_msm_partial_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp]),
     "amsm_partials_combine": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
+    "amsm_msm_partial_batch_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_vp), _sz, _sz, C.c_int, _vp]),
+    "amsm_partials_combine_batch": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "amsm_pedersen_commit": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "amsm_pedersen_commit_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "amsm_host_lincomb": (C.c_int, [C.c_int, _vp, _vp, _vp, _sz, _vp, _vp]),

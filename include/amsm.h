@@ -130,6 +130,14 @@ int amsm_msm_partial_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_
                             int scalars_mont, void* d_partial_out);
 int amsm_partials_combine(amsm_ctx* ctx, const void* d_partials, size_t n_partials, uint64_t* out_xy_mont,
                           uint8_t* out_is_inf);
+/* Batched forms (the prover commits several vectors back to back, src/hp_as/mod.rs:354-388): n_vecs MSMs over the
+ * rank's shard, pipelined like amsm_msm_batch_device, leave n_vecs consecutive records at d_partials_out; after ONE
+ * all-gather of all records, amsm_partials_combine_batch folds n_groups groups of `count` consecutive records
+ * (group g = the `count` ranks' records of MSM g) into n_groups consecutive affine points. */
+int amsm_msm_partial_batch_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* const* d_scalars,
+                                  size_t n_vecs, size_t n, int scalars_mont, void* d_partials_out);
+int amsm_partials_combine_batch(amsm_ctx* ctx, const void* d_partials, size_t n_groups, size_t count,
+                                uint64_t* out_xy_mont, uint8_t* out_is_inf);
 
 /* Replaces `PedersenCommitment::commit(ck, elems, Some(r))` (ext): MSM over ck.generators[..n] plus
  * r * hiding_generator (single scalar-mul, done on the host like SURVEY.md section 8(a) row a11).

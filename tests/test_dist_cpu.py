@@ -69,8 +69,12 @@ def _worker(rank, world, init_file, n, q):
         sc = cref.rng_scalars(0x5EED0001, n)
         lo, hi = shard_bounds(n, rank, world)
         eng = OracleEngine(c, xy[lo:hi])
-        out, inf = ShardedMSM(eng).msm(sc[lo:hi], mont=False)
-        q.put((rank, out.tolist(), inf))
+        sm = ShardedMSM(eng)
+        out, inf = sm.msm(sc[lo:hi], mont=False)
+        # batched form: 3 MSMs (the second with the scalars reversed), one all-gather of all the records
+        sc2 = cref.rng_scalars(0x5EED0002, n)
+        outs, infs = sm.msm_batch([sc[lo:hi], sc2[lo:hi], sc[lo:hi]], mont=False)
+        q.put((rank, out.tolist(), inf, outs.tolist(), [bool(x) for x in infs]))
     finally:
         dist.destroy_process_group()
 
@@ -91,5 +95,7 @@ def test_sharded_msm_world2_gloo(n, cref):
             assert p.exitcode == 0
     c = o.PALLAS
     ref, rinf = cref.msm(c.curve_id, cref.rng_points(c.curve_id, 0x5EED1001, n), cref.rng_scalars(0x5EED0001, n))
-    for rank, out, inf in res:
+    ref2, rinf2 = cref.msm(c.curve_id, cref.rng_points(c.curve_id, 0x5EED1001, n), cref.rng_scalars(0x5EED0002, n))
+    for rank, out, inf, outs, infs in res:
         assert inf == rinf and out == ref.tolist(), rank
+        assert infs == [rinf, rinf2, rinf] and outs == [ref.tolist(), ref2.tolist(), ref.tolist()], rank

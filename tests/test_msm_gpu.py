@@ -260,6 +260,35 @@ def test_partials_roundtrip_single_rank(ctxs, cref):
         assert bool(inf.value) == rinf and np.array_equal(out, ref)
 
 
+def test_partials_batch_roundtrip_single_rank(ctxs, cref):
+    """Batched multi-GPU entry points on one device: two key shards play two ranks; each leaves 3 records, the
+    records are regrouped as an all-gather would deliver them and folded in one call."""
+    import torch
+    from accumulation_amd import CommitterKey
+    from accumulation_amd.dist import HipEngine
+    c = o.PALLAS
+    ctx = ctxs[c.name]
+    n, half = 2500, 1200
+    xy = cref.rng_points(c.curve_id, 41, n)
+    scs = [cref.rng_scalars(50 + j, n) for j in range(3)]
+    refs = [cref.msm(c.curve_id, xy, sc, threads=4) for sc in scs]
+    for flags in (1, 2):
+        parts = []
+        engs = []
+        for lo, hi in ((0, half), (half, n)):
+            eng = HipEngine(ctx, CommitterKey.load(ctx, xy[lo:hi], None, flags))
+            engs.append(eng)
+            parts.append(eng.partial_batch([ctx.upload(sc[lo:hi]) for sc in scs], mont=False).clone())
+        rec = engs[0].record_bytes
+        gathered = torch.cat(parts)  # [rank][msm][record]
+        grouped = gathered.view(2, 3, rec).permute(1, 0, 2).contiguous().view(-1)
+        outs, infs = engs[0].combine_batch(grouped, 3, 2)
+        for j in range(3):
+            assert bool(infs[j]) == refs[j][1] and np.array_equal(outs[j], refs[j][0]), (flags, j)
+        for e in engs:
+            e.ck.free()
+
+
 def test_randomized_geometry_stress(ctxs, cref):
     """Random (n, window, key kind, chunk length) combinations against the C oracle: exercises entry counts that are
     not multiples of the group size, chunks that straddle many / few buckets, windows whose last digit is short."""
