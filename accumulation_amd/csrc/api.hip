@@ -40,7 +40,7 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   hipEvent_t ev[ST_COUNT + 1] = {};
   hipEvent_t done = nullptr;
   DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
-      sort_tmp, scan_tmp;
+      sort_tmp, scan_tmp, prep_small;
   void* h_pinned = nullptr;
   size_t h_pinned_bytes = 0;
   MsmGeom geom = {};
@@ -57,6 +57,7 @@ struct amsm_ctx {
   hipStream_t s_prep = nullptr;  // digits, sort, bounds, scan (memory-bound)
   hipStream_t s_tail = nullptr;  // fold partials, bucket reduce, fold, D2H (latency-bound)
   bool own_stream = false;
+  bool custom_prep = true;  // AMSM_PREP=rocprim: digits + rocPRIM radix sort + bounds + rocPRIM scan instead (A/B, fallback)
   int window_override = 0;
   int K0 = 0;          // 0 = automatic (see make_geom)
   int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x resident 256-lane blocks per CU x 4
@@ -305,6 +306,21 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
 
   HIP_TRY(hipMemsetAsync(sl->misc.p, 0, 64, st));
   stage_mark(ctx, sl, ST_DIGITS, st);
+  if (ctx->custom_prep && prep_supported(g)) {
+    // 5-dispatch prep chain (prep_kernels.h); the stage marks keep their names: "sort" = scatter + local sort
+    TRY(ensure(sl->prep_small, 4 * (4096 + 1) * 4));
+    PrepBuffers pb;
+    pb.d_small = (u32*)sl->prep_small.p;
+    pb.part = vals_a;
+    pb.vals_sorted = vals_b;
+    pb.start = (u32*)sl->start.p;
+    pb.items = (u32*)sl->items.p;
+    pb.item_off = (u32*)sl->item_off.p;
+    pb.err = d_err;
+    if (launch_prep<Fr>(st, (const u32*)d_scalars, scalars_mont, g, pb) != 0) return AMSM_E_HIP;
+    stage_mark(ctx, sl, ST_SORT, st);
+    stage_mark(ctx, sl, ST_BOUNDS, st);
+  } else {
   const bool keys16 = g.B < 65536u;  // every key (incl. the "digit 0" key B) fits 16 bits
   launch_digits<Fr>(st, (const u32*)d_scalars, scalars_mont, g, keys_a, keys16, vals_a, d_err);
   stage_mark(ctx, sl, ST_SORT, st);
@@ -339,6 +355,7 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
                                     (size_t)(g.B + 1), rocprim::plus<u32>(), st));
   }
   AMSM_DBG("pre-l0");
+  }
   HIP_TRY(hipEventRecord(sl->prep_done, st));
   HIP_TRY(hipStreamWaitEvent(sm, sl->prep_done, 0));
   stage_mark(ctx, sl, ST_ACCUM_L0, sm);
@@ -915,6 +932,7 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
       c->wave_slots = prop.multiProcessorCount * std::max(1, per_cu) * 4;
     }
   }
+  if (const char* e = getenv("AMSM_PREP")) c->custom_prep = strcmp(e, "rocprim") != 0;
   if (const char* e = getenv("AMSM_K0")) c->K0 = std::max(0, atoi(e));
   if (const char* e = getenv("AMSM_K1")) c->K1 = std::max(1, atoi(e));
   if (const char* e = getenv("AMSM_RED_S")) c->red_s = std::max(1, atoi(e));
@@ -933,7 +951,7 @@ void amsm_ctx_destroy(amsm_ctx* c) {
     Slot* sl = &c->slot[k];
     DevBuf* bufs[] = {&sl->keys_a, &sl->keys_b, &sl->vals_a, &sl->vals_b, &sl->start, &sl->items, &sl->item_off,
                       &sl->partials, &sl->buckets, &sl->red_out, &sl->fold_out, &sl->heavy, &sl->misc, &sl->sort_tmp,
-                      &sl->scan_tmp};
+                      &sl->scan_tmp, &sl->prep_small};
     for (DevBuf* b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (sl->h_pinned) (void)hipHostFree(sl->h_pinned);

@@ -2,6 +2,7 @@
 // loops) instantiated for the scalar fields of both curves, plus the curve-independent bounds kernel.
 #include "launch.h"
 #include "vec_kernels.h"
+#include "prep_kernels.h"
 
 #include <cstring>
 
@@ -19,12 +20,60 @@ void launch_bounds(hipStream_t st, const void* keys_sorted, bool keys16, u32* va
                        g, start, items);
 }
 
+// partitions of 2^SH consecutive buckets, at most PREP_MAX_P of them (about 512 when the bucket count allows)
+constexpr u32 PREP_MAX_P = 4096;
+static PrepGeom prep_geom(const MsmGeom& g) {
+  PrepGeom pg;
+  pg.SH = 4;
+  while (((g.B + (1u << pg.SH) - 1u) >> pg.SH) > 512u && pg.SH < 10u) pg.SH++;
+  while (((g.B + (1u << pg.SH) - 1u) >> pg.SH) > PREP_MAX_P) pg.SH++;
+  pg.P = (g.B + (1u << pg.SH) - 1u) >> pg.SH;
+  pg.SPB = g.W <= 16u ? 512u : 256u;  // SPB * W <= 8192 staged entries
+  unsigned long long max_idx = (unsigned long long)g.base_off + g.n - 1ull +
+                               (g.precomp ? (unsigned long long)(g.W - 1u) * g.table_stride : 0ull);
+  pg.IB = 1;
+  while ((max_idx >> pg.IB) != 0ull) pg.IB++;
+  return pg;
+}
+bool prep_supported(const MsmGeom& g) {
+  if (g.n == 0 || g.W > 32u) return false;  // W > 32 <=> c < 8: tiny problems, the rocPRIM chain is fine there
+  PrepGeom pg = prep_geom(g);
+  // entry word = negate | bucket-id low bits << IB | index; k_prep_local keeps 2 * 2^SH + 256 words in LDS
+  return pg.SH <= 12u && pg.IB + pg.SH <= 31u;
+}
+
 void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
   hipLaunchKernelGGL(k_vec_fill, dim3(cdiv_(n, 256)), dim3(256), 0, st, out, make_uint4(v[0], v[1], v[2], v[3]),
                      make_uint4(v[4], v[5], v[6], v[7]), n);
 }
 
 #define AMSM_FR_LAUNCHERS(FR)                                                                                        \
+  template <>                                                                                                        \
+  int launch_prep<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBuffers& b) {               \
+    PrepGeom pg = prep_geom(g);                                                                                      \
+    u32* part_total = b.d_small;                                                                                     \
+    u32* part_start = b.d_small + (PREP_MAX_P + 1);                                                                  \
+    u32* part_cursor = b.d_small + 2 * (PREP_MAX_P + 1);                                                             \
+    u32* part_items = b.d_small + 3 * (PREP_MAX_P + 1);                                                              \
+    if (hipMemsetAsync(b.d_small, 0, 4 * (PREP_MAX_P + 1) * sizeof(u32), st) != hipSuccess) return -1;               \
+    u32 blocks = cdiv_(g.n, pg.SPB);                                                                                 \
+    u32 cap = pg.SPB * g.W;                                                                                          \
+    size_t lds_scatter = (3 * pg.P + cap) * sizeof(u32) + cap * sizeof(uint16_t);                                    \
+    hipLaunchKernelGGL((k_prep_hist<FR>), dim3(blocks), dim3(256), pg.P * sizeof(u32), st, scalars, mont, g, pg,      \
+                       part_total, b.err);                                                                           \
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P);                       \
+    if (g.W <= 16u)                                                                                                  \
+      hipLaunchKernelGGL((k_prep_scatter<FR, 16, 2>), dim3(blocks), dim3(256), lds_scatter, st, scalars, mont, g, pg, \
+                         part_start, part_cursor, b.part);                                                           \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_prep_scatter<FR, 32, 1>), dim3(blocks), dim3(256), lds_scatter, st, scalars, mont, g, pg, \
+                         part_start, part_cursor, b.part);                                                           \
+    hipLaunchKernelGGL(k_prep_local, dim3(pg.P), dim3(256), (2 * (1u << pg.SH) + 256) * sizeof(u32), st, part_start, \
+                       b.part, g, pg, b.vals_sorted, b.start, b.items, b.item_off, part_items);                      \
+    hipLaunchKernelGGL(k_prep_offsets, dim3(cdiv_(g.B, 256)), dim3(256), (pg.P + 256) * sizeof(u32), st, part_start, \
+                       part_items, pg, g, b.start, b.items, b.item_off, b.vals_sorted);                              \
+    return 0;                                                                                                        \
+  }                                                                                                                  \
   template <>                                                                                                        \
   void launch_digits<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, void* keys, bool keys16, u32* vals, \
                          u32* err) {                                                                                 \

@@ -47,6 +47,21 @@ void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>
 void launch_digits(hipStream_t st, const u32* scalars, int mont, MsmGeom g, void* keys, bool keys16, u32* vals, u32* err);
+// Custom prep chain (prep_kernels.h): scalars -> sorted entry list + bucket table in 5 dispatches.  d_small holds
+// 4 * (4096 + 1) words (partition totals, starts, cursors, partial counts) and is zeroed by the launcher.
+struct PrepBuffers {
+  u32* d_small;       // >= 4 * (4096 + 1) words
+  u32* part;          // E words: entries grouped by partition
+  u32* vals_sorted;   // E + 16 words
+  u32* start;         // B + 2 words
+  u32* items;         // B + 2 words
+  u32* item_off;      // B + 2 words
+  u32* err;
+};
+bool prep_supported(const MsmGeom& g);
+template <class Fr>
+int launch_prep(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBuffers& b);
+
 template <class Fr>
 void launch_vec_random(hipStream_t st, u32* out, u64 seed, u32 n, int mont);
 template <class Fr>

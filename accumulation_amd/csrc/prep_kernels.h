@@ -1,0 +1,369 @@
+// MSM "prep": scalars -> the bucket-sorted entry list accumulate L0 consumes, in FIVE dependent dispatches.
+//
+// The first version of this stage was k_digits + rocPRIM radix_sort_pairs + k_bounds + rocPRIM exclusive_scan: 14
+// dependent dispatches.  Stand-alone that costs ~0.35 ms at 2^20 pairs, but in a batch it runs BESIDE the previous
+// MSM's accumulate L0, which holds every wave slot and releases them only when a generation of its workgroups
+// retires (every ~0.4 ms): each dependent dispatch waits for such a boundary, the chain outlives L0 and the next
+// L0 starts late (measured with rocprofv3).  The chain here is short enough to finish inside L0:
+//
+//   k_prep_hist     per workgroup, LDS histogram of its entries over P coarse partitions (partition = bucket id
+//                   >> SH, i.e. 2^SH consecutive buckets), then one global atomicAdd per non-empty partition.
+//   k_prep_scan     one workgroup: part_start = exclusive scan of the P partition sizes.
+//   k_prep_scatter  per workgroup: recompute the digits, reserve a contiguous run in every partition it feeds (one
+//                   global atomicAdd per partition), regroup the entries by partition in LDS and write the runs.
+//   k_prep_local    one workgroup per partition: counting sort of the partition by the low SH bits of the bucket id
+//                   with LDS counters, entries go straight to their final position; emits start[], items[] and the
+//                   last-of-bucket flag.  The order of entries INSIDE a bucket is arbitrary (LDS atomics): the bucket
+//                   sum does not depend on it and only canonical affine results are ever compared.
+//   k_prep_offsets  item_off[b] += partials of the partitions before b's; start[B]; zeroed pad entries.
+//
+// Entries with digit 0 are never emitted (the sort used to carry them to the end of the list).  Skewed inputs
+// (all-equal scalars put every entry of a window into ONE bucket) only make one partition large: its
+// workgroup loops over it, nothing overflows.
+#pragma once
+#include "fp.h"
+#include "msm_types.h"
+
+namespace amsm {
+
+struct PrepGeom {
+  u32 SH;   // log2(buckets per partition)
+  u32 P;    // partitions = ceil(B / 2^SH)
+  u32 SPB;  // scalars per workgroup of k_prep_hist / k_prep_scatter (256 lanes x 2)
+  u32 IB;   // bits of a table index (entry word: negate | bucket id low bits << IB | index)
+};
+
+constexpr u32 PREP_ENTRY_LAST = 0x40000000u;  // == ENTRY_LAST of msm_kernels.h
+
+// Calls f(key, value) for every non-zero signed c-bit digit of scalar i; returns non-zero when the scalar does not
+// fit W windows (caller reports AMSM_E_SCALAR_RANGE).  key = bucket id, value = sign | index into the key table.
+template <class Fr, class F>
+AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const MsmGeom& g, u32 i, F&& f) {
+  Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
+  if (mont) s = fe_from_mont<Fr>(s);
+  const u32 c = g.c;
+  const u32 mask = (1u << c) - 1u;
+  const u32 half = 1u << (c - 1);
+  u32 carry = 0;
+  for (u32 w = 0; w < g.W; w++) {
+    u32 raw = (s.v[0] & mask) + carry;
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
+    s.v[7] >>= c;
+    u32 neg = 0;
+    carry = 0;
+    u32 d = raw;
+    if (raw > half) {
+      d = (1u << c) - raw;
+      neg = 1;
+      carry = 1;
+    }
+    if (d != 0) {
+      u32 set = g.precomp ? 0u : w;
+      u32 key = set * g.nb + (d - 1);
+      u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
+      f(key, idx | (neg << 31));
+    }
+  }
+  u32 rest = carry;
+#pragma unroll
+  for (int k = 0; k < 8; k++) rest |= s.v[k];
+  return rest;
+}
+
+// Same walk with the window loop unrolled to MAXW (>= g.W): f(w, key, value) sees w as an unrolled index, so callers
+// can keep per-window state in registers.
+template <class Fr, int MAXW, class F>
+AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont, const MsmGeom& g, u32 i, F&& f) {
+  Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
+  if (mont) s = fe_from_mont<Fr>(s);
+  const u32 c = g.c;
+  const u32 mask = (1u << c) - 1u;
+  const u32 half = 1u << (c - 1);
+  u32 carry = 0;
+#pragma unroll
+  for (int w = 0; w < MAXW; w++) {
+    if ((u32)w < g.W) {
+      u32 raw = (s.v[0] & mask) + carry;
+#pragma unroll
+      for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
+      s.v[7] >>= c;
+      u32 neg = 0;
+      carry = 0;
+      u32 d = raw;
+      if (raw > half) {
+        d = (1u << c) - raw;
+        neg = 1;
+        carry = 1;
+      }
+      if (d != 0) {
+        u32 set = g.precomp ? 0u : (u32)w;
+        u32 key = set * g.nb + (d - 1);
+        u32 idx = g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
+        f(w, key, idx | (neg << 31));
+      }
+    }
+  }
+}
+
+// dynamic LDS: P counters
+template <class Fr>
+__global__ void __launch_bounds__(256)
+    k_prep_hist(const u32* __restrict__ scalars, int mont, MsmGeom g, PrepGeom pg, u32* __restrict__ part_total,
+                u32* __restrict__ err) {
+  extern __shared__ u32 prep_lds[];
+  u32* cnt = prep_lds;
+  for (u32 p = threadIdx.x; p < pg.P; p += blockDim.x) cnt[p] = 0;
+  __syncthreads();
+  u32 bad = 0;
+  for (u32 r = 0; r < pg.SPB; r += blockDim.x) {
+    u32 i = blockIdx.x * pg.SPB + r + threadIdx.x;
+    if (i < g.n) bad |= scalar_entries<Fr>(scalars, mont, g, i, [&](u32 key, u32) { atomicAdd(&cnt[key >> pg.SH], 1u); });
+  }
+  if (bad) atomicOr(err, 1u);
+  __syncthreads();
+  for (u32 p = threadIdx.x; p < pg.P; p += blockDim.x) {
+    u32 v = cnt[p];
+    if (v) atomicAdd(&part_total[p], v);
+  }
+}
+
+// Exclusive scan of n values by ONE workgroup of 1024 lanes (n is at most a few thousand partitions / a few hundred
+// thousand buckets): each lane sums a contiguous slice, the slice sums are scanned through LDS, then the slices are
+// re-walked.  out[n] = total when `with_total`.
+AMSM_DEV void block_exclusive_scan(const u32* __restrict__ in, u32* __restrict__ out, u32 n, bool with_total, u32* lds) {
+  const u32 T = blockDim.x, t = threadIdx.x;
+  u32 per = (n + T - 1) / T;
+  u32 lo = min(t * per, n), hi = min(lo + per, n);
+  u32 sum = 0;
+  for (u32 k = lo; k < hi; k++) sum += in[k];
+  lds[t] = sum;
+  __syncthreads();
+  // Hillis-Steele over T slice sums
+  for (u32 d = 1; d < T; d <<= 1) {
+    u32 v = t >= d ? lds[t - d] : 0u;
+    __syncthreads();
+    lds[t] += v;
+    __syncthreads();
+  }
+  u32 run = lds[t] - sum;  // exclusive prefix of this slice
+  for (u32 k = lo; k < hi; k++) {
+    u32 v = in[k];
+    out[k] = run;
+    run += v;
+  }
+  if (with_total && t == T - 1) out[n] = lds[T - 1];
+}
+
+__global__ void __launch_bounds__(1024) k_prep_scan(const u32* __restrict__ part_total, u32* __restrict__ part_start, u32 P) {
+  __shared__ u32 lds[1024];
+  block_exclusive_scan(part_total, part_start, P, true, lds);
+}
+
+// Entry word inside the partition buffers: bit 31 = negate, bits [IB, IB + SH) = bucket id low bits, bits [0, IB) =
+// table index (IB = PrepGeom::IB; the host checks IB + SH <= 31).
+//
+// k_prep_scatter: a workgroup takes SPB = 512 scalars (2 per lane), ranks every
+// entry inside its partition with an LDS counter, reserves one contiguous run per partition in global memory (one
+// global atomicAdd each), regroups the entries by partition in LDS and copies them out so that consecutive lanes
+// write consecutive words (runs of SPB * W / P entries: 64 B at P = 512).  Scattering word by word instead cost
+// 360 us at 2^20 pairs (33 M partial-line write transactions); staged it is bandwidth bound.
+// dynamic LDS: 3 * P words + SPB * W words (staged entries) + SPB * W half-words (their partition).
+// SPT = scalars per lane (SPB = 256 * SPT), MAXW >= W; SPB * W <= 8192.
+template <class Fr, int MAXW, int SPT>
+__global__ void __launch_bounds__(256)
+    k_prep_scatter(const u32* __restrict__ scalars, int mont, MsmGeom g, PrepGeom pg, const u32* __restrict__ part_start,
+                   u32* __restrict__ part_cursor, u32* __restrict__ part) {
+  extern __shared__ u32 prep_lds[];
+  const u32 cap = pg.SPB * g.W;  // staged entries (upper bound)
+  u32* cnt = prep_lds;           // entries per partition (rank counters in step 1)
+  u32* loff = prep_lds + pg.P;   // block-local exclusive prefix
+  u32* gbase = prep_lds + 2 * pg.P;
+  u32* staged = prep_lds + 3 * pg.P;
+  uint16_t* staged_p = reinterpret_cast<uint16_t*>(staged + cap);
+  const u32 t = threadIdx.x, T = blockDim.x;
+  for (u32 p = t; p < pg.P; p += T) cnt[p] = 0;
+  __syncthreads();
+  // 1. rank every entry inside its partition; the ranks (< SPB * W <= 8192) stay in registers, two per word
+  u32 rk[SPT][MAXW / 2];
+#pragma unroll
+  for (int r = 0; r < SPT; r++) {
+#pragma unroll
+    for (int k = 0; k < MAXW / 2; k++) rk[r][k] = 0;
+    u32 i = blockIdx.x * pg.SPB + r * T + t;
+    if (i < g.n)
+      scalar_entries_unrolled<Fr, MAXW>(scalars, mont, g, i, [&](int w, u32 key, u32) {
+        u32 rank = atomicAdd(&cnt[key >> pg.SH], 1u);
+        rk[r][w >> 1] |= rank << ((w & 1) * 16);
+      });
+  }
+  __syncthreads();
+  // 2. block-local exclusive prefix over partitions (slice per lane + Hillis-Steele over the slice sums) and the
+  //    global run reservation
+  {
+    u32* sl = reinterpret_cast<u32*>(staged);  // scratch: T words, before staging starts
+    u32 per = (pg.P + T - 1) / T;
+    u32 lo = min(t * per, pg.P), hi = min(lo + per, pg.P);
+    u32 sum = 0;
+    for (u32 p = lo; p < hi; p++) sum += cnt[p];
+    sl[t] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < T; d <<= 1) {
+      u32 v = t >= d ? sl[t - d] : 0u;
+      __syncthreads();
+      sl[t] += v;
+      __syncthreads();
+    }
+    u32 run = sl[t] - sum;
+    for (u32 p = lo; p < hi; p++) {
+      u32 v = cnt[p];
+      loff[p] = run;
+      gbase[p] = v ? part_start[p] + atomicAdd(&part_cursor[p], v) : 0u;
+      run += v;
+    }
+  }
+  __syncthreads();
+  // 3. regroup by partition in LDS (the digits are recomputed: cheaper than keeping 2 W entry words in registers)
+  const u32 low = (1u << pg.SH) - 1u;
+#pragma unroll
+  for (int r = 0; r < SPT; r++) {
+    u32 i = blockIdx.x * pg.SPB + r * T + t;
+    if (i < g.n)
+      scalar_entries_unrolled<Fr, MAXW>(scalars, mont, g, i, [&](int w, u32 key, u32 val) {
+        u32 p = key >> pg.SH;
+        u32 rank = (rk[r][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+        u32 slot = loff[p] + rank;
+        staged[slot] = (val & 0x80000000u) | ((key & low) << pg.IB) | (val & 0x7fffffffu);
+        staged_p[slot] = (uint16_t)p;
+      });
+  }
+  __syncthreads();
+  // 4. copy out: consecutive lanes -> consecutive slots -> (mostly) consecutive global words
+  u32 total = loff[pg.P - 1] + cnt[pg.P - 1];
+  for (u32 j = t; j < total; j += T) {
+    u32 p = staged_p[j];
+    part[gbase[p] + (j - loff[p])] = staged[j];
+  }
+}
+
+// One workgroup per partition: counting sort by the bucket id's low bits with LDS counters; entries go straight to
+// their final position.  dynamic LDS: 2 * 2^SH words (per-bucket count -> end, offset -> cursor) + 256 scan words.
+__global__ void __launch_bounds__(256)
+    k_prep_local(const u32* __restrict__ part_start, const u32* __restrict__ part, MsmGeom g, PrepGeom pg,
+                 u32* __restrict__ vals_sorted, u32* __restrict__ start, u32* __restrict__ items, u32* __restrict__ item_off,
+                 u32* __restrict__ part_items) {
+  extern __shared__ u32 prep_lds[];
+  const u32 NB = 1u << pg.SH;
+  u32* cnt = prep_lds;       // entries per bucket of this partition, later the bucket's end offset
+  u32* off = prep_lds + NB;  // exclusive prefix, later the running cursor
+  u32* sl = prep_lds + 2 * NB;
+  const u32 p = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  const u32 ps = part_start[p], pe = part_start[p + 1];
+  const u32 low = NB - 1u, idx_mask = (1u << pg.IB) - 1u;
+  for (u32 k = t; k < NB; k += T) cnt[k] = 0;
+  __syncthreads();
+  for (u32 j = ps + t; j < pe; j += T) atomicAdd(&cnt[(part[j] >> pg.IB) & low], 1u);
+  __syncthreads();
+  const u32 b0 = p << pg.SH;
+  // exclusive prefix of the bucket sizes (entries) and of the bucket chunk counts (partials), lane t owns a slice
+  u32 per = (NB + T - 1) / T;
+  u32 lo_k = min(t * per, NB), hi_k = min(lo_k + per, NB);
+  u32 sum = 0;
+  for (u32 k = lo_k; k < hi_k; k++) sum += cnt[k];
+  sl[t] = sum;
+  __syncthreads();
+  for (u32 d = 1; d < T; d <<= 1) {
+    u32 v = t >= d ? sl[t - d] : 0u;
+    __syncthreads();
+    sl[t] += v;
+    __syncthreads();
+  }
+  u32 run = sl[t] - sum;
+  u32 my_items = 0;
+  for (u32 k = lo_k; k < hi_k; k++) {
+    u32 c = cnt[k];
+    off[k] = run;
+    u32 lo = ps + run, hi = lo + c;
+    u32 it = c ? (hi - 1) / g.K0 - lo / g.K0 + 1 : 0u;
+    if (b0 + k < g.B) {
+      start[b0 + k] = lo;  // also for empty buckets: where the bucket would start
+      items[b0 + k] = it;
+    }
+    cnt[k] = run + c;  // end offset of the bucket inside the partition
+    my_items += it;
+    run += c;
+  }
+  __syncthreads();
+  // exclusive prefix of the chunk counts inside the partition (k_prep_offsets adds the partitions before it)
+  sl[t] = my_items;
+  __syncthreads();
+  for (u32 d = 1; d < T; d <<= 1) {
+    u32 v = t >= d ? sl[t - d] : 0u;
+    __syncthreads();
+    sl[t] += v;
+    __syncthreads();
+  }
+  u32 irun = sl[t] - my_items;
+  for (u32 k = lo_k; k < hi_k; k++) {
+    if (b0 + k < g.B) {
+      item_off[b0 + k] = irun;
+      irun += items[b0 + k];  // own write, same lane
+    }
+  }
+  if (t == T - 1) part_items[p] = sl[T - 1];
+  __syncthreads();
+  // final placement; the entry that lands on the last position of its bucket carries the flag
+  for (u32 j = ps + t; j < pe; j += T) {
+    u32 e = part[j];
+    u32 k = (e >> pg.IB) & low;
+    u32 pos = atomicAdd(&off[k], 1u);
+    u32 v = (e & 0x80000000u) | (e & idx_mask);
+    if (pos + 1 == cnt[k]) v |= PREP_ENTRY_LAST;
+    vals_sorted[ps + pos] = v;
+  }
+}
+
+// item_off[b] += partials of the partitions before b's; closes start[] / items[] / item_off[] at index B and zeroes
+// the entries accumulate L0 may prefetch past the end of the list.  dynamic LDS: P + 256 words.
+__global__ void __launch_bounds__(256)
+    k_prep_offsets(const u32* __restrict__ part_start, const u32* __restrict__ part_items, PrepGeom pg, MsmGeom g,
+                   u32* __restrict__ start, u32* __restrict__ items, u32* __restrict__ item_off, u32* __restrict__ vals_sorted) {
+  extern __shared__ u32 prep_lds[];
+  u32* pref = prep_lds;  // exclusive prefix of part_items
+  u32* sl = prep_lds + pg.P;
+  const u32 t = threadIdx.x, T = blockDim.x;
+  u32 per = (pg.P + T - 1) / T;
+  u32 lo = min(t * per, pg.P), hi = min(lo + per, pg.P);
+  u32 sum = 0;
+  for (u32 p = lo; p < hi; p++) sum += part_items[p];
+  sl[t] = sum;
+  __syncthreads();
+  for (u32 d = 1; d < T; d <<= 1) {
+    u32 v = t >= d ? sl[t - d] : 0u;
+    __syncthreads();
+    sl[t] += v;
+    __syncthreads();
+  }
+  u32 run = sl[t] - sum;
+  for (u32 p = lo; p < hi; p++) {
+    pref[p] = run;
+    run += part_items[p];
+  }
+  __syncthreads();
+  u32 b = blockIdx.x * T + t;
+  if (b < g.B) item_off[b] += pref[b >> pg.SH];
+  if (blockIdx.x == 0) {
+    const u32 e_valid = part_start[pg.P];
+    if (t == 0) {
+      start[g.B] = e_valid;  // entries with a non-zero digit
+      items[g.B] = 0;
+      item_off[g.B] = sl[T - 1];  // total number of partials
+    }
+    // accumulate L0 reads entries in groups of 4 up to the group holding entry E - 1 and prefetches the point of
+    // every entry it reads: everything between the last real entry and that group's end must be a valid index
+    const u32 pad_end = ((g.E + 3u) & ~3u);
+    for (u32 k = e_valid + t; k < pad_end; k += T) vals_sorted[k] = 0;
+  }
+}
+
+}  // namespace amsm
