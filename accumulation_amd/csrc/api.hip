@@ -224,13 +224,13 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   if (ctx->K0 > 0) {
     g.K0 = (u32)ctx->K0;
   } else {
-    // <= 32 entries per lane per round of resident waves, rounds equalised: measured best on MI355X for batches of
-    // MSMs (tools/ab_pipeline.py, 2^20 Pallas: K0 = 32 -> 703, 24 -> 700, 44 -> 695, 64 -> 690, 16 -> 634
-    // Mpairs/s): shorter chunks let the other MSMs' prep / tail kernels in sooner, longer ones halve the partials
+    // <= 24 entries per lane per round of resident waves, rounds equalised: measured best on MI355X for batches of
+    // MSMs (tools/ab_pipeline.py, 2^20 Pallas: K0 = 24 -> 761-769, 32 -> 749, 20 -> 750, 44 -> 727, 64 -> 715
+    // Mpairs/s): shorter chunks let the other MSMs' prep / tail kernels in sooner, longer ones save partials
     unsigned long long lanes = (unsigned long long)ctx->wave_slots * 64ull;
-    unsigned long long rounds = (g.E + lanes * 32ull - 1) / (lanes * 32ull);
+    unsigned long long rounds = (g.E + lanes * 24ull - 1) / (lanes * 24ull);
     unsigned long long k = (g.E + lanes * rounds - 1) / (lanes * rounds);
-    g.K0 = (u32)std::min<unsigned long long>(std::max<unsigned long long>(k, 16ull), 32ull);
+    g.K0 = (u32)std::min<unsigned long long>(std::max<unsigned long long>(k, 16ull), 24ull);
   }
   g.K0 = (g.K0 + 3u) & ~3u;  // accumulate L0 reads entries in groups of 4
   g.K1 = (u32)ctx->K1;

@@ -63,13 +63,13 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
                        part_total, b.err);                                                                           \
     hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P);                       \
     if (g.W <= 16u)                                                                                                  \
-      hipLaunchKernelGGL((k_prep_scatter<FR, 16, 2>), dim3(blocks), dim3(256), lds_scatter, st, scalars, mont, g, pg, \
+      hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1>), dim3(blocks), dim3(512), lds_scatter, st, scalars, mont, g, pg, \
                          part_start, part_cursor, b.part);                                                           \
     else                                                                                                             \
       hipLaunchKernelGGL((k_prep_scatter<FR, 32, 1>), dim3(blocks), dim3(256), lds_scatter, st, scalars, mont, g, pg, \
                          part_start, part_cursor, b.part);                                                           \
-    hipLaunchKernelGGL(k_prep_local, dim3(pg.P), dim3(256), (2 * (1u << pg.SH) + 256) * sizeof(u32), st, part_start, \
-                       b.part, g, pg, b.vals_sorted, b.start, b.items, b.item_off, part_items);                      \
+    hipLaunchKernelGGL(k_prep_local, dim3(pg.P), dim3(1024), (2 * (1u << pg.SH) + 1024) * sizeof(u32), st,           \
+                       part_start, b.part, g, pg, b.vals_sorted, b.start, b.items, b.item_off, part_items);          \
     hipLaunchKernelGGL(k_prep_offsets, dim3(cdiv_(g.B, 256)), dim3(256), (pg.P + 256) * sizeof(u32), st, part_start, \
                        part_items, pg, g, b.start, b.items, b.item_off, b.vals_sorted);                              \
     return 0;                                                                                                        \

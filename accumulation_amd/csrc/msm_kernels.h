@@ -41,6 +41,7 @@ namespace amsm {
 // (`global_load_lds_dwordx4`), 16 bytes per lane, lanes arranged so that a point's 64/96 bytes are read by
 // ADJACENT lanes of ONE wave-instruction: one memory request per point instead of one per 16-byte piece
 // (4-6x fewer L2/HBM requests than each lane loading its own point with dwordx4s; measured in DESIGN.md).
+// Two regions per wave alternate, so a gather has two mixed additions (~8 us) to land.
 // The LDS image is lane-linear (DMA writes base + lane*16): byte o of the wave's region belongs to point
 // o / PB, so lane l then reads its own point back with ds_read_b128s.  One region per wave, no barrier.
 template <class Fq>
@@ -82,9 +83,11 @@ template <class Fq>
 __global__ void __launch_bounds__(256)
     k_accum_l0(const u32* __restrict__ table, const u32* __restrict__ vals_sorted, const u32* __restrict__ start,
                const u32* __restrict__ item_off, MsmGeom g, u32* __restrict__ partials) {
-  __shared__ __attribute__((aligned(16))) u32 lds[4 * GatherLds<Fq>::WAVE_BYTES / 4];
+  // two gather regions per wave: the points of mixed addition i+2 are fetched while i and i+1 are computed
+  __shared__ __attribute__((aligned(16))) u32 lds[2 * 4 * GatherLds<Fq>::WAVE_BYTES / 4];
   const u32 lane = threadIdx.x & 63u;
-  u32* lds_wave = lds + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (GatherLds<Fq>::WAVE_BYTES / 4);
+  u32* lds_wave0 = lds + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (2 * GatherLds<Fq>::WAVE_BYTES / 4);
+  u32* lds_wave1 = lds_wave0 + GatherLds<Fq>::WAVE_BYTES / 4;
   u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   u32 e_valid = start[g.B];  // entries with a non-zero digit (key B = digit 0 sorts last)
   u32 s = c * g.K0;          // K0 is a multiple of 4: every lane's chunk is a 16-byte aligned run of entries
@@ -107,19 +110,23 @@ __global__ void __launch_bounds__(256)
     b_cur = lo;
   }
   XYZZ<Fq> acc = xyzz_inf<Fq>();
-  gather_issue<Fq>(table, cur.x & ENTRY_IDX, lds_wave, lane);
+  gather_issue<Fq>(table, cur.x & ENTRY_IDX, lds_wave0, lane);
+  gather_issue<Fq>(table, cur.y & ENTRY_IDX, lds_wave1, lane);
   for (u32 grp = 0; grp < g.K0; grp += 4) {
     uint4 nn = v4[min(s + grp + 8, last_grp) / 4];
-    u32 w[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+    u32 w[6] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       u32 k = s + grp + i;
-      // the DMA of this iteration's points was issued one mixed addition ago; hipcc does not track it, so
-      // wait explicitly, then pull the own point into registers before the region is refilled
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      Affine<Fq> pt = gather_read<Fq>(lds_wave, lane);
+      u32* region = (i & 1) ? lds_wave1 : lds_wave0;  // grp is a multiple of 4: entry parity = i parity
+      // The DMA of this iteration's points was issued two mixed additions ago; hipcc does not track it, so wait
+      // explicitly: memory operations retire in order, so "at most the N_INSTR newest outstanding" (the gather of
+      // the next iteration) means this one has landed.  Then pull the own point into registers and refill the region.
+      if (GatherLds<Fq>::N_INSTR == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      Affine<Fq> pt = gather_read<Fq>(region, lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      gather_issue<Fq>(table, w[i + 1] & ENTRY_IDX, lds_wave, lane);
+      gather_issue<Fq>(table, w[i + 2] & ENTRY_IDX, region, lane);
       if (k < e) {
         u32 v = w[i];
         xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (v & ENTRY_NEG) != 0));

@@ -163,15 +163,15 @@ __global__ void __launch_bounds__(1024) k_prep_scan(const u32* __restrict__ part
 // Entry word inside the partition buffers: bit 31 = negate, bits [IB, IB + SH) = bucket id low bits, bits [0, IB) =
 // table index (IB = PrepGeom::IB; the host checks IB + SH <= 31).
 //
-// k_prep_scatter: a workgroup takes SPB = 512 scalars (2 per lane), ranks every
+// k_prep_scatter: a workgroup takes SPB = 512 scalars (one per lane), ranks every
 // entry inside its partition with an LDS counter, reserves one contiguous run per partition in global memory (one
 // global atomicAdd each), regroups the entries by partition in LDS and copies them out so that consecutive lanes
 // write consecutive words (runs of SPB * W / P entries: 64 B at P = 512).  Scattering word by word instead cost
 // 360 us at 2^20 pairs (33 M partial-line write transactions); staged it is bandwidth bound.
 // dynamic LDS: 3 * P words + SPB * W words (staged entries) + SPB * W half-words (their partition).
-// SPT = scalars per lane (SPB = 256 * SPT), MAXW >= W; SPB * W <= 8192.
+// SPT = scalars per lane (SPB = blockDim * SPT), MAXW >= W; SPB * W <= 8192.
 template <class Fr, int MAXW, int SPT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
     k_prep_scatter(const u32* __restrict__ scalars, int mont, MsmGeom g, PrepGeom pg, const u32* __restrict__ part_start,
                    u32* __restrict__ part_cursor, u32* __restrict__ part) {
   extern __shared__ u32 prep_lds[];
@@ -246,9 +246,10 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// One workgroup per partition: counting sort by the bucket id's low bits with LDS counters; entries go straight to
-// their final position.  dynamic LDS: 2 * 2^SH words (per-bucket count -> end, offset -> cursor) + 256 scan words.
-__global__ void __launch_bounds__(256)
+// One workgroup (1024 lanes: a partition is ~32 k entries and there are only ~512 of them) per partition: counting
+// sort by the bucket id's low bits with LDS counters; entries go straight to their final position.
+// dynamic LDS: 2 * 2^SH words (per-bucket count -> end, offset -> cursor) + blockDim scan words.
+__global__ void __launch_bounds__(1024)
     k_prep_local(const u32* __restrict__ part_start, const u32* __restrict__ part, MsmGeom g, PrepGeom pg,
                  u32* __restrict__ vals_sorted, u32* __restrict__ start, u32* __restrict__ items, u32* __restrict__ item_off,
                  u32* __restrict__ part_items) {
