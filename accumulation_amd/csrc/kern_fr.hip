@@ -59,8 +59,12 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
     u32 blocks = cdiv_(g.n, pg.SPB);                                                                                 \
     u32 cap = pg.SPB * g.W;                                                                                          \
     size_t lds_scatter = (3 * pg.P + cap) * sizeof(u32) + cap * sizeof(uint16_t);                                    \
-    hipLaunchKernelGGL((k_prep_hist<FR>), dim3(blocks), dim3(256), pg.P * sizeof(u32), st, scalars, mont, g, pg,      \
-                       part_total, b.err);                                                                           \
+    {  /* the histogram's blocking is independent of the scatter's: 1024 scalars, one per lane */                    \
+      PrepGeom ph = pg;                                                                                              \
+      ph.SPB = 1024;                                                                                                 \
+      hipLaunchKernelGGL((k_prep_hist<FR>), dim3(cdiv_(g.n, 1024)), dim3(1024), pg.P * sizeof(u32), st, scalars,      \
+                         mont, g, ph, part_total, b.err);                                                            \
+    }                                                                                                                \
     hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P);                       \
     if (g.W <= 16u)                                                                                                  \
       hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1>), dim3(blocks), dim3(512), lds_scatter, st, scalars, mont, g, pg, \

@@ -108,7 +108,7 @@ AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont,
 
 // dynamic LDS: P counters
 template <class Fr>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
     k_prep_hist(const u32* __restrict__ scalars, int mont, MsmGeom g, PrepGeom pg, u32* __restrict__ part_total,
                 u32* __restrict__ err) {
   extern __shared__ u32 prep_lds[];

@@ -105,6 +105,13 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or python -m accumulation_amd.build)")
+    # PyTorch ships its own copy of the HIP runtime (same soname as /opt/rocm's): whichever is loaded first serves
+    # both, and torch only finds its GPUs through its own.  Load torch's first when torch is installed, so that
+    # device tensors (RCCL all-gather buffers of dist.py) and this library can live in one process in either order.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
