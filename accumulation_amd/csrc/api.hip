@@ -40,7 +40,7 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   hipEvent_t ev[ST_COUNT + 1] = {};
   hipEvent_t done = nullptr;
   DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
-      sort_tmp, scan_tmp, prep_small;
+      sort_tmp, scan_tmp, prep_small, heavy_scratch;
   void* h_pinned = nullptr;
   size_t h_pinned_bytes = 0;
   MsmGeom geom = {};
@@ -137,14 +137,26 @@ inline int ilog2_ceil(size_t n) {
   return l;
 }
 
-// Window width.  Precomputed key: all windows share one bucket set, aim for a few hundred entries per
-// bucket.  Plain key: one bucket set per window, aim for >= ~128 entries per bucket.
+// Window width.  Measured on MI355X (build/sweep_c.py, Pallas, batches of MSMs), not derived: a width whose TOP
+// window holds only 2-3 scalar bits (255 mod c small: c = 9, 11, 12, 14, 18, 19) concentrates 2^-3 of all entries of
+// that window in a handful of buckets, which then take the heavy-bucket path; c = 8, 10, 13, 15, 16 do not.
+//   precomputed key (all windows share one bucket set): 2^10-2^12 -> 8, 2^13-2^14 -> 10, 2^15 -> 13, 2^16 -> 15,
+//   >= 2^17 -> 16 (2^18: 518 vs 361 Mpairs/s at the old lg-4 rule; 2^22: 774 vs 440).
+//   plain key (one bucket set per window): lg - 6 moved to the nearest width of that list.
 int choose_window(size_t n, bool precomp) {
   int lg = ilog2_ceil(n < 2 ? 2 : n);
-  int c = precomp ? lg - 4 : lg - 6;
+  if (precomp) {
+    if (lg >= 17) return 16;
+    if (lg == 16) return 15;
+    if (lg == 15) return 13;
+    if (lg >= 13) return 10;
+    return 8;
+  }
+  int c = lg - 6;
   if (c < 4) c = 4;
-  if (c > 20) c = 20;
-  return c;
+  if (c > 16) c = 16;
+  static const int good[13] = {4, 5, 6, 7, 8, 8, 10, 10, 10, 13, 13, 15, 16};  // index c - 4
+  return good[c - 4];
 }
 inline int windows_for(int c) { return 255 / c + 1; }  // W*c >= 256 (signed digits need one spare bit)
 
@@ -294,6 +306,8 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   TRY(ensure(sl->red_out, (size_t)g.n_sets * red_blocks * xyzz_bytes<Fq>()));
   TRY(ensure(sl->fold_out, (size_t)g.n_sets * xyzz_bytes<Fq>()));
   TRY(ensure(sl->heavy, (size_t)(g.B + 1) * 4));
+  // at most max_items / K1 buckets can hold more than K1 partials each
+  TRY(ensure(sl->heavy_scratch, ((size_t)max_items / std::max<u32>(g.K1, 1u) + 2) * accum_l2_slices<Fq>() * xyzz_bytes<Fq>()));
   TRY(ensure(sl->misc, 64));
   size_t rec = xyzz_bytes<Fq>();
   TRY(ensure_pinned(sl, g.n_sets * rec + 64));
@@ -370,7 +384,8 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
                       g, (u32*)sl->buckets.p, d_heavy_count, (u32*)sl->heavy.p);
   AMSM_DBG("l1");
   launch_accum_l2<Fq>(tl, (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
-                      (const u32*)d_heavy_count, (const u32*)sl->heavy.p, (u32*)sl->buckets.p);
+                      (const u32*)d_heavy_count, (const u32*)sl->heavy.p, (u32*)sl->heavy_scratch.p,
+                      (u32*)sl->buckets.p);
   AMSM_DBG("l2");
   if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_REDUCE], tl);
   launch_bucket_reduce<Fq>(tl, red_blocks, (const u32*)sl->buckets.p, g, (u32*)sl->red_out.p);
@@ -951,7 +966,7 @@ void amsm_ctx_destroy(amsm_ctx* c) {
     Slot* sl = &c->slot[k];
     DevBuf* bufs[] = {&sl->keys_a, &sl->keys_b, &sl->vals_a, &sl->vals_b, &sl->start, &sl->items, &sl->item_off,
                       &sl->partials, &sl->buckets, &sl->red_out, &sl->fold_out, &sl->heavy, &sl->misc, &sl->sort_tmp,
-                      &sl->scan_tmp, &sl->prep_small};
+                      &sl->scan_tmp, &sl->prep_small, &sl->heavy_scratch};
     for (DevBuf* b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (sl->h_pinned) (void)hipHostFree(sl->h_pinned);

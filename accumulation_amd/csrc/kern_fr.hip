@@ -33,6 +33,9 @@ static PrepGeom prep_geom(const MsmGeom& g) {
                                (g.precomp ? (unsigned long long)(g.W - 1u) * g.table_stride : 0ull);
   pg.IB = 1;
   while ((max_idx >> pg.IB) != 0ull) pg.IB++;
+  // the entry word has 31 bits for index + bucket-id low bits: trade partition size for partitions when it is tight
+  while (pg.IB + pg.SH > 31u && pg.SH > 0u && ((g.B + (1u << (pg.SH - 1)) - 1u) >> (pg.SH - 1)) <= PREP_MAX_P) pg.SH--;
+  pg.P = (g.B + (1u << pg.SH) - 1u) >> pg.SH;
   return pg;
 }
 bool prep_supported(const MsmGeom& g) {

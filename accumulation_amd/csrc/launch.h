@@ -19,7 +19,9 @@ void launch_accum_l1(hipStream_t st, u32 lanes_per_bucket, const u32* partials, 
                      u32* buckets, u32* heavy_count, u32* heavy_list);
 template <class Fq>
 void launch_accum_l2(hipStream_t st, const u32* partials, const u32* items, const u32* item_off,
-                     const u32* heavy_count, const u32* heavy_list, u32* buckets);
+                     const u32* heavy_count, const u32* heavy_list, u32* scratch, u32* buckets);
+template <class Fq>
+u32 accum_l2_slices();  // scratch records per heavy bucket
 template <class Fq>
 void launch_bucket_reduce(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* out);
 template <class Fq>

@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(256)
   u32* lds_wave0 = lds + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (2 * GatherLds<Fq>::WAVE_BYTES / 4);
   u32* lds_wave1 = lds_wave0 + GatherLds<Fq>::WAVE_BYTES / 4;
   u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 e_valid = start[g.B];  // entries with a non-zero digit (key B = digit 0 sorts last)
+  u32 e_valid = start[g.B];  // entries with a non-zero digit
+  if (blockIdx.x * blockDim.x * g.K0 >= e_valid) return;  // the grid is sized for n*W entries; zero digits emit none
   u32 s = c * g.K0;          // K0 is a multiple of 4: every lane's chunk is a 16-byte aligned run of entries
   u32 e = min(s + g.K0, e_valid);
   // every lane runs all K0 iterations (the gather is cooperative); lanes past their range replay a valid
@@ -228,24 +229,44 @@ AMSM_DEV void block_reduce_xyzz(XYZZ<Fq>& acc, u32* lds) {
   }
 }
 
-// accumulate L2: one workgroup per heavy bucket (grid-stride over the heavy list).
+// accumulate L2: heavy buckets (more than K1 partials: skewed digit distributions) in two steps so that
+// the sequential chain per lane stays short whatever the skew: (a) L2_SLICES workgroups per heavy bucket each sum a
+// slice of its partials (lane-strided sums, wave shuffles, LDS) into a scratch record, (b) one wave per heavy bucket
+// folds the L2_SLICES records.  A single workgroup per bucket cost 3.8 ms for the 16 buckets of an all-equal 2^20
+// vector (172 dependent additions per lane).
+constexpr u32 L2_SLICES = 32;
 template <class Fq>
 __global__ void __launch_bounds__(256)
-    k_accum_l2(const u32* __restrict__ partials, const u32* __restrict__ items, const u32* __restrict__ item_off,
-               const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list, u32* __restrict__ buckets) {
+    k_accum_l2a(const u32* __restrict__ partials, const u32* __restrict__ items, const u32* __restrict__ item_off,
+                const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list, u32* __restrict__ scratch) {
   __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
   u32 nh = *heavy_count;
-  for (u32 h = blockIdx.x; h < nh; h += gridDim.x) {
+  const u32 sidx = blockIdx.x;  // slice
+  for (u32 h = blockIdx.y; h < nh; h += gridDim.y) {
     u32 b = heavy_list[h];
     u32 n = items[b], off = item_off[b];
+    u32 per = (n + L2_SLICES - 1) / L2_SLICES;
+    u32 lo = min(sidx * per, n), hi = min(lo + per, n);
     XYZZ<Fq> acc = xyzz_inf<Fq>();
-    for (u32 k = threadIdx.x; k < n; k += blockDim.x) {
+    for (u32 k = lo + threadIdx.x; k < hi; k += blockDim.x) {
       XYZZ<Fq> p = xyzz_load<Fq>(partials, off + k);
       xyzz_add<Fq>(acc, p);
     }
     block_reduce_xyzz<Fq>(acc, lds);
-    if (threadIdx.x == 0) xyzz_store<Fq>(buckets, b, acc);
+    if (threadIdx.x == 0) xyzz_store<Fq>(scratch, (size_t)h * L2_SLICES + sidx, acc);
     __syncthreads();
+  }
+}
+template <class Fq>
+__global__ void __launch_bounds__(64)
+    k_accum_l2b(const u32* __restrict__ scratch, const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
+                u32* __restrict__ buckets) {
+  u32 nh = *heavy_count;
+  for (u32 h = blockIdx.x; h < nh; h += gridDim.x) {
+    XYZZ<Fq> acc = xyzz_inf<Fq>();
+    if (threadIdx.x < L2_SLICES) acc = xyzz_load<Fq>(scratch, (size_t)h * L2_SLICES + threadIdx.x);
+    wave_reduce_xyzz<Fq>(acc);
+    if (threadIdx.x == 0) xyzz_store<Fq>(buckets, heavy_list[h], acc);
   }
 }
 

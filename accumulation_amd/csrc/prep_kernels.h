@@ -35,6 +35,24 @@ struct PrepGeom {
 
 constexpr u32 PREP_ENTRY_LAST = 0x40000000u;  // == ENTRY_LAST of msm_kernels.h
 
+// ctr[idx]++ on an LDS counter, returning the old value.  When every active lane of the wave hits the SAME counter
+// (skewed digit distributions -- the all-equal vectors of SURVEY.md F8 -- make that the common case) one lane adds
+// the wave's population instead of 64 serialized same-address atomics.
+AMSM_DEV u32 lds_count(u32* ctr, u32 idx) {
+  const u64 active = __ballot(1);
+  const u32 first = __builtin_amdgcn_readfirstlane(idx);
+  const u64 same = __ballot(idx == first);
+  if (same == active) {
+    const u32 lane = __lane_id();
+    const u32 below = (u32)__popcll(same & ((1ull << lane) - 1ull));
+    u32 base = 0;
+    if (below == 0) base = atomicAdd(&ctr[first], (u32)__popcll(same));
+    base = __builtin_amdgcn_readfirstlane(base);  // the first active lane is the one that did the add
+    return base + below;
+  }
+  return atomicAdd(&ctr[idx], 1u);
+}
+
 // Calls f(key, value) for every non-zero signed c-bit digit of scalar i; returns non-zero when the scalar does not
 // fit W windows (caller reports AMSM_E_SCALAR_RANGE).  key = bucket id, value = sign | index into the key table.
 template <class Fr, class F>
@@ -118,7 +136,7 @@ __global__ void __launch_bounds__(1024)
   u32 bad = 0;
   for (u32 r = 0; r < pg.SPB; r += blockDim.x) {
     u32 i = blockIdx.x * pg.SPB + r + threadIdx.x;
-    if (i < g.n) bad |= scalar_entries<Fr>(scalars, mont, g, i, [&](u32 key, u32) { atomicAdd(&cnt[key >> pg.SH], 1u); });
+    if (i < g.n) bad |= scalar_entries<Fr>(scalars, mont, g, i, [&](u32 key, u32) { lds_count(cnt, key >> pg.SH); });
   }
   if (bad) atomicOr(err, 1u);
   __syncthreads();
@@ -193,7 +211,7 @@ __global__ void __launch_bounds__(512)
     u32 i = blockIdx.x * pg.SPB + r * T + t;
     if (i < g.n)
       scalar_entries_unrolled<Fr, MAXW>(scalars, mont, g, i, [&](int w, u32 key, u32) {
-        u32 rank = atomicAdd(&cnt[key >> pg.SH], 1u);
+        u32 rank = lds_count(cnt, key >> pg.SH);
         rk[r][w >> 1] |= rank << ((w & 1) * 16);
       });
   }
@@ -263,7 +281,18 @@ __global__ void __launch_bounds__(1024)
   const u32 low = NB - 1u, idx_mask = (1u << pg.IB) - 1u;
   for (u32 k = t; k < NB; k += T) cnt[k] = 0;
   __syncthreads();
-  for (u32 j = ps + t; j < pe; j += T) atomicAdd(&cnt[(part[j] >> pg.IB) & low], 1u);
+  // entries are read four at a time once the partition is long enough to care (skewed inputs make partitions of
+  // millions of entries; one workgroup still owns each): head up to 16-byte alignment, uint4 body, tail
+  const u32 body_lo = min((ps + 3u) & ~3u, pe), body_hi = max(body_lo, pe & ~3u);
+  for (u32 j = ps + t; j < body_lo; j += T) lds_count(cnt, (part[j] >> pg.IB) & low);
+  for (u32 j = body_lo + 4u * t; j < body_hi; j += 4u * T) {
+    uint4 e4 = *reinterpret_cast<const uint4*>(part + j);
+    lds_count(cnt, (e4.x >> pg.IB) & low);
+    lds_count(cnt, (e4.y >> pg.IB) & low);
+    lds_count(cnt, (e4.z >> pg.IB) & low);
+    lds_count(cnt, (e4.w >> pg.IB) & low);
+  }
+  for (u32 j = body_hi + t; j < pe; j += T) lds_count(cnt, (part[j] >> pg.IB) & low);
   __syncthreads();
   const u32 b0 = p << pg.SH;
   // exclusive prefix of the bucket sizes (entries) and of the bucket chunk counts (partials), lane t owns a slice
@@ -314,14 +343,22 @@ __global__ void __launch_bounds__(1024)
   if (t == T - 1) part_items[p] = sl[T - 1];
   __syncthreads();
   // final placement; the entry that lands on the last position of its bucket carries the flag
-  for (u32 j = ps + t; j < pe; j += T) {
-    u32 e = part[j];
+  auto place = [&](u32 e) {
     u32 k = (e >> pg.IB) & low;
-    u32 pos = atomicAdd(&off[k], 1u);
+    u32 pos = lds_count(off, k);
     u32 v = (e & 0x80000000u) | (e & idx_mask);
     if (pos + 1 == cnt[k]) v |= PREP_ENTRY_LAST;
     vals_sorted[ps + pos] = v;
+  };
+  for (u32 j = ps + t; j < body_lo; j += T) place(part[j]);
+  for (u32 j = body_lo + 4u * t; j < body_hi; j += 4u * T) {
+    uint4 e4 = *reinterpret_cast<const uint4*>(part + j);
+    place(e4.x);
+    place(e4.y);
+    place(e4.z);
+    place(e4.w);
   }
+  for (u32 j = body_hi + t; j < pe; j += T) place(part[j]);
 }
 
 // item_off[b] += partials of the partitions before b's; closes start[] / items[] / item_off[] at index B and zeroes
@@ -360,9 +397,12 @@ __global__ void __launch_bounds__(256)
       items[g.B] = 0;
       item_off[g.B] = sl[T - 1];  // total number of partials
     }
-    // accumulate L0 reads entries in groups of 4 up to the group holding entry E - 1 and prefetches the point of
-    // every entry it reads: everything between the last real entry and that group's end must be a valid index
-    const u32 pad_end = ((g.E + 3u) & ~3u);
+    // accumulate L0 reads entries in groups of 4 and prefetches the point of every entry it reads; its last active
+    // workgroup covers entries up to the next multiple of 256 * K0 past e_valid (plus two groups of look-ahead), clamped
+    // to the group holding entry E - 1: everything in that range past the real entries must be a valid table index
+    const u32 span = 256u * g.K0;
+    unsigned long long reach = ((unsigned long long)(e_valid / span) + 1ull) * span + 16ull;
+    const u32 pad_end = (u32)min(reach, (unsigned long long)((g.E + 3u) & ~3u));
     for (u32 k = e_valid + t; k < pad_end; k += T) vals_sorted[k] = 0;
   }
 }

@@ -25,7 +25,7 @@ def emit(**kw):
     print(json.dumps(kw), flush=True)
 
 
-def bench_msm(curve, log2n, reps=12):
+def bench_msm(curve, log2n, reps=40):
     ctx = Context(curve)
     n = 1 << log2n
     t0 = time.time()
