@@ -137,7 +137,7 @@ inline int ilog2_ceil(size_t n) {
   return l;
 }
 
-// Window width.  Measured on MI355X (build/sweep_c.py, Pallas, batches of MSMs), not derived: a width whose TOP
+// Window width.  Measured on MI355X (tools/sweep_window.py, Pallas, batches of MSMs), not derived: a width whose TOP
 // window holds only 2-3 scalar bits (255 mod c small: c = 9, 11, 12, 14, 18, 19) concentrates 2^-3 of all entries of
 // that window in a handful of buckets, which then take the heavy-bucket path; c = 8, 10, 13, 15, 16 do not.
 //   precomputed key (all windows share one bucket set): 2^10-2^12 -> 8, 2^13-2^14 -> 10, 2^15 -> 13, 2^16 -> 15,
