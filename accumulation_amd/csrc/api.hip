@@ -455,31 +455,51 @@ int msm_device_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, con
   return rc;
 }
 
-// n_vecs MSMs over the same key, N_SLOTS in flight (slot 0 heads run on the context's stream).
+// k MSMs over (windows of) the same key, N_SLOTS in flight on the per-stage streams.  MSM v uses generators
+// [offs[v], offs[v] + ns[v]) and the scalars at d_scalars[v].
 template <class Fq, class Fr>
-int msm_batch_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* const* d_scalars,
-                   size_t n_vecs, size_t n, int scalars_mont, std::vector<host::HXYZZ<Fq>>* out) {
-  if (base_off > bases->n) return AMSM_E_INVALID_ARG;
-  n = std::min(n, bases->n - base_off);
-  out->assign(n_vecs, host::hx_inf<Fq>());
-  if (n == 0 || n_vecs == 0) return AMSM_OK;
+int msm_multi_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t k, const size_t* offs, const void* const* d_scalars,
+                   const size_t* ns, int scalars_mont, std::vector<host::HXYZZ<Fq>>* out) {
+  out->assign(k, host::hx_inf<Fq>());
+  std::vector<size_t> len(k);
+  for (size_t v = 0; v < k; v++) {
+    if (offs[v] > bases->n) return AMSM_E_INVALID_ARG;
+    len[v] = std::min(ns[v], bases->n - offs[v]);
+  }
+  if (k == 0) return AMSM_OK;
   stage_begin(ctx);
   TRY(prep_fork(ctx));
   int rc = AMSM_OK;
-  for (size_t v = 0; v < n_vecs && rc == AMSM_OK; v++) {
-    Slot* sl = &ctx->slot[v % N_SLOTS];
-    if (sl->busy) rc = msm_collect<Fq>(ctx, sl, &(*out)[v - N_SLOTS]);
-    if (rc == AMSM_OK) rc = msm_enqueue<Fq, Fr>(ctx, sl, bases, base_off, d_scalars[v], n, scalars_mont);
+  std::vector<long> owner(N_SLOTS, -1);  // which MSM a busy slot carries
+  size_t slot_rr = 0;
+  for (size_t v = 0; v < k && rc == AMSM_OK; v++) {
+    if (len[v] == 0) continue;  // identity
+    Slot* sl = &ctx->slot[slot_rr % N_SLOTS];
+    if (sl->busy) rc = msm_collect<Fq>(ctx, sl, &(*out)[owner[slot_rr % N_SLOTS]]);
+    if (rc == AMSM_OK) {
+      rc = msm_enqueue<Fq, Fr>(ctx, sl, bases, offs[v], d_scalars[v], len[v], scalars_mont);
+      owner[slot_rr % N_SLOTS] = (long)v;
+      slot_rr++;
+    }
   }
-  for (size_t v = (n_vecs >= (size_t)N_SLOTS ? n_vecs - N_SLOTS : 0); v < n_vecs; v++) {
-    Slot* sl = &ctx->slot[v % N_SLOTS];
+  for (int j = 0; j < N_SLOTS; j++) {  // drain in enqueue order
+    size_t s = (slot_rr + j) % N_SLOTS;
+    Slot* sl = &ctx->slot[s];
     if (sl->busy) {
-      int r2 = msm_collect<Fq>(ctx, sl, &(*out)[v]);
+      int r2 = msm_collect<Fq>(ctx, sl, &(*out)[owner[s]]);
       if (rc == AMSM_OK) rc = r2;
     }
   }
   stage_end(ctx);
   return rc;
+}
+
+// n_vecs MSMs over the same generators (the prover's back-to-back commits)
+template <class Fq, class Fr>
+int msm_batch_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* const* d_scalars,
+                   size_t n_vecs, size_t n, int scalars_mont, std::vector<host::HXYZZ<Fq>>* out) {
+  std::vector<size_t> offs(n_vecs, base_off), ns(n_vecs, n);
+  return msm_multi_xyzz<Fq, Fr>(ctx, bases, n_vecs, offs.data(), d_scalars, ns.data(), scalars_mont, out);
 }
 
 // batch_normalization_into_affine (src/hp_as/mod.rs:468): one inversion for the whole batch
@@ -1094,6 +1114,26 @@ int amsm_msm_batch_device(amsm_ctx* c, const amsm_bases* b, size_t off, const vo
   return AMSM_OK;
 }
 
+int amsm_msm_multi_device(amsm_ctx* c, const amsm_bases* b, size_t n_msms, const size_t* base_offs,
+                          const void* const* d_scalars, const size_t* ns, int mont, uint64_t* out_xy, uint8_t* out_inf) {
+  if (!c || !b || (n_msms && (!base_offs || !d_scalars || !ns || !out_xy)) || b->curve != c->curve ||
+      b->device != c->device)
+    return AMSM_E_INVALID_ARG;
+  for (size_t v = 0; v < n_msms; v++)
+    if (ns[v] && !d_scalars[v]) return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (c->curve == AMSM_PALLAS) {
+    std::vector<host::HXYZZ<PallasFq>> r;
+    TRY((msm_multi_xyzz<PallasFq, PallasFr>(c, b, n_msms, base_offs, d_scalars, ns, mont, &r)));
+    write_affine_batch<PallasFq>(r, out_xy, out_inf);
+  } else {
+    std::vector<host::HXYZZ<Bls12381Fq>> r;
+    TRY((msm_multi_xyzz<Bls12381Fq, Bls12381Fr>(c, b, n_msms, base_offs, d_scalars, ns, mont, &r)));
+    write_affine_batch<Bls12381Fq>(r, out_xy, out_inf);
+  }
+  return AMSM_OK;
+}
+
 size_t amsm_partial_bytes(const amsm_ctx* c) {
   if (!c) return 0;
   return c->curve == AMSM_PALLAS ? xyzz_bytes<PallasFq>() : xyzz_bytes<Bls12381Fq>();
@@ -1300,35 +1340,66 @@ const void* amsm_bases_device_ptr(const amsm_bases* b) {
   return b->n ? b->d_abi : b->d_table;
 }
 
+static void canonical_scalar(int curve, const uint64_t* x_mont, u32 out[8]) {
+  if (curve == AMSM_PALLAS) {
+    host::HFe<PallasFr> x;
+    memcpy(x.v, x_mont, 32);
+    x = host::h_from_mont<PallasFr>(x);
+    memcpy(out, x.v, 32);
+  } else {
+    host::HFe<Bls12381Fr> x;
+    memcpy(x.v, x_mont, 32);
+    x = host::h_from_mont<Bls12381Fr>(x);
+    memcpy(out, x.v, 32);
+  }
+}
+
 int amsm_points_fold(amsm_ctx* c, const void* d_l, const void* d_r, size_t n, const uint64_t* x_mont, unsigned nbits,
                      void* d_out) {
   if (!c || !x_mont || (n && (!d_l || !d_r || !d_out)) || n >= (1ull << 32) || nbits > 256) return AMSM_E_INVALID_ARG;
   TRY(bind_device(c));
   if (!n) return AMSM_OK;
-  // canonical scalar to the device (tiny, stream-ordered through the context's misc buffer of slot 0)
-  u64 canon[4];
-  if (c->curve == AMSM_PALLAS) {
-    host::HFe<PallasFr> x;
-    memcpy(x.v, x_mont, 32);
-    x = host::h_from_mont<PallasFr>(x);
-    memcpy(canon, x.v, 32);
-  } else {
-    host::HFe<Bls12381Fr> x;
-    memcpy(x.v, x_mont, 32);
-    x = host::h_from_mont<Bls12381Fr>(x);
-    memcpy(canon, x.v, 32);
-  }
-  TRY(ensure(c->scalars, 64));
-  HIP_TRY(hipMemcpyAsync(c->scalars.p, canon, 32, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // canon is a stack buffer
+  u32 canon[8];
+  canonical_scalar(c->curve, x_mont, canon);
   if (c->curve == AMSM_PALLAS)
-    launch_points_fold<PallasFq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, (const u32*)c->scalars.p, nbits,
-                                 (u32*)d_out);
+    launch_points_fold<PallasFq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, canon, nbits, (u32*)d_out, true);
   else
-    launch_points_fold<Bls12381Fq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, (const u32*)c->scalars.p, nbits,
-                                   (u32*)d_out);
+    launch_points_fold<Bls12381Fq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, canon, nbits, (u32*)d_out, true);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(c->stream));  // the scalar buffer is reused by the next call
+  return AMSM_OK;
+}
+
+int amsm_bases_fold(amsm_ctx* c, const amsm_bases* key, size_t n_half, const uint64_t* x_mont, unsigned nbits,
+                    amsm_bases** out) {
+  if (!c || !key || !out || !x_mont || key->curve != c->curve || key->device != c->device || nbits > 256 ||
+      n_half == 0 || 2 * n_half > key->n)
+    return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  size_t pb = (c->curve == AMSM_PALLAS) ? affine_bytes<PallasFq>() : affine_bytes<Bls12381Fq>();
+  amsm_bases* b = new (std::nothrow) amsm_bases();
+  if (!b) return AMSM_E_OOM;
+  b->curve = c->curve;
+  b->device = c->device;
+  b->n = n_half;
+  if (hipMalloc((void**)&b->d_table, n_half * pb) != hipSuccess) {
+    (void)hipGetLastError();
+    delete b;
+    return AMSM_E_OOM;
+  }
+  u32 canon[8];
+  canonical_scalar(c->curve, x_mont, canon);
+  const u32* l = key->d_table;  // level 0 of a precomputed table is the key itself
+  const u32* r = (const u32*)((const char*)key->d_table + n_half * pb);
+  if (c->curve == AMSM_PALLAS)
+    launch_points_fold<PallasFq>(c->stream, l, r, (u32)n_half, canon, nbits, b->d_table, false);
+  else
+    launch_points_fold<Bls12381Fq>(c->stream, l, r, (u32)n_half, canon, nbits, b->d_table, false);
+  if (hipGetLastError() != hipSuccess) {
+    (void)hipFree(b->d_table);
+    delete b;
+    return AMSM_E_HIP;
+  }
+  *out = b;  // stream-ordered: every consumer (MSM prep, another fold) is ordered behind the context's stream
   return AMSM_OK;
 }
 
@@ -1385,6 +1456,21 @@ int amsm_ipa_check_poly_coeffs(amsm_ctx* c, const uint64_t* xi_mont, size_t k, v
   TRY(bind_device(c));
   if (c->curve == AMSM_PALLAS) launch_check_poly_coeffs<PallasFr>(c->stream, (const u32*)xi_mont, (u32)k, (u32*)d_out);
   else launch_check_poly_coeffs<Bls12381Fr>(c->stream, (const u32*)xi_mont, (u32)k, (u32*)d_out);
+  HIP_TRY(hipGetLastError());
+  return AMSM_OK;
+}
+
+int amsm_ipa_round_scalars(amsm_ctx* c, const uint64_t* xi_mont, size_t j, size_t log_n, const void* d_coeffs,
+                           void* d_out_l, void* d_out_r) {
+  if (!c || !d_coeffs || !d_out_l || !d_out_r || (j && !xi_mont) || log_n == 0 || log_n > 30 || j >= log_n)
+    return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  if (c->curve == AMSM_PALLAS)
+    launch_ipa_round_scalars<PallasFr>(c->stream, (const u32*)xi_mont, (u32)j, (u32)log_n, (const u32*)d_coeffs,
+                                       (u32*)d_out_l, (u32*)d_out_r);
+  else
+    launch_ipa_round_scalars<Bls12381Fr>(c->stream, (const u32*)xi_mont, (u32)j, (u32)log_n, (const u32*)d_coeffs,
+                                         (u32*)d_out_l, (u32*)d_out_r);
   HIP_TRY(hipGetLastError());
   return AMSM_OK;
 }

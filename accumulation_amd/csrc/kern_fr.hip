@@ -124,6 +124,16 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
     hipLaunchKernelGGL((k_check_poly_coeffs<FR>), dim3(cdiv_(1u << k, 256)), dim3(256), 0, st, a, out);              \
   }                                                                                                                  \
   template <>                                                                                                        \
+  void launch_ipa_round_scalars<FR>(hipStream_t st, const u32* xi, u32 j, u32 log_n, const u32* c, u32* out_l,       \
+                                    u32* out_r) {                                                                    \
+    CheckPolyArgs a;                                                                                                 \
+    memset(&a, 0, sizeof(a));                                                                                        \
+    memcpy(a.xi, xi, (size_t)j * 32);                                                                                \
+    a.k = j;                                                                                                         \
+    hipLaunchKernelGGL((k_ipa_round_scalars<FR>), dim3(cdiv_(1u << log_n, 256)), dim3(256), 0, st, a, j, log_n, c,    \
+                       out_l, out_r);                                                                                \
+  }                                                                                                                  \
+  template <>                                                                                                        \
   void launch_spmv<FR>(hipStream_t st, const u32* row_ptr, const u32* col, const u32* val, const u32* input,         \
                        u32 n_input, const u32* witness, u32 n_witness, u32* out, u32 n_rows) {                       \
     hipLaunchKernelGGL((k_spmv<FR>), dim3(cdiv_(n_rows, 256)), dim3(256), 0, st, row_ptr, col, val, input, n_input,   \

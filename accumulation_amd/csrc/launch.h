@@ -44,7 +44,8 @@ template <class Fq>
 void launch_points_export(hipStream_t st, const u32* src, u32* dst, u32 n);
 
 template <class Fq>
-void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const u32* d_x_canon, u32 nbits, u32* out);
+void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const u32 x_canon[8], u32 nbits, u32* out,
+                        bool abi_radix);
 
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>
@@ -81,6 +82,8 @@ template <class Fr>
 void launch_vec_powers(hipStream_t st, const u32 point_mont[8], u32 n, u32* out);
 template <class Fr>
 void launch_vec_inner_product(hipStream_t st, const u32* a, const u32* b, u32 n, u32 blocks, u32* out);
+template <class Fr>
+void launch_ipa_round_scalars(hipStream_t st, const u32* xi_mont, u32 j, u32 log_n, const u32* c, u32* out_l, u32* out_r);
 template <class Fr>
 void launch_check_poly_coeffs(hipStream_t st, const u32* xi_mont, u32 k, u32* out);
 void launch_vec_fill(hipStream_t st, u32* out, const u32 value[8], u32 n);

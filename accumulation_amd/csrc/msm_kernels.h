@@ -352,21 +352,30 @@ __global__ void __launch_bounds__(256) k_precompute_level(u32* __restrict__ tabl
 // out[i] = l[i] + x * r[i] for affine point vectors (the commitment-key fold `key_l += key_r * xi` of the IPA
 // opening, ark_poly_commit::ipa_pc ext, under src/ipa_pc_as/mod.rs:454): one lane per point, left-to-right
 // double-and-add over the `nbits` low bits of the canonical scalar x, then one inversion back to affine.
-template <class Fq>
+struct Scalar256 {  // canonical scalar as a kernel argument
+  u32 w[8];
+};
+// ABI = true: l, r, out are caller-visible device buffers (C-ABI Montgomery radix in and out); false: key tables
+// (device radix, amsm_bases_fold)
+template <class Fq, bool ABI>
 __global__ void __launch_bounds__(256)
-    k_points_fold(const u32* __restrict__ l, const u32* __restrict__ r, u32 n, const u32* __restrict__ x_canon,
-                  u32 nbits, u32* __restrict__ out) {
+    k_points_fold(const u32* __restrict__ l, const u32* __restrict__ r, u32 n, Scalar256 x, u32 nbits,
+                  u32* __restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  // l, r, out are caller-visible device buffers: C-ABI Montgomery radix in and out
-  Affine<Fq> pr = affine_import<Fq>(affine_load<Fq>(r, i));
+  Affine<Fq> pr = affine_load<Fq>(r, i);
+  if (ABI) pr = affine_import<Fq>(pr);
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   for (int bit = (int)nbits - 1; bit >= 0; bit--) {
     acc = xyzz_dbl<Fq>(acc);
-    if ((x_canon[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd<Fq>(acc, pr);
+    if ((x.w[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd<Fq>(acc, pr);
   }
-  xyzz_madd<Fq>(acc, affine_import<Fq>(affine_load<Fq>(l, i)));
-  affine_store<Fq>(out, i, affine_export<Fq>(xyzz_to_affine<Fq>(acc)));
+  Affine<Fq> pl = affine_load<Fq>(l, i);
+  if (ABI) pl = affine_import<Fq>(pl);
+  xyzz_madd<Fq>(acc, pl);
+  Affine<Fq> res = xyzz_to_affine<Fq>(acc);
+  if (ABI) res = affine_export<Fq>(res);
+  affine_store<Fq>(out, i, res);
 }
 
 // is_inf bytes -> (0,0) encoding on device

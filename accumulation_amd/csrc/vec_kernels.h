@@ -170,6 +170,36 @@ __global__ void __launch_bounds__(256) k_check_poly_coeffs(CheckPolyArgs a, u32*
   fe_store<Fr>(out + (size_t)p * 8, acc);
 }
 
+// Scalars of the two cross commitments of IPA round j over the ORIGINAL key (no key folding between rounds).
+// The key of round j is G^(j)[i] = sum over the top-j-bit patterns b of (prod_t x_t^{b_t}) * G[i + sum_t b_t n/2^(t+1)],
+// so with s_j(k) = product of the challenges x_t (t < j) whose bit (log n - 1 - t) is set in k, and h = n / 2^(j+1):
+//   L_j = <c_r, G_l^(j)> = sum over k with bit (log n - 1 - j) clear of  c[h + (k mod h)] * s_j(k) * G[k]
+//   R_j = <c_l, G_r^(j)> = sum over k with that bit set             of  c[(k mod h)]     * s_j(k) * G[k]
+// (c = the current, folded coefficient vector of length 2h).  Each output has n/2 zeros, which the MSM skips.
+template <class Fr>
+__global__ void __launch_bounds__(256)
+    k_ipa_round_scalars(CheckPolyArgs a, u32 j, u32 log_n, const u32* __restrict__ c, u32* __restrict__ out_l,
+                        u32* __restrict__ out_r) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (1u << log_n)) return;
+  Fe<Fr> s = fe_one<Fr>();
+  for (u32 t = 0; t < j; t++) {
+    if ((k >> (log_n - 1 - t)) & 1u) {
+      Fe<Fr> x;
+#pragma unroll
+      for (int q = 0; q < 8; q++) x.v[q] = a.xi[t][q];
+      s = fe_mul<Fr>(s, x);
+    }
+  }
+  const u32 h = 1u << (log_n - 1 - j);
+  const u32 idx = k & (h - 1u);
+  const bool right = (k >> (log_n - 1 - j)) & 1u;
+  Fe<Fr> v = fe_mul<Fr>(fe_load<Fr>(c + (size_t)(right ? idx : h + idx) * 8), s);
+  Fe<Fr> z = fe_zero<Fr>();
+  fe_store<Fr>(out_l + (size_t)k * 8, right ? z : v);
+  fe_store<Fr>(out_r + (size_t)k * 8, right ? v : z);
+}
+
 // out[i] = value  (the reference's `vec![F::rand(rng); len]` hiding vectors, src/hp_as/mod.rs:189-190)
 __global__ void __launch_bounds__(256) k_vec_fill(u32* __restrict__ out, uint4 lo, uint4 hi, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;

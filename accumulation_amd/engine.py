@@ -239,6 +239,15 @@ class CommitterKey:
         ffi.check(ctx._lib.amsm_bases_generate(ctx._h, seed, n, flags, C.byref(h)), "amsm_bases_generate")
         return cls(ctx, h)
 
+    def fold(self, n_half: int, x_limbs: np.ndarray, nbits: int = 255) -> "CommitterKey":
+        """New (plain) key of n_half generators: out[i] = self[i] + x * self[n_half + i] -- the key fold
+        `key_l += key_r * xi` of the IPA opening (ark_poly_commit::ipa_pc ext, under src/ipa_pc_as/mod.rs:454),
+        key to key on the device.  x_limbs: the scalar in Montgomery form."""
+        h = C.c_void_p()
+        x = np.ascontiguousarray(x_limbs, dtype=np.uint64)
+        ffi.check(self.ctx._lib.amsm_bases_fold(self.ctx._h, self._h, n_half, _ptr(x), nbits, C.byref(h)), "amsm_bases_fold")
+        return CommitterKey(self.ctx, h)
+
     def supported_num_elems(self) -> int:
         return int(self.ctx._lib.amsm_bases_len(self._h))
 
@@ -297,6 +306,22 @@ class VariableBaseMSM:
         inf = np.zeros((k,), dtype=np.uint8)
         ffi.check(ctx._lib.amsm_msm_batch_device(ctx._h, bases._h, base_off, ptrs, k, n, 1 if mont else 0, _ptr(out),
                                                  _ptr(inf)), "amsm_msm_batch_device")
+        return out, inf
+
+
+    @staticmethod
+    def multi_scalar_mul_multi(bases: CommitterKey, jobs: Sequence[Tuple[int, "FrVector"]], mont: bool = True):
+        """Independent MSMs over windows of one key, pipelined on the device: job = (base_off, scalars); MSM j uses
+        generators [base_off, base_off + len(scalars)).  Returns (k x 2L u64, k uint8)."""
+        ctx = bases.ctx
+        k = len(jobs)
+        offs = (C.c_size_t * max(k, 1))(*[int(o) for o, _ in jobs])
+        ns = (C.c_size_t * max(k, 1))(*[v.n for _, v in jobs])
+        ptrs = (C.c_void_p * max(k, 1))(*[v.ptr for _, v in jobs])
+        out = np.zeros((k, 2 * ctx.fq_limbs), dtype=np.uint64)
+        inf = np.zeros((k,), dtype=np.uint8)
+        ffi.check(ctx._lib.amsm_msm_multi_device(ctx._h, bases._h, k, offs, ptrs, ns, 1 if mont else 0, _ptr(out),
+                                                 _ptr(inf)), "amsm_msm_multi_device")
         return out, inf
 
 

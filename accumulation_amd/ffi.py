@@ -56,6 +56,7 @@ SIGNATURES = {
     "amsm_msm": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_msm_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_msm_batch_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_vp), _sz, _sz, C.c_int, _vp, _vp]),
+    "amsm_msm_multi_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), C.c_int, _vp, _vp]),
     "amsm_partial_bytes": (_sz, [_vp]),
     "amsm_msm_partial_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp]),
     "amsm_partials_combine": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
@@ -75,9 +76,11 @@ SIGNATURES = {
     "amsm_bases_from_device": (C.c_int, [_vp, _vp, _sz, C.c_uint, C.POINTER(_vp)]),
     "amsm_bases_device_ptr": (_vp, [_vp]),
     "amsm_points_fold": (C.c_int, [_vp, _vp, _vp, _sz, _vp, C.c_uint, _vp]),
+    "amsm_bases_fold": (C.c_int, [_vp, _vp, _sz, _vp, C.c_uint, C.POINTER(_vp)]),
     "amsm_vec_inner_product": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "amsm_vec_powers": (C.c_int, [_vp, _vp, _sz, _vp]),
     "amsm_ipa_check_poly_coeffs": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "amsm_ipa_round_scalars": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "amsm_matrix_load": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, C.POINTER(_vp)]),
     "amsm_matrix_rows": (_sz, [_vp]),
     "amsm_matrix_free": (None, [_vp]),

@@ -122,6 +122,13 @@ int amsm_msm_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, con
 int amsm_msm_batch_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* const* d_scalars,
                           size_t n_vecs, size_t n, int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
 
+/* n_msms independent MSMs over windows of ONE key, pipelined like amsm_msm_batch_device: MSM v uses generators
+ * [base_offs[v], base_offs[v] + ns[v]) and the device scalars d_scalars[v].  The two cross commitments of an IPA
+ * round, <c_r, key_l> and <c_l, key_r> (ark_poly_commit::ipa_pc ext, under src/ipa_pc_as/mod.rs:454), are one call. */
+int amsm_msm_multi_device(amsm_ctx* ctx, const amsm_bases* bases, size_t n_msms, const size_t* base_offs,
+                          const void* const* d_scalars, const size_t* ns, int scalars_mont, uint64_t* out_xy_mont,
+                          uint8_t* out_is_inf);
+
 /* Multi-GPU (one process per GPU): each rank runs the MSM over its shard of the key and leaves a
  * fixed-size un-normalised partial in device memory; ranks all-gather the partials (RCCL, raw bytes)
  * and every rank folds them.  amsm_partial_bytes() is the per-rank record size. */
@@ -200,10 +207,23 @@ const void* amsm_bases_device_ptr(const amsm_bases* bases);
  * significant bits of the canonical x (128 for the truncated round challenges, 255 in general). */
 int amsm_points_fold(amsm_ctx* ctx, const void* d_l, const void* d_r, size_t n, const uint64_t* x_mont,
                      unsigned nbits, void* d_out);
+/* The same fold from key to key, with no detour through caller-visible buffers: *out = a new (never precomputed) key of
+ * n_half generators, out[i] = key[i] + x * key[n_half + i].  Stream-ordered on the context's stream. */
+int amsm_bases_fold(amsm_ctx* ctx, const amsm_bases* key, size_t n_half, const uint64_t* x_mont, unsigned nbits,
+                    amsm_bases** out);
 /* out_mont = sum_i a[i]*b[i]  (`inner_product` of the IPA rounds; polynomial evaluation as <coeffs, powers>). */
 int amsm_vec_inner_product(amsm_ctx* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* out_mont);
 /* d_out[i] = point^i, i < n  (the evaluation vector z of the opening). */
 int amsm_vec_powers(amsm_ctx* ctx, const uint64_t* point_mont, size_t n, void* d_out);
+/* Scalars of the two cross commitments L_j = <c_r, key_l>, R_j = <c_l, key_r> of opening round j (0-based) expressed
+ * over the ORIGINAL key of n = 2^log_n generators, so that no key is folded between rounds: with xi_0..xi_{j-1} the
+ * previous rounds' challenges (key_l += xi * key_r each round) and d_coeffs the current coefficient vector of
+ * length n / 2^j, d_out_l / d_out_r (n elements each, half of them zero) satisfy
+ * L_j = msm(key, d_out_l), R_j = msm(key, d_out_r).  The final folded key is msm(key, amsm_ipa_check_poly_coeffs(xi)).
+ * Same points as the reference's round-by-round folding (ext, under src/ipa_pc_as/mod.rs:454), n MSM pairs per
+ * round on the precomputed key instead of n / 2^j 128-bit scalar multiplications with an inversion each. */
+int amsm_ipa_round_scalars(amsm_ctx* ctx, const uint64_t* xi_mont, size_t j, size_t log_n, const void* d_coeffs,
+                           void* d_out_l, void* d_out_r);
 /* d_out[p] (p < 2^k) = coefficients of prod_{i=1..k} (1 + xi_i X^(2^(k-i))):
  * `SuccinctCheckPolynomial::compute_coeffs` (ext), call sites src/ipa_pc_as/mod.rs:400 and under :836. k <= 32. */
 int amsm_ipa_check_poly_coeffs(amsm_ctx* ctx, const uint64_t* xi_mont, size_t k, void* d_out);

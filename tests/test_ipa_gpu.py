@@ -69,6 +69,59 @@ def test_ipa_kernels_vs_oracle(env):
         assert h.np_to_point(c, got[i], 0) == o.add(c, pts[i], o.mul(c, x, pts[6 + i]))
 
 
+@pytest.mark.parametrize("flags", [1, 2], ids=["precomputed", "plain"])
+def test_ipa_rounds_without_key_folding_vs_oracle(env, flags):
+    """The opening's rounds computed two ways must give the same points: the reference's way -- fold the key every
+    round (here with the big-int oracle, and on the device with amsm_bases_fold) -- and the product's way --
+    amsm_ipa_round_scalars over the original key + amsm_msm_multi_device, final key from the check polynomial."""
+    from accumulation_amd import CommitterKey, VariableBaseMSM, ffi
+    from accumulation_amd.engine import _ptr
+    from accumulation_amd.ipa_pc import SuccinctCheckPolynomial
+    from accumulation_amd.scalar_field import Fr
+    ctx, _ = env
+    c = o.PALLAS
+    fr = Fr(ctx.curve)
+    log_n, n = 4, 16
+    pts = o.rng_points(c, 91, n)
+    xy, _ = h.points_to_np(c, pts)
+    key = CommitterKey.load(ctx, xy, None, flags)
+    coeffs = [o.rng_scalar(92, i) % c.r for i in range(n)]
+    xs = [o.rng_scalar(93, i) % (1 << 128) for i in range(log_n)]
+    d_c = ctx.upload(fr.to_limbs_many(coeffs))
+    u_l, u_r = ctx.vector(n), ctx.vector(n)
+    g, cur, dev_key, owned = list(pts), list(coeffs), key, False
+    for j in range(log_n):
+        half = len(cur) // 2
+        exp_l = o.msm_naive(c, g[:half], cur[half:])   # <c_r, key_l>
+        exp_r = o.msm_naive(c, g[half:], cur[:half])   # <c_l, key_r>
+        xi = fr.to_limbs_many(xs[:j]) if j else None
+        ffi.check(ctx._lib.amsm_ipa_round_scalars(ctx._h, _ptr(xi), j, log_n, d_c.ptr, u_l.ptr, u_r.ptr), "round scalars")
+        out, inf = VariableBaseMSM.multi_scalar_mul_multi(key, [(0, u_l), (0, u_r)], mont=True)
+        assert h.np_to_point(c, out[0], inf[0]) == exp_l and h.np_to_point(c, out[1], inf[1]) == exp_r, j
+        # the same two commitments over the device-folded key (windows of one key: base_off 0 / half)
+        cv = ctx.upload(fr.to_limbs_many(cur))
+        out2, inf2 = VariableBaseMSM.multi_scalar_mul_multi(dev_key, [(0, cv.view(half, half)), (half, cv.view(0, half))],
+                                                            mont=True)
+        assert h.np_to_point(c, out2[0], inf2[0]) == exp_l and h.np_to_point(c, out2[1], inf2[1]) == exp_r, j
+        # fold: key_l += x * key_r, c_l += x^-1 * c_r
+        x = xs[j]
+        g = [o.add(c, g[i], o.mul(c, x, g[half + i])) for i in range(half)]
+        inv = pow(x, -1, c.r)
+        cur = [(cur[i] + inv * cur[half + i]) % c.r for i in range(half)]
+        d_c = ctx.upload(fr.to_limbs_many(cur))
+        nk = dev_key.fold(half, fr.to_limbs(x), 128)
+        if owned:
+            dev_key.free()
+        dev_key, owned = nk, True
+        got, ginf = dev_key.read(0, half)
+        assert [h.np_to_point(c, got[i], ginf[i]) for i in range(half)] == g, j
+    s_vec = SuccinctCheckPolynomial(xs).compute_coeffs(ctx)
+    fk, finf = VariableBaseMSM.multi_scalar_mul(key, s_vec, mont=True)
+    assert h.np_to_point(c, fk, finf) == g[0]
+    dev_key.free()
+    key.free()
+
+
 @pytest.mark.parametrize("hiding", [False, True], ids=["plain", "hiding"])
 def test_ipa_commit_open_check(env, hiding):
     from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
