@@ -340,6 +340,42 @@ def test_chunk_length_override(cref, k0):
             os.environ["AMSM_K0"] = old
 
 
+@pytest.mark.parametrize("prep", ["rocprim", "custom"])
+def test_prep_chain_variants_agree(cref, prep):
+    """The 5-dispatch prep chain (prep_kernels.h) and its fallback (digits + rocPRIM sort + bounds + scan) feed
+    accumulate L0 the same buckets: both must reproduce the CPU oracle on uniform, all-equal and sparse scalars, with
+    precomputed and plain keys, on both curves."""
+    import os
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    old = os.environ.get("AMSM_PREP")
+    os.environ["AMSM_PREP"] = prep
+    try:
+        for c in (o.PALLAS, o.BLS12_381_G1):
+            ctx = Context(c.curve_id)
+            n = 6001
+            xy = cref.rng_points(c.curve_id, 11, n)
+            cases = {"uniform": cref.rng_scalars(12, n)}
+            eq = cases["uniform"].copy()
+            eq[:] = eq[0]
+            cases["all_equal"] = eq
+            sp = np.zeros_like(cases["uniform"])
+            sp[::97] = cases["uniform"][::97]
+            cases["sparse"] = sp
+            for name, sc in cases.items():
+                ref, rinf = cref.msm(c.curve_id, xy, sc, threads=4)
+                for flags in (1, 2):
+                    ck = CommitterKey.load(ctx, xy, None, flags)
+                    out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
+                    assert oinf == rinf and np.array_equal(out, ref), (prep, c.name, name, flags)
+                    ck.free()
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("AMSM_PREP", None)
+        else:
+            os.environ["AMSM_PREP"] = old
+
+
 def test_bls12_381_2_18_vs_c_oracle(ctxs, cref):
     """BASELINE.json config 3 family (384-bit base field): 2^18 BLS12-381 G1 pairs, bit-exact vs the CPU restatement."""
     from accumulation_amd import CommitterKey, VariableBaseMSM
