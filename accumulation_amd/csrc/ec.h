@@ -11,9 +11,11 @@
 // The formulas are written once, in the bound-aware primitives of fp.h.  On a saturated field every value is
 // canonical and the K's are ignored.  On an unsaturated field (fpu.h; Pallas Fq, cap = 2^261 ~ 128 p) values are
 // only bounded; the invariant of a point held in registers or memory is
-//        X, Y < 8p      ZZ, ZZZ < 2p      (affine / loaded coordinates: canonical, < p)
+//        X < 8p      Y < 3p      ZZ, ZZZ < 2p      (affine / loaded coordinates: canonical, < p)
 // and the comments `[< k p]` give the bound of each intermediate: a product of A < a p and B < b p is
-// < (1 + a b / 128) p, a difference `x - y (+K p)` needs y < K p and is < (x + K) p.
+// < (1 + a b / 128) p, a difference `x - y (+K p)` needs y < K p and is < (x + K) p; the fused
+// `a b - c d` (ONE reduction for both products, fe_mul_sub_mul_k<K>) needs c < (K - 1) p and is
+// < (1 + (a b + K d) / 128) p.
 #pragma once
 #include "fp.h"
 
@@ -74,7 +76,7 @@ AMSM_DEV XYZZ<P> xyzz_dbl(const XYZZ<P>& p) {
   XYZZ<P> r;
   r.x = fe_sub_bcc_k<P, 4>(fe_sqr<P>(m), zero, s);           // m^2 [< 1.2p] - 2s (+4p)  [< 5.2p]
   Fe<P> t = fe_sub_k<P, 8>(s, r.x);                          // [< 9.2p]
-  r.y = fe_sub_k<P, 2>(fe_mul<P>(m, t), fe_mul<P>(w, p.y));  // [< 1.4p] - [< 1.1p] (+2p)  [< 3.4p]
+  r.y = fe_mul_sub_mul_k<P, 4>(m, t, p.y, w);                // (m t + (4p - y) w) / R': (42 + 6) / 128  [< 1.4p]
   r.zz = fe_mul<P>(v, p.zz);                                 // [< 1.1p]
   r.zzz = fe_mul<P>(w, p.zzz);                               // [< 1.1p]
   return r;
@@ -93,7 +95,7 @@ AMSM_DEV XYZZ<P> xyzz_dbl_affine(const Affine<P>& p) {  // p.x, p.y < 2p, tight
   XYZZ<P> r;
   r.x = fe_sub_bcc_k<P, 4>(fe_sqr<P>(m), zero, s);           // [< 5.2p]
   Fe<P> t = fe_sub_k<P, 8>(s, r.x);                          // [< 9.1p]
-  r.y = fe_sub_k<P, 2>(fe_mul<P>(m, t), fe_mul<P>(w, p.y));  // [< 3.3p]
+  r.y = fe_mul_sub_mul_k<P, 2>(m, t, p.y, w);                // (m t + (2p - y) w) / R'  [< 1.3p]
   r.zz = v;
   r.zzz = w;
   return r;
@@ -118,7 +120,7 @@ AMSM_DEV void xyzz_madd(XYZZ<P>& acc, const Affine<P>& q) {
   Fe<P> u2 = fe_mul<P>(q.x, acc.zz);    // [< 1.1p]
   Fe<P> s2 = fe_mul<P>(q.y, acc.zzz);   // [< 1.1p]
   Fe<P> p = fe_sub_k<P, 8>(u2, acc.x);  // [< 9.1p]
-  Fe<P> r = fe_sub_k<P, 8>(s2, acc.y);  // [< 9.1p]
+  Fe<P> r = fe_sub_k<P, 4>(s2, acc.y);  // [< 5.1p]
   if (fe_is_zero_mod<P, 16>(p)) {
     if (fe_is_zero_mod<P, 16>(r)) {
       Affine<P> qt;
@@ -133,9 +135,9 @@ AMSM_DEV void xyzz_madd(XYZZ<P>& acc, const Affine<P>& q) {
   Fe<P> pp = fe_sqr<P>(p);                                // [< 1.7p]
   Fe<P> ppp = fe_mul<P>(p, pp);                           // [< 1.2p]
   Fe<P> qq = fe_mul<P>(acc.x, pp);                        // [< 1.2p]
-  Fe<P> x3 = fe_sub_bcc_k<P, 4>(fe_sqr<P>(r), ppp, qq);   // r^2 [< 1.7p] - ppp - 2qq [< 3.6p] (+4p)  [< 5.7p]
+  Fe<P> x3 = fe_sub_bcc_k<P, 4>(fe_sqr<P>(r), ppp, qq);   // r^2 [< 1.3p] - ppp - 2qq [< 3.6p] (+4p)  [< 5.3p]
   Fe<P> t = fe_sub_k<P, 8>(qq, x3);                       // [< 9.2p]
-  Fe<P> y3 = fe_sub_k<P, 2>(fe_mul<P>(r, t), fe_mul<P>(acc.y, ppp));  // [< 1.7p] - [< 1.1p] (+2p)  [< 3.7p]
+  Fe<P> y3 = fe_mul_sub_mul_k<P, 4>(r, t, acc.y, ppp);   // (r t + (4p - y1) ppp) / R': (84 + 5) / 128  [< 1.7p]
   acc.x = x3;
   acc.y = y3;
   acc.zz = fe_mul<P>(acc.zz, pp);     // [< 1.1p]
@@ -169,7 +171,7 @@ AMSM_DEV void xyzz_add(XYZZ<P>& acc, const XYZZ<P>& q) {
   Fe<P> qq = fe_mul<P>(u1, pp);                          // [< 1.1p]
   Fe<P> x3 = fe_sub_bcc_k<P, 4>(fe_sqr<P>(r), ppp, qq);  // [< 1.1p] - [< 3.3p] (+4p)  [< 5.1p]
   Fe<P> t = fe_sub_k<P, 8>(qq, x3);                      // [< 9.1p]
-  Fe<P> y3 = fe_sub_k<P, 2>(fe_mul<P>(r, t), fe_mul<P>(s1, ppp));  // [< 1.3p] - [< 1.1p] (+2p)  [< 3.3p]
+  Fe<P> y3 = fe_mul_sub_mul_k<P, 2>(r, t, s1, ppp);      // (r t + (2p - s1) ppp) / R': (29 + 3) / 128  [< 1.3p]
   acc.x = x3;
   acc.y = y3;
   acc.zz = fe_mul<P>(fe_mul<P>(acc.zz, q.zz), pp);       // [< 1.1p]

@@ -264,6 +264,12 @@ AMSM_DEV Fe<P> fe_sub_bcc_k(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c) {  /
   if constexpr (P::UNSAT) return u_sub_bcc_k<P, K>(a, b, c);
   else return fe_sub<P>(fe_sub<P>(fe_sub<P>(a, b), c), c);
 }
+// a*b - c*d   (unsat: + (K p * d) / R', needs c < K p; ONE Montgomery reduction for both products)
+template <class P, u32 K>
+AMSM_DEV Fe<P> fe_mul_sub_mul_k(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
+  if constexpr (P::UNSAT) return u_mul_add_mul<P>(a, b, u_kp_minus_lazy<P, K>(c), d);
+  else return fe_sub<P>(fe_mul<P>(a, b), fe_mul<P>(c, d));
+}
 template <class P>
 AMSM_DEV Fe<P> fe_dbl(const Fe<P>& a) {
   if constexpr (P::UNSAT) return u_times<P, 2>(a);

@@ -120,6 +120,55 @@ AMSM_DEV Fe<P> u_mul(const Fe<P>& a, const Fe<P>& b) {
   return r;
 }
 
+// (a*b + c*d) / 2^(B*L) mod p with ONE reduction: both products are accumulated column by column before the
+// Montgomery step (saves a whole reduction, ~40 % of a multiplication, wherever the group law subtracts two products).
+// Needs: limbs of a, c < 2^(B+1), limbs of b, d < 2^B.  Gives: tight, value < p + (a*b + c*d) / 2^(B*L).
+template <class P>
+AMSM_DEV Fe<P> u_mul_add_mul(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
+  constexpr int L = P::L;
+  constexpr u32 M = u_mask<P>();
+  u64 acc = 0;
+  u32 m[L];
+  Fe<P> r;
+#pragma unroll
+  for (int k = 0; k < 2 * L; k++) {
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (j >= 0 && j < L) {
+        acc += (u64)a.v[i] * b.v[j];
+        acc += (u64)c.v[i] * d.v[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int j = k - i;
+      if (i < k && j >= 1 && j < L && P::mod(j < 0 || j >= L ? 0 : j) != 0) acc += (u64)m[i] * P::mod(j < 0 || j >= L ? 0 : j);
+    }
+    if (k < L) {
+      u32 lo = (u32)acc & M;
+      m[k] = (P::NINV == M) ? ((0u - lo) & M) : ((lo * P::NINV) & M);
+      acc += (u64)m[k] * P::mod(0);
+      acc >>= P::B;
+    } else {
+      r.v[k - L] = (k == 2 * L - 1) ? (u32)acc : ((u32)acc & M);
+      acc >>= P::B;
+    }
+  }
+  return r;
+}
+
+// K*p - y with lazy limbs (< 2^(B+1)): multiplication operand only.  Needs y tight and y < (K - 1)*p, so that the
+// (unnormalised) top limb cannot go negative.
+template <class P, u32 K>
+AMSM_DEV Fe<P> u_kp_minus_lazy(const Fe<P>& y) {
+  constexpr UKpBp<P, K, 1> c{};
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.v[i] = c.v[i] - y.v[i];
+  return r;
+}
+
 // a^2 / 2^(B*L): the cross products are taken once against doubled limbs (45 instead of 81 products for L = 9).
 // Needs: a tight.  Gives: tight, value < p + a^2 / 2^(B*L).
 template <class P>
