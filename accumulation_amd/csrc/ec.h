@@ -117,10 +117,8 @@ AMSM_DEV void xyzz_madd(XYZZ<P>& acc, const Affine<P>& q) {
     acc.zzz = fe_one<P>();
     return;
   }
-  Fe<P> u2 = fe_mul<P>(q.x, acc.zz);    // [< 1.1p]
-  Fe<P> s2 = fe_mul<P>(q.y, acc.zzz);   // [< 1.1p]
-  Fe<P> p = fe_sub_k<P, 8>(u2, acc.x);  // [< 9.1p]
-  Fe<P> r = fe_sub_k<P, 4>(s2, acc.y);  // [< 5.1p]
+  Fe<P> p = fe_mul_sub_k<P, 9>(q.x, acc.zz, acc.x);   // u2 - X1 (+9p)  [< 10.1p]
+  Fe<P> r = fe_mul_sub_k<P, 4>(q.y, acc.zzz, acc.y);  // s2 - Y1 (+4p)  [< 5.1p]
   if (fe_is_zero_mod<P, 16>(p)) {
     if (fe_is_zero_mod<P, 16>(r)) {
       Affine<P> qt;
@@ -132,10 +130,10 @@ AMSM_DEV void xyzz_madd(XYZZ<P>& acc, const Affine<P>& q) {
     }
     return;
   }
-  Fe<P> pp = fe_sqr<P>(p);                                // [< 1.7p]
+  Fe<P> pp = fe_sqr<P>(p);                                // [< 1.8p]
   Fe<P> ppp = fe_mul<P>(p, pp);                           // [< 1.2p]
   Fe<P> qq = fe_mul<P>(acc.x, pp);                        // [< 1.2p]
-  Fe<P> x3 = fe_sub_bcc_k<P, 4>(fe_sqr<P>(r), ppp, qq);   // r^2 [< 1.3p] - ppp - 2qq [< 3.6p] (+4p)  [< 5.3p]
+  Fe<P> x3 = fe_sqr_sub_bcc_k<P, 4>(r, ppp, qq);          // r^2 [< 1.3p] - ppp - 2qq [< 3.6p] (+4p)  [< 5.3p]
   Fe<P> t = fe_sub_k<P, 8>(qq, x3);                       // [< 9.2p]
   Fe<P> y3 = fe_mul_sub_mul_k<P, 4>(r, t, acc.y, ppp);   // (r t + (4p - y1) ppp) / R': (84 + 5) / 128  [< 1.7p]
   acc.x = x3;

@@ -264,6 +264,26 @@ AMSM_DEV Fe<P> fe_sub_bcc_k(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c) {  /
   if constexpr (P::UNSAT) return u_sub_bcc_k<P, K>(a, b, c);
   else return fe_sub<P>(fe_sub<P>(fe_sub<P>(a, b), c), c);
 }
+// a*b - c   (unsat: + K p, needs c < (K - 1) p; the subtraction rides in the product's upper columns, result tight)
+template <class P, u32 K>
+AMSM_DEV Fe<P> fe_mul_sub_k(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c) {
+  if constexpr (P::UNSAT) {
+    Fe<P> add = u_kp_minus_lazy<P, K>(c);
+    return u_mul<P, true>(a, b, &add);
+  } else {
+    return fe_sub<P>(fe_mul<P>(a, b), c);
+  }
+}
+// a^2 - b - 2c   (unsat: + K p, needs b + 2c < K p)
+template <class P, u32 K>
+AMSM_DEV Fe<P> fe_sqr_sub_bcc_k(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c) {
+  if constexpr (P::UNSAT) {
+    Fe<P> add = u_kp_minus_bcc_raw<P, K>(b, c);
+    return u_sqr<P, true>(a, &add);
+  } else {
+    return fe_sub<P>(fe_sub<P>(fe_sub<P>(fe_sqr<P>(a), b), c), c);
+  }
+}
 // a*b - c*d   (unsat: + (K p * d) / R', needs c < K p; ONE Montgomery reduction for both products)
 template <class P, u32 K>
 AMSM_DEV Fe<P> fe_mul_sub_mul_k(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {

@@ -88,8 +88,11 @@ AMSM_DEV void u_carry(Fe<P>& a) {
 
 // Montgomery product a*b / 2^(B*L) mod p.  Needs: limbs of a < 2^(B+1), limbs of b < 2^B (or the reverse).
 // Gives: tight, value < p + a*b / 2^(B*L).
-template <class P>
-AMSM_DEV Fe<P> u_mul(const Fe<P>& a, const Fe<P>& b) {
+// With ADD: returns a*b / 2^(B*L) + add, the addend's limbs (any u32, e.g. the unnormalised K*p - x) going straight
+// into the upper columns of the product, so "product minus value" costs L 64-bit adds instead of a subtraction and
+// a carry pass, and the result is tight.
+template <class P, bool ADD = false>
+AMSM_DEV Fe<P> u_mul(const Fe<P>& a, const Fe<P>& b, const Fe<P>* add = nullptr) {
   constexpr int L = P::L;
   constexpr u32 M = u_mask<P>();
   u64 acc = 0;
@@ -113,6 +116,7 @@ AMSM_DEV Fe<P> u_mul(const Fe<P>& a, const Fe<P>& b) {
       acc += (u64)m[k] * P::mod(0);
       acc >>= P::B;
     } else {
+      if (ADD) acc += add->v[k - L];
       r.v[k - L] = (k == 2 * L - 1) ? (u32)acc : ((u32)acc & M);
       acc >>= P::B;
     }
@@ -171,8 +175,8 @@ AMSM_DEV Fe<P> u_kp_minus_lazy(const Fe<P>& y) {
 
 // a^2 / 2^(B*L): the cross products are taken once against doubled limbs (45 instead of 81 products for L = 9).
 // Needs: a tight.  Gives: tight, value < p + a^2 / 2^(B*L).
-template <class P>
-AMSM_DEV Fe<P> u_sqr(const Fe<P>& a) {
+template <class P, bool ADD = false>
+AMSM_DEV Fe<P> u_sqr(const Fe<P>& a, const Fe<P>* add = nullptr) {
   constexpr int L = P::L;
   constexpr u32 M = u_mask<P>();
   u32 a2[L];
@@ -202,6 +206,7 @@ AMSM_DEV Fe<P> u_sqr(const Fe<P>& a) {
       acc += (u64)m[k] * P::mod(0);
       acc >>= P::B;
     } else {
+      if (ADD) acc += add->v[k - L];
       r.v[k - L] = (k == 2 * L - 1) ? (u32)acc : ((u32)acc & M);
       acc >>= P::B;
     }
@@ -228,6 +233,16 @@ AMSM_DEV Fe<P> u_sub_bcc_k(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c) {
 #pragma unroll
   for (int i = 0; i < P::L; i++) r.v[i] = a.v[i] + kp.v[i] - b.v[i] - 2u * c.v[i];
   u_carry<P>(r);
+  return r;
+}
+
+// K*p - b - 2c, unnormalised (limbs < 2^32): addend of u_mul<ADD> / u_sqr<ADD> only.  Needs b, c tight, b + 2c < K*p.
+template <class P, u32 K>
+AMSM_DEV Fe<P> u_kp_minus_bcc_raw(const Fe<P>& b, const Fe<P>& c) {
+  constexpr UKpBp<P, K, 3> kp{};
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.v[i] = kp.v[i] - b.v[i] - 2u * c.v[i];
   return r;
 }
 
