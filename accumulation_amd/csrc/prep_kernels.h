@@ -37,7 +37,10 @@ constexpr u32 PREP_ENTRY_LAST = 0x40000000u;  // == ENTRY_LAST of msm_kernels.h
 
 // ctr[idx]++ on an LDS counter, returning the old value.  When every active lane of the wave hits the SAME counter
 // (skewed digit distributions -- the all-equal vectors of SURVEY.md F8 -- make that the common case) one lane adds
-// the wave's population instead of 64 serialized same-address atomics.
+// the wave's population instead of 64 serialized same-address atomics.  Used by k_prep_local on oversized partitions
+// only: there one workgroup walks millions of entries; everywhere else plain LDS atomics are as fast.
+// (k_prep_local is bound by its 16.8 M scattered 4-byte stores -- L2 write transactions, ~62 us at 2^20 -- not by
+// loads or atomics: keeping the partition in registers between the two passes did not change its 75 us.)
 AMSM_DEV u32 lds_count(u32* ctr, u32 idx) {
   const u64 active = __ballot(1);
   const u32 first = __builtin_amdgcn_readfirstlane(idx);
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(1024)
   u32 bad = 0;
   for (u32 r = 0; r < pg.SPB; r += blockDim.x) {
     u32 i = blockIdx.x * pg.SPB + r + threadIdx.x;
-    if (i < g.n) bad |= scalar_entries<Fr>(scalars, mont, g, i, [&](u32 key, u32) { lds_count(cnt, key >> pg.SH); });
+    if (i < g.n) bad |= scalar_entries<Fr>(scalars, mont, g, i, [&](u32 key, u32) { atomicAdd(&cnt[key >> pg.SH], 1u); });
   }
   if (bad) atomicOr(err, 1u);
   __syncthreads();
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(512)
     u32 i = blockIdx.x * pg.SPB + r * T + t;
     if (i < g.n)
       scalar_entries_unrolled<Fr, MAXW>(scalars, mont, g, i, [&](int w, u32 key, u32) {
-        u32 rank = lds_count(cnt, key >> pg.SH);
+        u32 rank = atomicAdd(&cnt[key >> pg.SH], 1u);
         rk[r][w >> 1] |= rank << ((w & 1) * 16);
       });
   }
@@ -284,15 +287,23 @@ __global__ void __launch_bounds__(1024)
   // entries are read four at a time once the partition is long enough to care (skewed inputs make partitions of
   // millions of entries; one workgroup still owns each): head up to 16-byte alignment, uint4 body, tail
   const u32 body_lo = min((ps + 3u) & ~3u, pe), body_hi = max(body_lo, pe & ~3u);
-  for (u32 j = ps + t; j < body_lo; j += T) lds_count(cnt, (part[j] >> pg.IB) & low);
+  // a partition several times the expected size means a skewed digit distribution: whole waves then hit one counter,
+  // and the wave-aggregated increment is worth its extra instructions (uniform per workgroup)
+  const bool skew = (pe - ps) > 4u * (g.E / pg.P + 1u);
+  auto count = [&](u32 e) {
+    u32 k = (e >> pg.IB) & low;
+    if (skew) lds_count(cnt, k);
+    else atomicAdd(&cnt[k], 1u);
+  };
+  for (u32 j = ps + t; j < body_lo; j += T) count(part[j]);
   for (u32 j = body_lo + 4u * t; j < body_hi; j += 4u * T) {
     uint4 e4 = *reinterpret_cast<const uint4*>(part + j);
-    lds_count(cnt, (e4.x >> pg.IB) & low);
-    lds_count(cnt, (e4.y >> pg.IB) & low);
-    lds_count(cnt, (e4.z >> pg.IB) & low);
-    lds_count(cnt, (e4.w >> pg.IB) & low);
+    count(e4.x);
+    count(e4.y);
+    count(e4.z);
+    count(e4.w);
   }
-  for (u32 j = body_hi + t; j < pe; j += T) lds_count(cnt, (part[j] >> pg.IB) & low);
+  for (u32 j = body_hi + t; j < pe; j += T) count(part[j]);
   __syncthreads();
   const u32 b0 = p << pg.SH;
   // exclusive prefix of the bucket sizes (entries) and of the bucket chunk counts (partials), lane t owns a slice
@@ -345,7 +356,7 @@ __global__ void __launch_bounds__(1024)
   // final placement; the entry that lands on the last position of its bucket carries the flag
   auto place = [&](u32 e) {
     u32 k = (e >> pg.IB) & low;
-    u32 pos = lds_count(off, k);
+    u32 pos = skew ? lds_count(off, k) : atomicAdd(&off[k], 1u);
     u32 v = (e & 0x80000000u) | (e & idx_mask);
     if (pos + 1 == cnt[k]) v |= PREP_ENTRY_LAST;
     vals_sorted[ps + pos] = v;
