@@ -123,11 +123,14 @@ def main() -> int:
         # latency of ONE synchronous MSM call (no overlap between consecutive MSMs), for reference
         out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
         inf = C.c_uint8(0)
+        ctx.set_profiling(True)
         t1 = time.perf_counter()
         for _ in range(5):
             ffi.check(ctx._lib.amsm_msm_device(ctx._h, ck._h, 0, scalars.ptr, n, 0, _ptr(out), C.byref(inf)),
                       "amsm_msm_device")
         ms_sync = (time.perf_counter() - t1) / 5 * 1e3
+        stage_ms_alone = ctx.stage_ms()  # stages of the last blocking call: nothing else on the GPU
+        ctx.set_profiling(False)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -181,6 +184,9 @@ def main() -> int:
                 # the kernel is integer-VALU bound, not HBM bound: the ceiling that binds is
                 # the issue rate of the 10-multiplication mixed addition measured in isolation (tools/fp_bench.hip)
                 "alu": alu_roofline(args, ck, n, dom_ms),
+                # the same kernel with the GPU to itself (one blocking MSM call after the timed region)
+                "kernel_ms_unshared": stage_ms_alone.get(dom, 0.0),
+                "alu_unshared": alu_roofline(args, ck, n, stage_ms_alone.get(dom, 0.0)),
             },
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         }
