@@ -289,6 +289,27 @@ def test_partials_batch_roundtrip_single_rank(ctxs, cref):
             e.ck.free()
 
 
+def test_sharded_msm_batch_world1(ctxs, cref):
+    """dist.ShardedMSM over the HIP engine without a process group (world 1): msm() and msm_batch() both return the
+    whole-job MSM; this is the code path bench.py --gpus N runs per rank (the all-gather itself is covered on CPU)."""
+    from accumulation_amd import CommitterKey
+    from accumulation_amd.dist import HipEngine, ShardedMSM
+    c = o.PALLAS
+    ctx = ctxs[c.name]
+    n = 3000
+    xy = cref.rng_points(c.curve_id, 61, n)
+    scs = [cref.rng_scalars(70 + j, n) for j in range(4)]
+    refs = [cref.msm(c.curve_id, xy, sc, threads=4) for sc in scs]
+    ck = CommitterKey.load(ctx, xy, None, 1)
+    sm = ShardedMSM(HipEngine(ctx, ck))
+    out, inf = sm.msm(ctx.upload(scs[0]), mont=False)
+    assert inf == refs[0][1] and np.array_equal(out, refs[0][0])
+    outs, infs = sm.msm_batch([ctx.upload(sc) for sc in scs], mont=False)
+    for j in range(4):
+        assert bool(infs[j]) == refs[j][1] and np.array_equal(outs[j], refs[j][0]), j
+    ck.free()
+
+
 def test_randomized_geometry_stress(ctxs, cref):
     """Random (n, window, key kind, chunk length) combinations against the C oracle: exercises entry counts that are
     not multiples of the group size, chunks that straddle many / few buckets, windows whose last digit is short."""
