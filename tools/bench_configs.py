@@ -65,7 +65,7 @@ def bench_degenerate(log2n):
     ctx.close()
 
 
-def bench_r1cs_nark_as(log2c, reps=2):
+def bench_r1cs_nark_as(log2c, reps=8):
     """cfg4: r1cs_nark_as over 2^log2c constraints (DummyCircuit of examples/scaling-nark.rs:21-56), no zk:
     one accumulation = 1 input + 1 old accumulator => 2 SpMV + nested hp_as (2 MSMs) + witness combination."""
     from accumulation_amd import r1cs_nark as nark
@@ -106,7 +106,7 @@ def bench_r1cs_nark_as(log2c, reps=2):
     ctx.close()
 
 
-def bench_ipa(log2d, reps=1):
+def bench_ipa(log2d, reps=3):
     """cfg2: ipa_pc_as with d+1 = 2^log2d: decide = one (d+1)-point MSM; prove = succinct checks + one IPA opening."""
     from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
     from accumulation_amd.ipa_pc_as import AtomicASForInnerProductArgPC as IAS, InputInstance as IpaInput
