@@ -158,7 +158,11 @@ int choose_window(size_t n, bool precomp) {
   static const int good[13] = {4, 5, 6, 7, 8, 8, 10, 10, 10, 13, 13, 15, 16};  // index c - 4
   return good[c - 4];
 }
-inline int windows_for(int c) { return 255 / c + 1; }  // W*c >= 256 (signed digits need one spare bit)
+// Both scalar fields are 255 bits wide.  Windows below the top one use signed digits (|d| <= 2^(c-1), carry into the
+// next window); the top window is unsigned, so W = ceil(255 / c) windows suffice.  Only when c divides 255 can the top
+// digit exceed the 2^(c-1) buckets: the excess becomes a second entry on the same table row (slot W).
+inline int windows_for(int c) { return (255 + c - 1) / c; }
+inline int slots_for(int c) { return windows_for(c) + (windows_for(c) * c == 255 ? 1 : 0); }
 
 template <class Fq>
 constexpr size_t affine_bytes() {
@@ -225,8 +229,9 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   g.nb = 1u << (c - 1);
   g.n_sets = bases->precomp ? 1u : (u32)W;
   g.B = g.n_sets * g.nb;
-  if ((unsigned long long)n * W >= (1ull << 30)) return AMSM_E_UNSUPPORTED;  // entry words carry a 30-bit index
-  g.E = (u32)(n * W);
+  g.S = (u32)slots_for(c);
+  if ((unsigned long long)n * g.S >= (1ull << 30)) return AMSM_E_UNSUPPORTED;  // entry words carry a 30-bit index
+  g.E = (u32)(n * g.S);
   g.base_off = (u32)base_off;
   g.table_stride = (u32)bases->n;
   g.precomp = (u32)bases->precomp;

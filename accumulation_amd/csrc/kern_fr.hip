@@ -28,7 +28,7 @@ static PrepGeom prep_geom(const MsmGeom& g) {
   while (((g.B + (1u << pg.SH) - 1u) >> pg.SH) > 512u && pg.SH < 10u) pg.SH++;
   while (((g.B + (1u << pg.SH) - 1u) >> pg.SH) > PREP_MAX_P) pg.SH++;
   pg.P = (g.B + (1u << pg.SH) - 1u) >> pg.SH;
-  pg.SPB = g.W <= 16u ? 512u : 256u;  // SPB * W <= 8192 staged entries
+  pg.SPB = g.S <= 16u ? 512u : 256u;  // SPB * S <= 8192 staged entries
   unsigned long long max_idx = (unsigned long long)g.base_off + g.n - 1ull +
                                (g.precomp ? (unsigned long long)(g.W - 1u) * g.table_stride : 0ull);
   pg.IB = 1;
@@ -39,7 +39,7 @@ static PrepGeom prep_geom(const MsmGeom& g) {
   return pg;
 }
 bool prep_supported(const MsmGeom& g) {
-  if (g.n == 0 || g.W > 32u) return false;  // W > 32 <=> c < 8: tiny problems, the rocPRIM chain is fine there
+  if (g.n == 0 || g.S > 32u) return false;  // S > 32 <=> c < 8: tiny problems, the rocPRIM chain is fine there
   PrepGeom pg = prep_geom(g);
   // entry word = negate | bucket-id low bits << IB | index; k_prep_local keeps 2 * 2^SH + 256 words in LDS
   return pg.SH <= 12u && pg.IB + pg.SH <= 31u;
@@ -60,7 +60,7 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
     u32* part_items = b.d_small + 3 * (PREP_MAX_P + 1);                                                              \
     if (hipMemsetAsync(b.d_small, 0, 4 * (PREP_MAX_P + 1) * sizeof(u32), st) != hipSuccess) return -1;               \
     u32 blocks = cdiv_(g.n, pg.SPB);                                                                                 \
-    u32 cap = pg.SPB * g.W;                                                                                          \
+    u32 cap = pg.SPB * g.S;                                                                                          \
     size_t lds_scatter = (3 * pg.P + cap) * sizeof(u32) + cap * sizeof(uint16_t);                                    \
     {  /* the histogram's blocking is independent of the scatter's: 1024 scalars, one per lane */                    \
       PrepGeom ph = pg;                                                                                              \
@@ -69,7 +69,7 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
                          mont, g, ph, part_total, b.err);                                                            \
     }                                                                                                                \
     hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P);                       \
-    if (g.W <= 16u)                                                                                                  \
+    if (g.S <= 16u)                                                                                                  \
       hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1>), dim3(blocks), dim3(512), lds_scatter, st, scalars, mont, g, pg, \
                          part_start, part_cursor, b.part);                                                           \
     else                                                                                                             \

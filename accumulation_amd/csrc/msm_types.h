@@ -13,11 +13,12 @@ constexpr int HP_MAX_INPUTS = 8;  // max inputs+accumulators of one hp_as t-vect
 struct MsmGeom {
   u32 n;             // pairs in this call
   u32 c;             // window bits (2..24)
-  u32 W;             // windows
+  u32 W;             // windows = ceil(255 / c)
+  u32 S;             // entry slots per scalar: W, or W + 1 when c divides 255 (the unsigned top window can spill)
   u32 nb;            // buckets per set = 2^(c-1)
   u32 n_sets;        // 1 when precomputed, else W
   u32 B;             // n_sets * nb  (key B = "digit 0", dropped)
-  u32 E;             // n * W entries
+  u32 E;             // n * S entries (upper bound; zero digits emit none)
   u32 base_off;      // first generator used
   u32 table_stride;  // generators per table level (key length)
   u32 precomp;       // table has W levels

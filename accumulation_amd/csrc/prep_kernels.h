@@ -56,8 +56,9 @@ AMSM_DEV u32 lds_count(u32* ctr, u32 idx) {
   return atomicAdd(&ctr[idx], 1u);
 }
 
-// Calls f(key, value) for every non-zero signed c-bit digit of scalar i; returns non-zero when the scalar does not
-// fit W windows (caller reports AMSM_E_SCALAR_RANGE).  key = bucket id, value = sign | index into the key table.
+// Calls f(key, value) for every non-zero digit of scalar i (signed c-bit digits, the top window unsigned); returns
+// non-zero when the scalar does not fit W windows (caller reports AMSM_E_SCALAR_RANGE).  key = bucket id, value =
+// sign | index into the key table.  At most g.S entries per scalar.
 template <class Fr, class F>
 AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const MsmGeom& g, u32 i, F&& f) {
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
@@ -71,19 +72,25 @@ AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const Msm
 #pragma unroll
     for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
     s.v[7] >>= c;
-    u32 neg = 0;
+    u32 set = g.precomp ? 0u : w;
+    u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
     carry = 0;
-    u32 d = raw;
-    if (raw > half) {
-      d = (1u << c) - raw;
-      neg = 1;
-      carry = 1;
-    }
-    if (d != 0) {
-      u32 set = g.precomp ? 0u : w;
-      u32 key = set * g.nb + (d - 1);
-      u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
-      f(key, idx | (neg << 31));
+    if (w + 1 == g.W) {
+      // top window: taken unsigned (no carry out of the scalar), so its digit can reach 2^c = 2 nb when c divides
+      // the scalar width; the excess over nb becomes a second entry on the same table row
+      u32 d1 = min(raw, half), d2 = raw - d1;
+      if (d2 > (g.S > g.W ? half : 0u)) carry = 1;  // not representable: reported through `rest` below
+      if (d1) f(set * g.nb + (d1 - 1), idx);
+      if (d2 && g.S > g.W) f(set * g.nb + (min(d2, half) - 1), idx);
+    } else {
+      u32 neg = 0;
+      u32 d = raw;
+      if (raw > half) {
+        d = (1u << c) - raw;
+        neg = 1;
+        carry = 1;
+      }
+      if (d != 0) f(set * g.nb + (d - 1), idx | (neg << 31));
     }
   }
   u32 rest = carry;
@@ -109,19 +116,24 @@ AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont,
 #pragma unroll
       for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
       s.v[7] >>= c;
-      u32 neg = 0;
+      u32 set = g.precomp ? 0u : (u32)w;
+      u32 idx = g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
       carry = 0;
-      u32 d = raw;
-      if (raw > half) {
-        d = (1u << c) - raw;
-        neg = 1;
-        carry = 1;
-      }
-      if (d != 0) {
-        u32 set = g.precomp ? 0u : (u32)w;
-        u32 key = set * g.nb + (d - 1);
-        u32 idx = g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
-        f(w, key, idx | (neg << 31));
+      if ((u32)w + 1 == g.W) {  // unsigned top window, see scalar_entries; the spill uses slot w + 1 (= W < MAXW)
+        u32 d1 = min(raw, half), d2 = raw - d1;
+        if (d1) f(w, set * g.nb + (d1 - 1), idx);
+        if (w + 1 < MAXW) {
+          if (d2 && g.S > g.W) f(w + 1, set * g.nb + (min(d2, half) - 1), idx);
+        }
+      } else {
+        u32 neg = 0;
+        u32 d = raw;
+        if (raw > half) {
+          d = (1u << c) - raw;
+          neg = 1;
+          carry = 1;
+        }
+        if (d != 0) f(w, set * g.nb + (d - 1), idx | (neg << 31));
       }
     }
   }
@@ -190,13 +202,13 @@ __global__ void __launch_bounds__(1024) k_prep_scan(const u32* __restrict__ part
 // write consecutive words (runs of SPB * W / P entries: 64 B at P = 512).  Scattering word by word instead cost
 // 360 us at 2^20 pairs (33 M partial-line write transactions); staged it is bandwidth bound.
 // dynamic LDS: 3 * P words + SPB * W words (staged entries) + SPB * W half-words (their partition).
-// SPT = scalars per lane (SPB = blockDim * SPT), MAXW >= W; SPB * W <= 8192.
+// SPT = scalars per lane (SPB = blockDim * SPT), MAXW >= S (entry slots per scalar); SPB * S <= 8192.
 template <class Fr, int MAXW, int SPT>
 __global__ void __launch_bounds__(512)
     k_prep_scatter(const u32* __restrict__ scalars, int mont, MsmGeom g, PrepGeom pg, const u32* __restrict__ part_start,
                    u32* __restrict__ part_cursor, u32* __restrict__ part) {
   extern __shared__ u32 prep_lds[];
-  const u32 cap = pg.SPB * g.W;  // staged entries (upper bound)
+  const u32 cap = pg.SPB * g.S;  // staged entries (upper bound)
   u32* cnt = prep_lds;           // entries per partition (rank counters in step 1)
   u32* loff = prep_lds + pg.P;   // block-local exclusive prefix
   u32* gbase = prep_lds + 2 * pg.P;

@@ -241,19 +241,29 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
     s.v[7] >>= c;
-    u32 neg = 0;
-    carry = 0;
-    u32 d = raw;
-    if (raw > half) {
-      d = (1u << c) - raw;
-      neg = 1;
-      carry = 1;
-    }
     u32 set = g.precomp ? 0u : w;
-    u32 key = d == 0 ? g.B : set * g.nb + (d - 1);
     u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
-    keys[(size_t)w * g.n + i] = (KeyT)key;
-    vals[(size_t)w * g.n + i] = idx | (neg << 31);
+    carry = 0;
+    if (w + 1 == g.W) {  // unsigned top window (prep_kernels.h: scalar_entries); the spill has its own slot W
+      u32 d1 = min(raw, half), d2 = raw - d1;
+      if (d2 > (g.S > g.W ? half : 0u)) carry = 1;  // not representable: reported through `rest` below
+      keys[(size_t)w * g.n + i] = (KeyT)(d1 ? set * g.nb + (d1 - 1) : g.B);
+      vals[(size_t)w * g.n + i] = idx;
+      if (g.S > g.W) {
+        keys[(size_t)g.W * g.n + i] = (KeyT)(d2 ? set * g.nb + (min(d2, half) - 1) : g.B);
+        vals[(size_t)g.W * g.n + i] = idx;
+      }
+    } else {
+      u32 neg = 0;
+      u32 d = raw;
+      if (raw > half) {
+        d = (1u << c) - raw;
+        neg = 1;
+        carry = 1;
+      }
+      keys[(size_t)w * g.n + i] = (KeyT)(d == 0 ? g.B : set * g.nb + (d - 1));
+      vals[(size_t)w * g.n + i] = idx | (neg << 31);
+    }
   }
   u32 rest = carry;
 #pragma unroll

@@ -362,6 +362,44 @@ def test_chunk_length_override(cref, k0):
 
 
 @pytest.mark.parametrize("prep", ["rocprim", "custom"])
+def test_top_window_spill(cref, prep):
+    """Window widths that divide the 255-bit scalar width (3, 5, 15, 17) take the top window unsigned: its digit can
+    exceed the 2^(c-1) buckets by up to 2^(c-1) and is then split into two entries.  Scalars at and around the top of
+    the field (r - 1, r - 2, 2^254 + k, all-ones low windows so that the carry reaches the top) must still match the
+    CPU oracle, with both prep chains and both key kinds."""
+    import os
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    c = o.PALLAS
+    old = os.environ.get("AMSM_PREP")
+    os.environ["AMSM_PREP"] = prep
+    try:
+        ctx = Context(c.curve_id)
+        n = 600
+        xy = cref.rng_points(c.curve_id, 21, n)
+        special = [c.r - 1, c.r - 2, 1 << 254, (1 << 254) + 1, (1 << 254) - 1, c.r - (1 << 237), (1 << 254) + (1 << 253) % 1,
+                   c.r - 1 - (1 << 16), (1 << 238) - 1, (1 << 239) - 1, 0, 1]
+        ints = [special[i % len(special)] if i % 3 == 0 else o.rng_scalar(22, i) % c.r for i in range(n)]
+        sc = h.scalars_to_np(ints)
+        ref, rinf = cref.msm(c.curve_id, xy, sc, threads=4)
+        try:
+            for w in (3, 5, 15, 17, 16):
+                ctx.set_window(w)
+                for flags in (1, 2):
+                    ck = CommitterKey.load(ctx, xy, None, flags)
+                    out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
+                    assert oinf == rinf and np.array_equal(out, ref), (prep, w, flags)
+                    ck.free()
+        finally:
+            ctx.set_window(0)
+        ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("AMSM_PREP", None)
+        else:
+            os.environ["AMSM_PREP"] = old
+
+
+@pytest.mark.parametrize("prep", ["rocprim", "custom"])
 def test_prep_chain_variants_agree(cref, prep):
     """The 5-dispatch prep chain (prep_kernels.h) and its fallback (digits + rocPRIM sort + bounds + scan) feed
     accumulate L0 the same buckets: both must reproduce the CPU oracle on uniform, all-equal and sparse scalars, with
