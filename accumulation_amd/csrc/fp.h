@@ -10,6 +10,11 @@
 // multiplier and no carry-in on the MAD, and a VALU write of VCC/SGPR needs 2 wait states before a VALU
 // reads it as carry-in.  All loops are fully unrolled over compile-time limb counts and compile-time
 // moduli so zero / one limbs of the modulus fold away (Pallas: 3 real MADs per reduction round).
+//
+// Two representations live behind one set of primitives: the saturated 32-bit-limb fields of this file (both scalar
+// fields, the BLS12-381 base field) and the unsaturated 9 x 29-bit Pallas base field of fpu.h, which the MSM kernels
+// compute in (DevField below).  The group law (ec.h) only uses the bound-aware primitives near the end of this file
+// (fe_mul, fe_sqr, fe_sub_k, fe_mul_sub_k, fe_mul_sub_mul_k, ...), which are the plain modular operations here.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -4,15 +4,16 @@
 // structure: unsigned c-bit windows, 2^c-1 Jacobian buckets per window, running-sum reduction, serial
 // Horner).  The GPU pipeline is NOT a translation of that loop nest:
 //
-//   digits   : one lane per scalar; signed c-bit digits (halves the buckets), one (key,value) entry per
-//              window: key = bucket id, value = sign | index into the (pre-multiplied) generator table.
-//   sort     : device radix sort of the entries by bucket id (rocPRIM) -- turns the scatter into runs.
-//   bounds   : per bucket, binary search of its run [start,end) + number of K0-sized work items.
+//   prep     : (prep_kernels.h) scalars -> signed c-bit digits (halves the buckets) -> one entry per non-zero digit
+//              (value = sign | index into the pre-multiplied generator table) -> the entries grouped by bucket:
+//              partition histogram, scatter into ~512 partitions, per-partition counting sort, bucket table
+//              (start[], number of K0-sized work items, last-of-bucket flags).  Five dispatches; the first version
+//              (k_digits + rocPRIM radix sort + k_bounds + rocPRIM scan, 14 dispatches) is kept as a fallback.
 //   accum L0 : one lane per work item: <= K0 mixed additions (XYZZ, 8M+2S) gathered from the table.
 //              Work items are equal sized, so wave64 lanes stay converged whatever the digit
 //              distribution is (the reference's harness feeds all-equal scalars).
-//   accum L1 : one lane per bucket folds its L0 partials; buckets with many partials go to
-//   accum L2 : one 256-lane workgroup per heavy bucket (strided sums + wave-shuffle / LDS tree).
+//   accum L1 : 1 / 4 / 16 lanes per bucket fold its L0 partials; buckets with more than K1 partials go to
+//   accum L2 : 32 workgroups per heavy bucket (strided sums + wave-shuffle / LDS tree), then one folding wave.
 //   reduce   : sum_j j*B_j per bucket set: per-lane running sums over s buckets, a small scalar
 //              multiple, then a wave-shuffle + LDS tree per workgroup; one partial per workgroup.
 //   fold     : one wave folds the workgroup partials with __shfl_xor (single XYZZ result).
@@ -26,8 +27,6 @@
 #include "rng.h"
 
 namespace amsm {
-
-
 
 // ---------------------------------------------------------------------------------------------
 // accumulate L0: lane c owns the fixed-size chunk [c*K0, (c+1)*K0) of the SORTED entry list, whatever
