@@ -211,7 +211,7 @@ struct RunInfo {
   MsmGeom g;
 };
 
-int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n, MsmGeom* out) {
+int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n, MsmGeom* out, int group_shift = -1) {
   MsmGeom g;
   memset(&g, 0, sizeof(g));
   int c, W;
@@ -227,7 +227,9 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   g.c = (u32)c;
   g.W = (u32)W;
   g.nb = 1u << (c - 1);
-  g.n_sets = bases->precomp ? 1u : (u32)W;
+  g.groups = group_shift >= 0 ? 2u : 1u;
+  g.group_shift = group_shift >= 0 ? (u32)group_shift : 0u;
+  g.n_sets = g.groups * (bases->precomp ? 1u : (u32)W);
   g.B = g.n_sets * g.nb;
   g.S = (u32)slots_for(c);
   if ((unsigned long long)n * g.S >= (1ull << 30)) return AMSM_E_UNSUPPORTED;  // entry words carry a 30-bit index
@@ -291,9 +293,9 @@ int prep_fork(amsm_ctx* ctx) {
 // in sl->fold_out and queues their D2H into sl->h_pinned.
 template <class Fq, class Fr>
 int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
-                int scalars_mont) {
+                int scalars_mont, int group_shift = -1) {
   MsmGeom g;
-  TRY(make_geom(ctx, bases, base_off, n, &g));
+  TRY(make_geom(ctx, bases, base_off, n, &g, group_shift));
   sl->geom = g;
   hipStream_t st = ctx->s_prep;  // digits / sort / bounds
   hipStream_t sm = ctx->stream;  // accumulate L0
@@ -407,7 +409,8 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   return AMSM_OK;
 }
 
-// Wait for slot `sl`, then host Horner over the window sums (plain key) -> one XYZZ on the host.
+// Wait for slot `sl`, then host Horner over the window sums (plain key) -> one XYZZ per group on the host
+// (`out` has room for sl->geom.groups results).
 template <class Fq>
 int msm_collect(amsm_ctx* ctx, Slot* sl, host::HXYZZ<Fq>* out) {
   const MsmGeom& g = sl->geom;
@@ -425,12 +428,17 @@ int msm_collect(amsm_ctx* ctx, Slot* sl, host::HXYZZ<Fq>* out) {
   u32* h = (u32*)sl->h_pinned;
   u32 err = *(u32*)((char*)h + g.n_sets * rec);
   if (err) return AMSM_E_SCALAR_RANGE;
-  host::HXYZZ<Fq> acc = host::hx_from_device<Fq>(h + (size_t)(g.n_sets - 1) * (rec / 4));
-  for (int w = (int)g.n_sets - 2; w >= 0; w--) {
-    for (u32 k = 0; k < g.c; k++) acc = host::hx_dbl<Fq>(acc);
-    acc = host::hx_add<Fq>(acc, host::hx_from_device<Fq>(h + (size_t)w * (rec / 4)));
+  // one result per group: Horner over the group's window sums (plain key) or its single record (precomputed key)
+  const u32 per = g.n_sets / g.groups;
+  for (u32 grp = 0; grp < g.groups; grp++) {
+    const u32* base = h + (size_t)grp * per * (rec / 4);
+    host::HXYZZ<Fq> acc = host::hx_from_device<Fq>(base + (size_t)(per - 1) * (rec / 4));
+    for (int w = (int)per - 2; w >= 0; w--) {
+      for (u32 k = 0; k < g.c; k++) acc = host::hx_dbl<Fq>(acc);
+      acc = host::hx_add<Fq>(acc, host::hx_from_device<Fq>(base + (size_t)w * (rec / 4)));
+    }
+    out[grp] = acc;
   }
-  *out = acc;
   return AMSM_OK;
 }
 
@@ -750,6 +758,24 @@ int partials_combine_impl(amsm_ctx* ctx, const void* d_partials, size_t count, u
   for (size_t i = 0; i < count; i++)
     acc = host::hx_add<Fq>(acc, host::hx_from_device<Fq>((const u32*)sl->h_pinned + i * (rec / 4)));
   write_affine<Fq>(acc, out_xy, out_inf);
+  return AMSM_OK;
+}
+
+template <class Fq, class Fr>
+int msm_grouped_impl(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n, int mont,
+                     unsigned group_shift, uint64_t* out_xy, uint8_t* out_inf) {
+  if (base_off > bases->n) return AMSM_E_INVALID_ARG;
+  n = std::min(n, bases->n - base_off);
+  std::vector<host::HXYZZ<Fq>> r(2, host::hx_inf<Fq>());
+  if (n) {
+    stage_begin(ctx);
+    TRY(prep_fork(ctx));
+    TRY((msm_enqueue<Fq, Fr>(ctx, &ctx->slot[0], bases, base_off, d_scalars, n, mont, (int)group_shift)));
+    int rc = msm_collect<Fq>(ctx, &ctx->slot[0], r.data());
+    stage_end(ctx);
+    if (rc != AMSM_OK) return rc;
+  }
+  write_affine_batch<Fq>(r, out_xy, out_inf);
   return AMSM_OK;
 }
 
@@ -1139,6 +1165,15 @@ int amsm_msm_multi_device(amsm_ctx* c, const amsm_bases* b, size_t n_msms, const
   return AMSM_OK;
 }
 
+int amsm_msm_grouped_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* d_scalars, size_t n, int mont,
+                            unsigned group_shift, uint64_t* out_xy, uint8_t* out_inf) {
+  if (!c || !b || !out_xy || (n && !d_scalars) || group_shift > 31 || b->curve != c->curve || b->device != c->device)
+    return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  return DISPATCH(c, (msm_grouped_impl<PallasFq, PallasFr>(c, b, off, d_scalars, n, mont, group_shift, out_xy, out_inf)),
+                  (msm_grouped_impl<Bls12381Fq, Bls12381Fr>(c, b, off, d_scalars, n, mont, group_shift, out_xy, out_inf)));
+}
+
 size_t amsm_partial_bytes(const amsm_ctx* c) {
   if (!c) return 0;
   return c->curve == AMSM_PALLAS ? xyzz_bytes<PallasFq>() : xyzz_bytes<Bls12381Fq>();
@@ -1467,7 +1502,7 @@ int amsm_ipa_check_poly_coeffs(amsm_ctx* c, const uint64_t* xi_mont, size_t k, v
 
 int amsm_ipa_round_scalars(amsm_ctx* c, const uint64_t* xi_mont, size_t j, size_t log_n, const void* d_coeffs,
                            void* d_out_l, void* d_out_r) {
-  if (!c || !d_coeffs || !d_out_l || !d_out_r || (j && !xi_mont) || log_n == 0 || log_n > 30 || j >= log_n)
+  if (!c || !d_coeffs || !d_out_l || (j && !xi_mont) || log_n == 0 || log_n > 30 || j >= log_n)
     return AMSM_E_INVALID_ARG;
   TRY(bind_device(c));
   if (c->curve == AMSM_PALLAS)

@@ -16,7 +16,9 @@ struct MsmGeom {
   u32 W;             // windows = ceil(255 / c)
   u32 S;             // entry slots per scalar: W, or W + 1 when c divides 255 (the unsigned top window can spill)
   u32 nb;            // buckets per set = 2^(c-1)
-  u32 n_sets;        // 1 when precomputed, else W
+  u32 n_sets;        // bucket sets = groups * (1 when precomputed, else W)
+  u32 groups;        // 1, or 2: scalar i adds into the sum of group (i >> group_shift) & 1 (two MSMs in one pass)
+  u32 group_shift;
   u32 B;             // n_sets * nb  (key B = "digit 0", dropped)
   u32 E;             // n * S entries (upper bound; zero digits emit none)
   u32 base_off;      // first generator used

@@ -72,7 +72,7 @@ AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const Msm
 #pragma unroll
     for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
     s.v[7] >>= c;
-    u32 set = g.precomp ? 0u : w;
+    u32 set = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W) + (g.precomp ? 0u : w);
     u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
     carry = 0;
     if (w + 1 == g.W) {
@@ -116,7 +116,7 @@ AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont,
 #pragma unroll
       for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
       s.v[7] >>= c;
-      u32 set = g.precomp ? 0u : (u32)w;
+      u32 set = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W) + (g.precomp ? 0u : (u32)w);
       u32 idx = g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
       carry = 0;
       if ((u32)w + 1 == g.W) {  // unsigned top window, see scalar_entries; the spill uses slot w + 1 (= W < MAXW)

@@ -195,6 +195,10 @@ __global__ void __launch_bounds__(256)
   const u32 idx = k & (h - 1u);
   const bool right = (k >> (log_n - 1 - j)) & 1u;
   Fe<Fr> v = fe_mul<Fr>(fe_load<Fr>(c + (size_t)(right ? idx : h + idx) * 8), s);
+  if (out_r == nullptr) {  // one vector for amsm_msm_grouped_device (group = that bit of k)
+    fe_store<Fr>(out_l + (size_t)k * 8, v);
+    return;
+  }
   Fe<Fr> z = fe_zero<Fr>();
   fe_store<Fr>(out_l + (size_t)k * 8, right ? z : v);
   fe_store<Fr>(out_r + (size_t)k * 8, right ? v : z);
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
     s.v[7] >>= c;
-    u32 set = g.precomp ? 0u : w;
+    u32 set = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W) + (g.precomp ? 0u : w);
     u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
     carry = 0;
     if (w + 1 == g.W) {  // unsigned top window (prep_kernels.h: scalar_entries); the spill has its own slot W

@@ -325,6 +325,18 @@ class VariableBaseMSM:
         return out, inf
 
 
+    @staticmethod
+    def multi_scalar_mul_grouped(bases: CommitterKey, scalars: "FrVector", group_shift: int, mont: bool = True,
+                                 base_off: int = 0):
+        """Two MSMs in one pass: result g = sum over the i with ((i >> group_shift) & 1) == g.  -> (2 x 2L u64, 2 uint8)"""
+        ctx = bases.ctx
+        out = np.zeros((2, 2 * ctx.fq_limbs), dtype=np.uint64)
+        inf = np.zeros((2,), dtype=np.uint8)
+        ffi.check(ctx._lib.amsm_msm_grouped_device(ctx._h, bases._h, base_off, scalars.ptr, scalars.n, 1 if mont else 0,
+                                                   group_shift, _ptr(out), _ptr(inf)), "amsm_msm_grouped_device")
+        return out, inf
+
+
 class PedersenCommitment:
     """ark_poly_commit::trivial_pc::PedersenCommitment (ext): setup / commit."""
 

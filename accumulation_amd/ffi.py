@@ -57,6 +57,7 @@ SIGNATURES = {
     "amsm_msm_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_msm_batch_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_vp), _sz, _sz, C.c_int, _vp, _vp]),
     "amsm_msm_multi_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), C.c_int, _vp, _vp]),
+    "amsm_msm_grouped_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, C.c_uint, _vp, _vp]),
     "amsm_partial_bytes": (_sz, [_vp]),
     "amsm_msm_partial_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp]),
     "amsm_partials_combine": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),

@@ -200,8 +200,8 @@ class InnerProductArgPC:
         h_prime = _lincomb(ctx, [ck.h], [round_challenge], fr)
         # The rounds never fold the key.  Round j's cross commitments L_j = <c_r, key_l>, R_j = <c_l, key_r> are
         # expressed over the ORIGINAL (precomputed, HBM-resident) key: amsm_ipa_round_scalars expands the current
-        # coefficients by the products of the previous challenges, and the two resulting MSMs (n pairs each, half of
-        # the scalars zero) run as one pipelined call.  Folding instead costs n / 2^j 128-bit scalar multiplications
+        # coefficients by the products of the previous challenges into ONE vector, and amsm_msm_grouped_device sums
+        # its two index classes (the bit that separates key_l from key_r in round j) in one pass.  Folding instead costs n / 2^j 128-bit scalar multiplications
         # with an inversion each per round -- a ~0.8 ms dependency chain per round whatever the size (measured:
         # 13 of 30 ms at d + 1 = 2^16).  The final folded key is one more MSM with the check polynomial's
         # coefficients.  Points are identical to the reference's (ext, under src/ipa_pc_as/mod.rs:454).
@@ -209,7 +209,7 @@ class InnerProductArgPC:
         n_full = n
         log_n = n.bit_length() - 1
         assert n == 1 << log_n
-        u_l, u_r = ctx.vector(n_full), ctx.vector(n_full)
+        u_l = ctx.vector(n_full)
         xs: List[int] = []
         l_vec, r_vec = [], []
         while n > 1:
@@ -217,9 +217,10 @@ class InnerProductArgPC:
             c_l, c_r = coeffs.view(0, half), coeffs.view(half, half)
             z_l, z_r = z.view(0, half), z.view(half, half)
             xi = fr.to_limbs_many(xs) if xs else None
-            ffi.check(ctx._lib.amsm_ipa_round_scalars(ctx._h, _ptr(xi), len(xs), log_n, coeffs.ptr, u_l.ptr, u_r.ptr),
+            j = len(xs)
+            ffi.check(ctx._lib.amsm_ipa_round_scalars(ctx._h, _ptr(xi), j, log_n, coeffs.ptr, u_l.ptr, None),
                       "amsm_ipa_round_scalars")
-            xy, inf = VariableBaseMSM.multi_scalar_mul_multi(key, [(0, u_l), (0, u_r)], mont=True)
+            xy, inf = VariableBaseMSM.multi_scalar_mul_grouped(key, u_l, log_n - 1 - j, mont=True)
             l_pt = _lincomb(ctx, [(xy[0], bool(inf[0])), h_prime], [1, cls._inner_product(ctx, fr, c_r, z_l)], fr)
             r_pt = _lincomb(ctx, [(xy[1], bool(inf[1])), h_prime], [1, cls._inner_product(ctx, fr, c_l, z_r)], fr)
             l_vec.append(l_pt)

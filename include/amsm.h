@@ -129,6 +129,12 @@ int amsm_msm_multi_device(amsm_ctx* ctx, const amsm_bases* bases, size_t n_msms,
                           const void* const* d_scalars, const size_t* ns, int scalars_mont, uint64_t* out_xy_mont,
                           uint8_t* out_is_inf);
 
+/* Two MSMs over disjoint index classes of ONE scalar vector in one pass: out[g] (g = 0, 1) = sum over the i with
+ * ((i >> group_shift) & 1) == g of scalars[i] * generators[base_off + i].  Same kernels as amsm_msm_device with two
+ * bucket sets; one prep, one accumulate, one tail instead of two (the cross commitments of an IPA round). */
+int amsm_msm_grouped_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
+                            int scalars_mont, unsigned group_shift, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+
 /* Multi-GPU (one process per GPU): each rank runs the MSM over its shard of the key and leaves a
  * fixed-size un-normalised partial in device memory; ranks all-gather the partials (RCCL, raw bytes)
  * and every rank folds them.  amsm_partial_bytes() is the per-rank record size. */
@@ -221,7 +227,10 @@ int amsm_vec_powers(amsm_ctx* ctx, const uint64_t* point_mont, size_t n, void* d
  * length n / 2^j, d_out_l / d_out_r (n elements each, half of them zero) satisfy
  * L_j = msm(key, d_out_l), R_j = msm(key, d_out_r).  The final folded key is msm(key, amsm_ipa_check_poly_coeffs(xi)).
  * Same points as the reference's round-by-round folding (ext, under src/ipa_pc_as/mod.rs:454), n MSM pairs per
- * round on the precomputed key instead of n / 2^j 128-bit scalar multiplications with an inversion each. */
+ * round on the precomputed key instead of n / 2^j 128-bit scalar multiplications with an inversion each.
+ * d_out_r may be NULL: d_out_l then receives the ONE vector u with L_j = sum over k with bit (log_n-1-j) clear of
+ * u[k] key[k] and R_j = the sum over the others, which amsm_msm_grouped_device(group_shift = log_n-1-j) computes in
+ * one pass. */
 int amsm_ipa_round_scalars(amsm_ctx* ctx, const uint64_t* xi_mont, size_t j, size_t log_n, const void* d_coeffs,
                            void* d_out_l, void* d_out_r);
 /* d_out[p] (p < 2^k) = coefficients of prod_{i=1..k} (1 + xi_i X^(2^(k-i))):

@@ -98,6 +98,10 @@ def test_ipa_rounds_without_key_folding_vs_oracle(env, flags):
         ffi.check(ctx._lib.amsm_ipa_round_scalars(ctx._h, _ptr(xi), j, log_n, d_c.ptr, u_l.ptr, u_r.ptr), "round scalars")
         out, inf = VariableBaseMSM.multi_scalar_mul_multi(key, [(0, u_l), (0, u_r)], mont=True)
         assert h.np_to_point(c, out[0], inf[0]) == exp_l and h.np_to_point(c, out[1], inf[1]) == exp_r, j
+        # ... and as ONE vector summed per index class in one pass
+        ffi.check(ctx._lib.amsm_ipa_round_scalars(ctx._h, _ptr(xi), j, log_n, d_c.ptr, u_l.ptr, None), "round scalars (1 vector)")
+        out1, inf1 = VariableBaseMSM.multi_scalar_mul_grouped(key, u_l, log_n - 1 - j, mont=True)
+        assert h.np_to_point(c, out1[0], inf1[0]) == exp_l and h.np_to_point(c, out1[1], inf1[1]) == exp_r, j
         # the same two commitments over the device-folded key (windows of one key: base_off 0 / half)
         cv = ctx.upload(fr.to_limbs_many(cur))
         out2, inf2 = VariableBaseMSM.multi_scalar_mul_multi(dev_key, [(0, cv.view(half, half)), (half, cv.view(0, half))],

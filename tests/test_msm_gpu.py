@@ -289,6 +289,29 @@ def test_partials_batch_roundtrip_single_rank(ctxs, cref):
             e.ck.free()
 
 
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_grouped_msm_vs_two_msms(ctxs, cref, c):
+    """amsm_msm_grouped_device: one pass, two sums over the index classes ((i >> shift) & 1); equals two MSMs with the
+    other class zeroed (CPU oracle), for precomputed and plain keys and several shifts."""
+    from accumulation_amd import CommitterKey, VariableBaseMSM
+    ctx = ctxs[c.name]
+    n = 2048
+    xy = cref.rng_points(c.curve_id, 81, n)
+    sc = cref.rng_scalars(82, n)
+    idx = np.arange(n)
+    for flags in (1, 2):
+        ck = CommitterKey.load(ctx, xy, None, flags)
+        dv = ctx.upload(sc)
+        for shift in (0, 3, 10):
+            out, inf = VariableBaseMSM.multi_scalar_mul_grouped(ck, dv, shift, mont=False)
+            for g in (0, 1):
+                masked = sc.copy()
+                masked[((idx >> shift) & 1) != g] = 0
+                ref, rinf = cref.msm(c.curve_id, xy, masked, threads=4)
+                assert bool(inf[g]) == rinf and np.array_equal(out[g], ref), (c.name, flags, shift, g)
+        ck.free()
+
+
 def test_sharded_msm_batch_world1(ctxs, cref):
     """dist.ShardedMSM over the HIP engine without a process group (world 1): msm() and msm_batch() both return the
     whole-job MSM; this is the code path bench.py --gpus N runs per rank (the all-gather itself is covered on CPU)."""
