@@ -208,6 +208,38 @@ def test_north_star_size_pallas_2_20(ctxs, cref):
     ck.free()
 
 
+def test_config5_size_pallas_2_22(ctxs, cref):
+    """BASELINE.json config 5 size: 2^22 Pallas pairs (4 GiB of precomputed key).  Size-independent properties --
+    the whole MSM equals the sum of the MSMs over its four 2^20-generator windows, and commit(a + 3b) = commit(a) +
+    3 commit(b) -- plus the bit-exact comparison with the window-parallel CPU restatement."""
+    from accumulation_amd import CommitterKey, VariableBaseMSM
+    from accumulation_amd.hp_as import combine_vectors
+    c = o.PALLAS
+    ctx = ctxs[c.name]
+    n, q = 1 << 22, 1 << 20
+    ck = CommitterKey.generate(ctx, 0x5EED1005, n)
+    assert ck.precomputed
+    a = ctx.random_vector(0x5EED0051, n, mont=True)
+    b = ctx.random_vector(0x5EED0052, n, mont=True)
+    ca, ia = VariableBaseMSM.multi_scalar_mul(ck, a, mont=True)
+    cb, ib = VariableBaseMSM.multi_scalar_mul(ck, b, mont=True)
+    Pa, Pb = h.np_to_point(c, ca, ia), h.np_to_point(c, cb, ib)
+    s = combine_vectors(ctx, [a, b], h.fr_mont_np(c, [1, 3]))
+    cs, is_ = VariableBaseMSM.multi_scalar_mul(ck, s, mont=True)
+    assert h.np_to_point(c, cs, is_) == o.add(c, Pa, o.mul(c, 3, Pb))
+    parts, pinf = VariableBaseMSM.multi_scalar_mul_multi(ck, [(k * q, a.view(k * q, q)) for k in range(4)], mont=True)
+    acc = None
+    for k in range(4):
+        acc = o.add(c, acc, h.np_to_point(c, parts[k], pinf[k]))
+    assert acc == Pa
+    xy, _ = ck.read()
+    sc = cref.fr_from_mont(c.curve_id, a.download())
+    ref, rinf = cref.msm(c.curve_id, xy, sc, threads=17)
+    assert ia == rinf and np.array_equal(ca, ref)
+    ck.free()
+    ctx.empty_cache()
+
+
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_pedersen_commit_with_hiding(ctxs, cref, c):
     """PedersenCommitment::commit(ck, v, Some(r)) = msm(ck, v) + r*H  (src/hp_as/mod.rs:196,911-918)."""
