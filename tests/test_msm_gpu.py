@@ -490,12 +490,14 @@ def test_prep_chain_variants_agree(cref, prep):
             os.environ["AMSM_PREP"] = old
 
 
-def test_bls12_381_2_18_vs_c_oracle(ctxs, cref):
-    """BASELINE.json config 3 family (384-bit base field): 2^18 BLS12-381 G1 pairs, bit-exact vs the CPU restatement."""
+@pytest.mark.parametrize("log2n", [18, 20])
+def test_bls12_381_vs_c_oracle(ctxs, cref, log2n):
+    """BASELINE.json config 3 (384-bit base field): 2^18 and the full 2^20 BLS12-381 G1 pairs, bit-exact vs the CPU
+    restatement."""
     from accumulation_amd import CommitterKey, VariableBaseMSM
     c = o.BLS12_381_G1
     ctx = ctxs[c.name]
-    n = 1 << 18
+    n = 1 << log2n
     ck = CommitterKey.generate(ctx, 0x5EED1002, n)
     assert ck.precomputed
     dv = ctx.random_vector(0x5EED0003, n, mont=False)
