@@ -1,4 +1,5 @@
-// Unsaturated-limb Montgomery arithmetic for the base field of the MSM hot loop (gfx950).
+// Unsaturated-limb Montgomery arithmetic for the base fields of the MSM hot loop (gfx950): Pallas Fq on 9 x 29 bits,
+// BLS12-381 Fq on 14 x 28 bits.
 //
 // gfx950 has no carry-in on v_mad_u64_u32 and a VALU carry write costs wait states, so the saturated 8 x 32-bit
 // schedule (fp_mul_gfx950.h) pays one v_addc per product.  Here an element is L limbs of B bits (Pallas Fq: 9 x 29,
@@ -35,6 +36,20 @@ struct PallasFqU {
   AMSM_TABLE(one, 9, 0x1fffff81u, 0x14a5d367u, 0x141ad3c0u, 0x1435eec5u, 0x1ffeefefu, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x003fffffu)
   AMSM_TABLE(k_import, 9, 0x1ffff001u, 0x10f30767u, 0x0ecfe231u, 0x0db0ce73u, 0x1fddbb8bu, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x003fffffu)
   AMSM_TABLE(k_export, 9, 0x1ffffffdu, 0x03c369c7u, 0x06452b4du, 0x186a17c8u, 0x1ffff992u, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x003fffffu)
+};
+
+struct Bls12381Fq;
+struct Bls12381FqU {  // 14 x 28 bits, R' = 2^392 ~ 2520 p: measured against the saturated schedule in tools/fp_bench.hip
+  using Sat = Bls12381Fq;
+  static constexpr int L = 14;
+  static constexpr int W = 12;
+  static constexpr int B = 28;
+  static constexpr bool UNSAT = true;
+  static constexpr u32 NINV = 0x0ffcfffdu;
+  AMSM_TABLE(mod, 14, 0x0fffaaabu, 0x0fefffffu, 0x03ffffb9u, 0x0fffeb15u, 0x06241eabu, 0x0a0f6b0fu, 0x0f6730d2u, 0x0f38512bu, 0x04774b84u, 0x04bacd76u, 0x0ba7b643u, 0x0e69a4b1u, 0x01ea397fu, 0x0001a011u)
+  AMSM_TABLE(one, 14, 0x0347fcb8u, 0x0d800000u, 0x0002b119u, 0x00cde6d2u, 0x0c7212e0u, 0x083a2090u, 0x0037669fu, 0x0da0f73eu, 0x09b09b42u, 0x01297bb0u, 0x0515d98fu, 0x0012ca7cu, 0x0659fcfau, 0x0000577au)
+  AMSM_TABLE(k_import, 14, 0x080e6299u, 0x03500034u, 0x0eb12856u, 0x0deb2699u, 0x0c988670u, 0x04ef6697u, 0x070983e8u, 0x0a4e6fe9u, 0x03e8a053u, 0x0ecf271eu, 0x0c20d323u, 0x06eb6385u, 0x047f1286u, 0x000156dau)
+  AMSM_TABLE(k_export, 14, 0x0002fffdu, 0x00900000u, 0x0c000276u, 0x0000bc40u, 0x08baebf4u, 0x05753c75u, 0x055f4898u, 0x07052574u, 0x07ce5853u, 0x056ec6d7u, 0x071a97a2u, 0x0e4935c0u, 0x0ec3fa80u, 0x00015f65u)
 };
 
 template <class P>

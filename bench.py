@@ -200,7 +200,7 @@ def main() -> int:
     return 0
 
 
-ALU_PEAK_GMADD = {"pallas": 18.7, "bls12_381_g1": 5.2}  # isolated xyzz_madd, all SIMDs busy (tools/fp_bench.hip)
+ALU_PEAK_GMADD = {"pallas": 18.7, "bls12_381_g1": 6.95}  # isolated xyzz_madd, all SIMDs busy (tools/fp_bench.hip)
 
 
 def alu_roofline(args, ck, n, kernel_ms):

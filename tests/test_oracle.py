@@ -62,16 +62,17 @@ def test_device_field_tables_match_oracle():
         assert inv == (-pow(m, -1, 1 << 32)) % (1 << 32)
 
 
-def test_device_unsaturated_field_tables_match_oracle():
-    """The 9 x 29-bit tables of the unsaturated Pallas base field (csrc/fpu.h): modulus, R' = 2^261, and the two
-    constants that convert between the C-ABI Montgomery radix 2^256 and R'."""
+@pytest.mark.parametrize("pack,modulus", [("PallasFqU", o.PALLAS.p), ("Bls12381FqU", o.BLS12_381_G1.p)])
+def test_device_unsaturated_field_tables_match_oracle(pack, modulus):
+    """The B-bit-limb tables of the unsaturated base fields (csrc/fpu.h): modulus, R' = 2^(B L), and the two constants
+    that convert between the C-ABI Montgomery radix 2^(32 W) and R'."""
     src = open(os.path.join(os.path.dirname(__file__), "..", "accumulation_amd", "csrc", "fpu.h")).read()
-    blk = src[src.index("struct PallasFqU {"):]
+    blk = src[src.index("struct " + pack + " {"):]
     blk = blk[:blk.index("};")]
     L = int(re.search(r"int L = (\d+);", blk).group(1))
     B = int(re.search(r"int B = (\d+);", blk).group(1))
     W = int(re.search(r"int W = (\d+);", blk).group(1))
-    m = o.PALLAS.p
+    m = modulus
 
     def tab(t):
         mm = re.search(r"AMSM_TABLE\(" + t + r", \d+, ([^)]*)\)", blk, re.S)
@@ -86,8 +87,9 @@ def test_device_unsaturated_field_tables_match_oracle():
     assert tab("k_export") == R_abi % m                               # mont_mul(x R_dev, k) = x R_abi
     ninv = int(re.search(r"NINV = (0x[0-9a-f]+)u", blk).group(1), 16)
     assert ninv == (-pow(m, -1, 1 << B)) % (1 << B)
-    # headroom the bound comments in ec.h rely on: 2^(B L) >= 127 p
+    # headroom the bound comments in ec.h rely on: 2^(B L) >= 127 p; column sums of two products fit 64 bits
     assert R_dev // m >= 127
+    assert 2 * L * (1 << (2 * B + 1)) + L * (1 << (2 * B)) < (1 << 64)
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256, MINW) kern(u32* out, int iters) {
   x.v[P::L - 1] &= 0x0fffffffu; y.v[P::L - 1] &= 0x0fffffffu;
   if constexpr (P::UNSAT) {  // tight limbs, value < 2^254
     for (int i = 0; i < P::L; i++) { x.v[i] &= u_mask<P>(); y.v[i] &= u_mask<P>(); }
-    x.v[P::L - 1] &= 0x003fffffu; y.v[P::L - 1] &= 0x003fffffu;
+    x.v[P::L - 1] &= (P::L == 9 ? 0x003fffffu : 0x00000fffu); y.v[P::L - 1] &= (P::L == 9 ? 0x003fffffu : 0x00000fffu);
   }
   if constexpr (MODE == 0) {  // dependent multiplication chain
     for (int i = 0; i < iters; i++) x = fe_mul<P>(x, y);
@@ -69,6 +69,9 @@ int main() {
     run<PallasFqU, 3, 4>("pallas 9x29 xyzz_madd (<=128 VGPR)", w, 400, 1, d_out);
     run<Bls12381Fq, 0>("bls12-381 fe_mul (asm)", w, 1000, 1, d_out);
     run<Bls12381Fq, 3>("bls12-381 xyzz_madd", w, 200, 1, d_out);
+    run<Bls12381FqU, 0>("bls12-381 14x28 fe_mul", w, 1000, 1, d_out);
+    run<Bls12381FqU, 4>("bls12-381 14x28 fe_sqr", w, 1000, 1, d_out);
+    run<Bls12381FqU, 3>("bls12-381 14x28 xyzz_madd", w, 200, 1, d_out);
   }
   return 0;
 }
