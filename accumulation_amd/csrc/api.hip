@@ -158,11 +158,8 @@ int choose_window(size_t n, bool precomp) {
   static const int good[13] = {4, 5, 6, 7, 8, 8, 10, 10, 10, 13, 13, 15, 16};  // index c - 4
   return good[c - 4];
 }
-// Both scalar fields are 255 bits wide.  Windows below the top one use signed digits (|d| <= 2^(c-1), carry into the
-// next window); the top window is unsigned, so W = ceil(255 / c) windows suffice.  Only when c divides 255 can the top
-// digit exceed the 2^(c-1) buckets: the excess becomes a second entry on the same table row (slot W).
-inline int windows_for(int c) { return (255 + c - 1) / c; }
-inline int slots_for(int c) { return windows_for(c) + (windows_for(c) * c == 255 ? 1 : 0); }
+inline int windows_for(int c) { return 255 / c + 1; }  // W*c >= 256 (signed digits need one spare bit)
+inline int slots_for(int c) { return windows_for(c); }   // entry slots per scalar
 
 template <class Fq>
 constexpr size_t affine_bytes() {

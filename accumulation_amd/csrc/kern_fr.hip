@@ -36,7 +36,19 @@ static PrepGeom prep_geom(const MsmGeom& g) {
   // the entry word has 31 bits for index + bucket-id low bits: trade partition size for partitions when it is tight
   while (pg.IB + pg.SH > 31u && pg.SH > 0u && ((g.B + (1u << (pg.SH - 1)) - 1u) >> (pg.SH - 1)) <= PREP_MAX_P) pg.SH--;
   pg.P = (g.B + (1u << pg.SH) - 1u) >> pg.SH;
+  // k_prep_local stages a partition in LDS when it fits: a 148 KiB budget (counters + scan words + entries; one
+  // 1024-lane workgroup per CU) holds the ~32 k entries of one of 512 partitions at 2^20 pairs with 4 k to spare
+  const u32 budget_words = 37888u, fixed_words = 2u * (1u << pg.SH) + 1024u;
+  pg.CAP = budget_words > fixed_words + 4096u ? budget_words - fixed_words : 0u;
   return pg;
+}
+static size_t prep_local_lds(const PrepGeom& pg) { return (2 * (size_t)(1u << pg.SH) + 1024 + pg.CAP) * sizeof(u32); }
+// more than 64 KiB of dynamic LDS needs the attribute once per process
+static bool prep_local_attr_done = false;
+static void prep_local_attr() {
+  if (prep_local_attr_done) return;
+  (void)hipFuncSetAttribute((const void*)k_prep_local, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  prep_local_attr_done = true;
 }
 bool prep_supported(const MsmGeom& g) {
   if (g.n == 0 || g.S > 32u) return false;  // S > 32 <=> c < 8: tiny problems, the rocPRIM chain is fine there
@@ -54,6 +66,7 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
   template <>                                                                                                        \
   int launch_prep<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBuffers& b) {               \
     PrepGeom pg = prep_geom(g);                                                                                      \
+    prep_local_attr();                                                                                               \
     u32* part_total = b.d_small;                                                                                     \
     u32* part_start = b.d_small + (PREP_MAX_P + 1);                                                                  \
     u32* part_cursor = b.d_small + 2 * (PREP_MAX_P + 1);                                                             \
@@ -75,7 +88,7 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
     else                                                                                                             \
       hipLaunchKernelGGL((k_prep_scatter<FR, 32, 1>), dim3(blocks), dim3(256), lds_scatter, st, scalars, mont, g, pg, \
                          part_start, part_cursor, b.part);                                                           \
-    hipLaunchKernelGGL(k_prep_local, dim3(pg.P), dim3(1024), (2 * (1u << pg.SH) + 1024) * sizeof(u32), st,           \
+    hipLaunchKernelGGL(k_prep_local, dim3(pg.P), dim3(1024), prep_local_lds(pg), st,                                 \
                        part_start, b.part, g, pg, b.vals_sorted, b.start, b.items, b.item_off, part_items);          \
     hipLaunchKernelGGL(k_prep_offsets, dim3(cdiv_(g.B, 256)), dim3(256), (pg.P + 256) * sizeof(u32), st, part_start, \
                        part_items, pg, g, b.start, b.items, b.item_off, b.vals_sorted);                              \

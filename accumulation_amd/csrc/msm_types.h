@@ -13,8 +13,8 @@ constexpr int HP_MAX_INPUTS = 8;  // max inputs+accumulators of one hp_as t-vect
 struct MsmGeom {
   u32 n;             // pairs in this call
   u32 c;             // window bits (2..24)
-  u32 W;             // windows = ceil(255 / c)
-  u32 S;             // entry slots per scalar: W, or W + 1 when c divides 255 (the unsigned top window can spill)
+  u32 W;             // windows = floor(255 / c) + 1
+  u32 S;             // entry slots per scalar (= W)
   u32 nb;            // buckets per set = 2^(c-1)
   u32 n_sets;        // bucket sets = groups * (1 when precomputed, else W)
   u32 groups;        // 1, or 2: scalar i adds into the sum of group (i >> group_shift) & 1 (two MSMs in one pass)

@@ -31,6 +31,7 @@ struct PrepGeom {
   u32 P;    // partitions = ceil(B / 2^SH)
   u32 SPB;  // scalars per workgroup of k_prep_hist / k_prep_scatter (256 lanes x 2)
   u32 IB;   // bits of a table index (entry word: negate | bucket id low bits << IB | index)
+  u32 CAP;  // entries k_prep_local can assemble in LDS (larger partitions scatter straight to memory)
 };
 
 constexpr u32 PREP_ENTRY_LAST = 0x40000000u;  // == ENTRY_LAST of msm_kernels.h
@@ -56,9 +57,11 @@ AMSM_DEV u32 lds_count(u32* ctr, u32 idx) {
   return atomicAdd(&ctr[idx], 1u);
 }
 
-// Calls f(key, value) for every non-zero digit of scalar i (signed c-bit digits, the top window unsigned); returns
-// non-zero when the scalar does not fit W windows (caller reports AMSM_E_SCALAR_RANGE).  key = bucket id, value =
-// sign | index into the key table.  At most g.S entries per scalar.
+// Calls f(key, value) for every non-zero signed c-bit digit of scalar i; returns non-zero when the scalar does not
+// fit W windows (caller reports AMSM_E_SCALAR_RANGE).  key = bucket id, value = sign | index into the key table.
+// (An unsigned top window -- W = ceil(255 / c) windows, the digit excess over the bucket count as a second entry --
+// was built and measured: c = 17 / W = 15 is no faster than c = 16 / W = 16 at any size, and the extra branch in the
+// unrolled walk cost k_prep_scatter 30 us; dropped.)
 template <class Fr, class F>
 AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const MsmGeom& g, u32 i, F&& f) {
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
@@ -66,32 +69,25 @@ AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const Msm
   const u32 c = g.c;
   const u32 mask = (1u << c) - 1u;
   const u32 half = 1u << (c - 1);
+  // first bucket set of this scalar's group (grouped MSM: two sums over index classes in one pass)
+  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W);
   u32 carry = 0;
   for (u32 w = 0; w < g.W; w++) {
     u32 raw = (s.v[0] & mask) + carry;
 #pragma unroll
     for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
     s.v[7] >>= c;
-    u32 set = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W) + (g.precomp ? 0u : w);
+    u32 set = set0 + (g.precomp ? 0u : w);
     u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
+    u32 neg = 0;
     carry = 0;
-    if (w + 1 == g.W) {
-      // top window: taken unsigned (no carry out of the scalar), so its digit can reach 2^c = 2 nb when c divides
-      // the scalar width; the excess over nb becomes a second entry on the same table row
-      u32 d1 = min(raw, half), d2 = raw - d1;
-      if (d2 > (g.S > g.W ? half : 0u)) carry = 1;  // not representable: reported through `rest` below
-      if (d1) f(set * g.nb + (d1 - 1), idx);
-      if (d2 && g.S > g.W) f(set * g.nb + (min(d2, half) - 1), idx);
-    } else {
-      u32 neg = 0;
-      u32 d = raw;
-      if (raw > half) {
-        d = (1u << c) - raw;
-        neg = 1;
-        carry = 1;
-      }
-      if (d != 0) f(set * g.nb + (d - 1), idx | (neg << 31));
+    u32 d = raw;
+    if (raw > half) {
+      d = (1u << c) - raw;
+      neg = 1;
+      carry = 1;
     }
+    if (d != 0) f(set * g.nb + (d - 1), idx | (neg << 31));
   }
   u32 rest = carry;
 #pragma unroll
@@ -108,6 +104,8 @@ AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont,
   const u32 c = g.c;
   const u32 mask = (1u << c) - 1u;
   const u32 half = 1u << (c - 1);
+  // first bucket set of this scalar's group (grouped MSM: two sums over index classes in one pass)
+  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W);
   u32 carry = 0;
 #pragma unroll
   for (int w = 0; w < MAXW; w++) {
@@ -116,25 +114,17 @@ AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont,
 #pragma unroll
       for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
       s.v[7] >>= c;
-      u32 set = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W) + (g.precomp ? 0u : (u32)w);
+      u32 set = set0 + (g.precomp ? 0u : (u32)w);
       u32 idx = g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
+      u32 neg = 0;
       carry = 0;
-      if ((u32)w + 1 == g.W) {  // unsigned top window, see scalar_entries; the spill uses slot w + 1 (= W < MAXW)
-        u32 d1 = min(raw, half), d2 = raw - d1;
-        if (d1) f(w, set * g.nb + (d1 - 1), idx);
-        if (w + 1 < MAXW) {
-          if (d2 && g.S > g.W) f(w + 1, set * g.nb + (min(d2, half) - 1), idx);
-        }
-      } else {
-        u32 neg = 0;
-        u32 d = raw;
-        if (raw > half) {
-          d = (1u << c) - raw;
-          neg = 1;
-          carry = 1;
-        }
-        if (d != 0) f(w, set * g.nb + (d - 1), idx | (neg << 31));
+      u32 d = raw;
+      if (raw > half) {
+        d = (1u << c) - raw;
+        neg = 1;
+        carry = 1;
       }
+      if (d != 0) f(w, set * g.nb + (d - 1), idx | (neg << 31));
     }
   }
 }
@@ -203,6 +193,8 @@ __global__ void __launch_bounds__(1024) k_prep_scan(const u32* __restrict__ part
 // 360 us at 2^20 pairs (33 M partial-line write transactions); staged it is bandwidth bound.
 // dynamic LDS: 3 * P words + SPB * W words (staged entries) + SPB * W half-words (their partition).
 // SPT = scalars per lane (SPB = blockDim * SPT), MAXW >= S (entry slots per scalar); SPB * S <= 8192.
+// (Tried: 1024 partitions -> 32-byte runs, 162 us instead of 82; 1024 scalars per workgroup with 108 KiB of LDS to get
+// the 64-byte runs back, 110 us and a slower batch.  512 partitions x 512 scalars it is.)
 template <class Fr, int MAXW, int SPT>
 __global__ void __launch_bounds__(512)
     k_prep_scatter(const u32* __restrict__ scalars, int mont, MsmGeom g, PrepGeom pg, const u32* __restrict__ part_start,
@@ -281,7 +273,7 @@ __global__ void __launch_bounds__(512)
 
 // One workgroup (1024 lanes: a partition is ~32 k entries and there are only ~512 of them) per partition: counting
 // sort by the bucket id's low bits with LDS counters; entries go straight to their final position.
-// dynamic LDS: 2 * 2^SH words (per-bucket count -> end, offset -> cursor) + blockDim scan words.
+// dynamic LDS: 2 * 2^SH words (per-bucket count -> end, offset -> cursor) + blockDim scan words + CAP staged entries.
 __global__ void __launch_bounds__(1024)
     k_prep_local(const u32* __restrict__ part_start, const u32* __restrict__ part, MsmGeom g, PrepGeom pg,
                  u32* __restrict__ vals_sorted, u32* __restrict__ start, u32* __restrict__ items, u32* __restrict__ item_off,
@@ -366,12 +358,18 @@ __global__ void __launch_bounds__(1024)
   if (t == T - 1) part_items[p] = sl[T - 1];
   __syncthreads();
   // final placement; the entry that lands on the last position of its bucket carries the flag
+  // Partitions of the usual size are assembled in LDS and written out as one coalesced stream: 16.8 M scattered
+  // 4-byte stores cost ~62 us of L2 write transactions at 2^20 pairs, the staged copy is bandwidth bound.  Oversized
+  // (skewed) partitions scatter straight to memory.
+  u32* stage = prep_lds + 2 * NB + T;
+  const bool staged = (pe - ps) <= pg.CAP;
   auto place = [&](u32 e) {
     u32 k = (e >> pg.IB) & low;
     u32 pos = skew ? lds_count(off, k) : atomicAdd(&off[k], 1u);
     u32 v = (e & 0x80000000u) | (e & idx_mask);
     if (pos + 1 == cnt[k]) v |= PREP_ENTRY_LAST;
-    vals_sorted[ps + pos] = v;
+    if (staged) stage[pos] = v;
+    else vals_sorted[ps + pos] = v;
   };
   for (u32 j = ps + t; j < body_lo; j += T) place(part[j]);
   for (u32 j = body_lo + 4u * t; j < body_hi; j += 4u * T) {
@@ -382,6 +380,19 @@ __global__ void __launch_bounds__(1024)
     place(e4.w);
   }
   for (u32 j = body_hi + t; j < pe; j += T) place(part[j]);
+  if (staged) {
+    __syncthreads();
+    const u32 n_p = pe - ps;
+    // 16-byte aligned body of the OUTPUT range, scalar head / tail
+    const u32 o_lo = min((ps + 3u) & ~3u, pe), o_hi = max(o_lo, pe & ~3u);
+    for (u32 j = ps + t; j < o_lo; j += T) vals_sorted[j] = stage[j - ps];
+    for (u32 j = o_lo + 4u * t; j < o_hi; j += 4u * T) {
+      u32 q = j - ps;
+      *reinterpret_cast<uint4*>(vals_sorted + j) = make_uint4(stage[q], stage[q + 1], stage[q + 2], stage[q + 3]);
+    }
+    for (u32 j = o_hi + t; j < pe; j += T) vals_sorted[j] = stage[j - ps];
+    (void)n_p;
+  }
 }
 
 // item_off[b] += partials of the partitions before b's; closes start[] / items[] / item_off[] at index B and zeroes

@@ -239,35 +239,26 @@ __global__ void __launch_bounds__(256)
   const u32 c = g.c;
   const u32 mask = (1u << c) - 1u;
   const u32 half = 1u << (c - 1);
+  // first bucket set of this scalar's group (grouped MSM: two sums over index classes in one pass)
+  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W);
   u32 carry = 0;
   for (u32 w = 0; w < g.W; w++) {
     u32 raw = (s.v[0] & mask) + carry;
 #pragma unroll
     for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
     s.v[7] >>= c;
-    u32 set = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W) + (g.precomp ? 0u : w);
+    u32 set = set0 + (g.precomp ? 0u : w);
     u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
+    u32 neg = 0;
     carry = 0;
-    if (w + 1 == g.W) {  // unsigned top window (prep_kernels.h: scalar_entries); the spill has its own slot W
-      u32 d1 = min(raw, half), d2 = raw - d1;
-      if (d2 > (g.S > g.W ? half : 0u)) carry = 1;  // not representable: reported through `rest` below
-      keys[(size_t)w * g.n + i] = (KeyT)(d1 ? set * g.nb + (d1 - 1) : g.B);
-      vals[(size_t)w * g.n + i] = idx;
-      if (g.S > g.W) {
-        keys[(size_t)g.W * g.n + i] = (KeyT)(d2 ? set * g.nb + (min(d2, half) - 1) : g.B);
-        vals[(size_t)g.W * g.n + i] = idx;
-      }
-    } else {
-      u32 neg = 0;
-      u32 d = raw;
-      if (raw > half) {
-        d = (1u << c) - raw;
-        neg = 1;
-        carry = 1;
-      }
-      keys[(size_t)w * g.n + i] = (KeyT)(d == 0 ? g.B : set * g.nb + (d - 1));
-      vals[(size_t)w * g.n + i] = idx | (neg << 31);
+    u32 d = raw;
+    if (raw > half) {
+      d = (1u << c) - raw;
+      neg = 1;
+      carry = 1;
     }
+    keys[(size_t)w * g.n + i] = (KeyT)(d == 0 ? g.B : set * g.nb + (d - 1));
+    vals[(size_t)w * g.n + i] = idx | (neg << 31);
   }
   u32 rest = carry;
 #pragma unroll

@@ -417,11 +417,10 @@ def test_chunk_length_override(cref, k0):
 
 
 @pytest.mark.parametrize("prep", ["rocprim", "custom"])
-def test_top_window_spill(cref, prep):
-    """Window widths that divide the 255-bit scalar width (3, 5, 15, 17) take the top window unsigned: its digit can
-    exceed the 2^(c-1) buckets by up to 2^(c-1) and is then split into two entries.  Scalars at and around the top of
-    the field (r - 1, r - 2, 2^254 + k, all-ones low windows so that the carry reaches the top) must still match the
-    CPU oracle, with both prep chains and both key kinds."""
+def test_top_of_field_scalars(cref, prep):
+    """Window widths that divide the 255-bit scalar width (3, 5, 15, 17) leave the top window holding only the carry
+    of the signed recoding.  Scalars at and around the top of the field (r - 1, r - 2, 2^254 + k, all-ones low windows
+    so that the carry reaches the top) must match the CPU oracle, with both prep chains and both key kinds."""
     import os
     from accumulation_amd import CommitterKey, Context, VariableBaseMSM
     c = o.PALLAS
