@@ -298,8 +298,6 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   hipStream_t sm = ctx->stream;  // accumulate L0
   const u32 max_items = g.E / g.K0 + g.B + 1;
   const u32 red_blocks = cdiv(g.red_threads, 256);
-  TRY(ensure(sl->keys_a, (size_t)g.E * 4));
-  TRY(ensure(sl->keys_b, (size_t)g.E * 4));
   TRY(ensure(sl->vals_a, (size_t)g.E * 4 + 64));
   TRY(ensure(sl->vals_b, (size_t)g.E * 4 + 64));  // read in groups of 4 entries
   TRY(ensure(sl->start, (size_t)(g.B + 2) * 4));
@@ -339,6 +337,10 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
     stage_mark(ctx, sl, ST_SORT, st);
     stage_mark(ctx, sl, ST_BOUNDS, st);
   } else {
+  TRY(ensure(sl->keys_a, (size_t)g.E * 4));  // only the rocPRIM chain sorts (key, value) pairs
+  TRY(ensure(sl->keys_b, (size_t)g.E * 4));
+  keys_a = (u32*)sl->keys_a.p;
+  keys_b = (u32*)sl->keys_b.p;
   const bool keys16 = g.B < 65536u;  // every key (incl. the "digit 0" key B) fits 16 bits
   launch_digits<Fr>(st, (const u32*)d_scalars, scalars_mont, g, keys_a, keys16, vals_a, d_err);
   stage_mark(ctx, sl, ST_SORT, st);
