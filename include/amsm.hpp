@@ -113,6 +113,13 @@ class CommitterKey {
     check(amsm_bases_read(ctx_->get(), h_, off, n, xy.data(), nullptr), "amsm_bases_read");
     return xy;
   }
+  // key[i] + x * key[n_half + i], key to key on the device: the `key_l += key_r * xi` of the IPA opening
+  // (ark_poly_commit::ipa_pc ext, under src/ipa_pc_as/mod.rs:454).  x in Montgomery form.
+  CommitterKey fold(size_t n_half, const Fr& x_mont, unsigned nbits = 255) const {
+    CommitterKey k(*ctx_);
+    check(amsm_bases_fold(ctx_->get(), h_, n_half, x_mont.data(), nbits, &k.h_), "amsm_bases_fold");
+    return k;
+  }
   std::vector<uint64_t> hiding_generator;  // affine x|y (Montgomery), host side
 
  private:
@@ -143,6 +150,56 @@ struct VariableBaseMSM {
                           &inf),
           "amsm_msm_device");
     out.infinity = inf != 0;
+    return out;
+  }
+};
+
+// Several MSMs in one call (pipelined on the device).  All take device-resident Montgomery scalars.
+struct MsmBatch {
+  // the same generators, several scalar vectors (the prover's back-to-back commits, src/hp_as/mod.rs:354-388)
+  static std::vector<Affine> same_bases(const CommitterKey& bases, const std::vector<const FrVector*>& vecs) {
+    std::vector<const void*> ptrs;
+    size_t len = 0;
+    for (const FrVector* v : vecs) {
+      ptrs.push_back(v->ptr());
+      len = v->len();
+    }
+    return run(bases, ptrs.size(), [&](uint64_t* xy, uint8_t* inf) {
+      return amsm_msm_batch_device(bases.ctx().get(), bases.get(), 0, ptrs.data(), ptrs.size(), len, 1, xy, inf);
+    }, "amsm_msm_batch_device");
+  }
+  // windows of one key: job = (first generator, scalars)
+  static std::vector<Affine> windows(const CommitterKey& bases, const std::vector<std::pair<size_t, const FrVector*>>& jobs) {
+    std::vector<size_t> offs, ns;
+    std::vector<const void*> ptrs;
+    for (auto& j : jobs) {
+      offs.push_back(j.first);
+      ns.push_back(j.second->len());
+      ptrs.push_back(j.second->ptr());
+    }
+    return run(bases, jobs.size(), [&](uint64_t* xy, uint8_t* inf) {
+      return amsm_msm_multi_device(bases.ctx().get(), bases.get(), jobs.size(), offs.data(), ptrs.data(), ns.data(), 1, xy, inf);
+    }, "amsm_msm_multi_device");
+  }
+  // two sums over the index classes ((i >> group_shift) & 1) of ONE scalar vector, in one pass
+  static std::vector<Affine> grouped(const CommitterKey& bases, const FrVector& scalars, unsigned group_shift) {
+    return run(bases, 2, [&](uint64_t* xy, uint8_t* inf) {
+      return amsm_msm_grouped_device(bases.ctx().get(), bases.get(), 0, scalars.ptr(), scalars.len(), 1, group_shift, xy, inf);
+    }, "amsm_msm_grouped_device");
+  }
+
+ private:
+  template <class F>
+  static std::vector<Affine> run(const CommitterKey& bases, size_t k, F&& call, const char* where) {
+    size_t w = 2 * (size_t)bases.ctx().fq_limbs();
+    std::vector<uint64_t> xy(k * w + 1);
+    std::vector<uint8_t> inf(k + 1);
+    check(call(xy.data(), inf.data()), where);
+    std::vector<Affine> out(k);
+    for (size_t i = 0; i < k; i++) {
+      out[i].xy.assign(xy.begin() + (long)(i * w), xy.begin() + (long)((i + 1) * w));
+      out[i].infinity = inf[i] != 0;
+    }
     return out;
   }
 };

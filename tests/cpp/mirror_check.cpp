@@ -46,6 +46,21 @@ int main() {
     auto comm = hp_as::compute_product_poly_comm(ck, t);
     print_point("ppc_low0", comm.first.at(0));
     print_point("ppc_high0", comm.second.at(0));
+    // several MSMs per call: same bases, windows of the key, index classes of one vector; key-to-key fold
+    {
+      auto same = MsmBatch::same_bases(ck, {&a, &b});
+      print_point("batch_a", same.at(0));
+      print_point("batch_b", same.at(1));
+      auto grp = MsmBatch::grouped(ck, a, 3);
+      print_point("grouped_0", grp.at(0));
+      print_point("grouped_1", grp.at(1));
+      CommitterKey folded = ck.fold(500, three, 8);  // key[i] + 3 key[500 + i]
+      FrVector a500 = FrVector::random(ctx, 11, 500, true);
+      print_point("fold_commit", VariableBaseMSM::multi_scalar_mul(folded, a500));
+      auto win = MsmBatch::windows(ck, {{0, &a500}, {500, &a500}});
+      print_point("win_lo", win.at(0));
+      print_point("win_hi", win.at(1));
+    }
     // error behaviour: a key without hiding generator cannot take a randomizer
     std::vector<uint64_t> xy = ck.read(0, 4);
     CommitterKey bare = CommitterKey::load(ctx, xy, nullptr);

@@ -63,4 +63,12 @@ def test_cpp_mirror_matches_oracle(built_lib, cref):
     t = o.compute_t_vecs(c, [ai, a2i], [bi, b2i], [1, 3], n)
     assert vals["t_vecs"] == ["3", "middle_skipped", "1"]
     assert pt("ppc_low0") == msm(t[0]) and pt("ppc_high0") == msm(t[2])
+    assert pt("batch_a") == Pa and pt("batch_b") == Pb
+    g0 = [v if ((i >> 3) & 1) == 0 else 0 for i, v in enumerate(ai)]
+    g1 = [v if ((i >> 3) & 1) == 1 else 0 for i, v in enumerate(ai)]
+    assert pt("grouped_0") == msm(g0) and pt("grouped_1") == msm(g1)
+    lo = msm(ai[:500] + [0] * 500)
+    hi = msm([0] * 500 + ai[:500])
+    assert pt("win_lo") == lo and pt("win_hi") == hi
+    assert pt("fold_commit") == o.add(c, lo, o.mul(c, 3, hi))  # <a, key_l + 3 key_r> = <a, key_l> + 3 <a, key_r>
     assert vals["error_check"] == ["-1"]
