@@ -927,6 +927,33 @@ int bind_device(const amsm_ctx* ctx) {
 // =============================================================================================
 // extern "C"
 // =============================================================================================
+// Host scalar-field helpers (no device work): what a scheme driver needs for its O(#inputs) challenge arithmetic.
+template <class Fr, class F>
+static void fr_map2(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, F&& f) {
+  for (size_t i = 0; i < n; i++) {
+    host::HFe<Fr> x, y;
+    memcpy(x.v, a + 4 * i, 32);
+    if (b) memcpy(y.v, b + 4 * i, 32);
+    host::HFe<Fr> r = f(x, y);
+    memcpy(out + 4 * i, r.v, 32);
+  }
+}
+#define AMSM_FR_OP(NAME, EXPR)                                                                             \
+  static int NAME(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {                      \
+    if ((curve != AMSM_PALLAS && curve != AMSM_BLS12_381_G1) || (n && (!a || !out))) return AMSM_E_INVALID_ARG; \
+    if (curve == AMSM_PALLAS) {                                                                            \
+      using F = PallasFr;                                                                                  \
+      fr_map2<F>(a, b, n, out, [](const host::HFe<F>& x, const host::HFe<F>& y) { (void)y; return EXPR; });  \
+    } else {                                                                                               \
+      using F = Bls12381Fr;                                                                                \
+      fr_map2<F>(a, b, n, out, [](const host::HFe<F>& x, const host::HFe<F>& y) { (void)y; return EXPR; });  \
+    }                                                                                                      \
+    return AMSM_OK;                                                                                        \
+  }
+AMSM_FR_OP(amsm_fr_mul_impl, host::h_mul<F>(x, y))
+AMSM_FR_OP(amsm_fr_add_impl, host::h_add<F>(x, y))
+AMSM_FR_OP(amsm_fr_to_mont_impl, host::h_to_mont<F>(x))
+AMSM_FR_OP(amsm_fr_from_mont_impl, host::h_from_mont<F>(x))
 extern "C" {
 
 const char* amsm_strerror(int s) {
@@ -1241,6 +1268,21 @@ int amsm_host_lincomb(int curve, const uint64_t* xy, const uint8_t* is_inf, cons
   if (curve == AMSM_BLS12_381_G1)
     return host_lincomb_impl<Bls12381Fq, Bls12381Fr>(xy, is_inf, scalars_mont, n, out_xy, out_inf);
   return AMSM_E_INVALID_ARG;
+}
+
+int amsm_fr_mul(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_t n, uint64_t* out_mont) {
+  if (n && !b_mont) return AMSM_E_INVALID_ARG;
+  return amsm_fr_mul_impl(curve, a_mont, b_mont, n, out_mont);
+}
+int amsm_fr_add(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_t n, uint64_t* out_mont) {
+  if (n && !b_mont) return AMSM_E_INVALID_ARG;
+  return amsm_fr_add_impl(curve, a_mont, b_mont, n, out_mont);
+}
+int amsm_fr_to_mont(int curve, const uint64_t* canonical, size_t n, uint64_t* out_mont) {
+  return amsm_fr_to_mont_impl(curve, canonical, nullptr, n, out_mont);
+}
+int amsm_fr_from_mont(int curve, const uint64_t* a_mont, size_t n, uint64_t* out_canonical) {
+  return amsm_fr_from_mont_impl(curve, a_mont, nullptr, n, out_canonical);
 }
 
 int amsm_vec_fill(amsm_ctx* c, const uint64_t* value_mont, size_t n, void* d_out) {

@@ -66,6 +66,10 @@ SIGNATURES = {
     "amsm_pedersen_commit": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "amsm_pedersen_commit_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "amsm_host_lincomb": (C.c_int, [C.c_int, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "amsm_fr_mul": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),
+    "amsm_fr_add": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),
+    "amsm_fr_to_mont": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "amsm_fr_from_mont": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_vec_fill": (C.c_int, [_vp, _vp, _sz, _vp]),
     "amsm_dev_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "amsm_dev_free": (C.c_int, [_vp, _vp]),

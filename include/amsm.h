@@ -202,6 +202,15 @@ int amsm_hp_t_vecs(amsm_ctx* ctx, const void* const* d_a, const size_t* a_lens, 
                    const size_t* b_lens, size_t n_inputs, const uint64_t* mu_mont, size_t n_mu, const void* d_hiding_a,
                    size_t hiding_a_len, const void* d_hiding_b, size_t hiding_b_len, void* const* d_t, size_t len);
 
+/* ---- host scalar-field helpers (no device work) -------------------------------------------------------------- */
+/* Elementwise over n scalars of 4 u64 each: what a scheme driver needs for its O(#inputs) challenge arithmetic
+ * (powers and products of squeezed challenges, src/hp_as/mod.rs:233-275) without its own field code.  The
+ * canonical value must be < r for amsm_fr_to_mont. */
+int amsm_fr_mul(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_t n, uint64_t* out_mont);
+int amsm_fr_add(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_t n, uint64_t* out_mont);
+int amsm_fr_to_mont(int curve, const uint64_t* canonical, size_t n, uint64_t* out_mont);
+int amsm_fr_from_mont(int curve, const uint64_t* a_mont, size_t n, uint64_t* out_canonical);
+
 /* ---- inner-product-argument opening (ark_poly_commit::ipa_pc, ext) ------------ */
 /* Committer key living in device memory (the folded keys of the IPA rounds change every round, so they are
  * never precomputed): wraps a COPY of n affine points (Montgomery x|y, (0,0) = identity) at d_xy. */
