@@ -101,7 +101,7 @@ class CommitterKey {
     return k;
   }
   ~CommitterKey() { amsm_bases_free(h_); }
-  CommitterKey(CommitterKey&& o) noexcept : ctx_(o.ctx_), h_(o.h_), hiding_generator(std::move(o.hiding_generator)) {
+  CommitterKey(CommitterKey&& o) noexcept : hiding_generator(std::move(o.hiding_generator)), ctx_(o.ctx_), h_(o.h_) {
     o.h_ = nullptr;
   }
   CommitterKey(const CommitterKey&) = delete;
