@@ -1,0 +1,94 @@
+"""Randomised differential test of the MSM entry points against the CPU oracle (longer than the pytest suite wants to be):
+random sizes, window overrides, key kinds, base offsets, scalar distributions (uniform / few distinct / sparse / top of
+the field), single / batch / multi / grouped calls, both curves.  Usage: python tools/fuzz_msm.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402
+
+from accumulation_amd import CommitterKey, Context, VariableBaseMSM  # noqa: E402
+from oracle import cref, pyref as o  # noqa: E402
+from tests import helpers as h  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rs = np.random.RandomState(seed)
+t_end = time.time() + budget
+n_cases = 0
+ctxs = {c.name: Context(c.curve_id) for c in (o.PALLAS, o.BLS12_381_G1)}
+pools = {c.name: cref.rng_points(c.curve_id, 1000 + seed, 40000) for c in (o.PALLAS, o.BLS12_381_G1)}
+
+
+def scalars(c, n, kind):
+    base = cref.rng_scalars(int(rs.randint(1 << 30)), n)
+    if kind == "uniform":
+        return base
+    if kind == "few":
+        k = min(n, int(rs.randint(1, 5)))
+        return base[rs.randint(0, k, size=n)]
+    if kind == "sparse":
+        out = np.zeros_like(base)
+        m = rs.rand(n) < 0.05
+        out[m] = base[m]
+        return out
+    if kind == "top":
+        sp = h.scalars_to_np([c.r - 1, c.r - 2, 1 << 254, (1 << 254) - 1, 1, 0, (1 << 128) - 1])
+        return sp[rs.randint(0, len(sp), size=n)]
+    raise ValueError(kind)
+
+
+while time.time() < t_end:
+    c = o.PALLAS if rs.rand() < 0.7 else o.BLS12_381_G1
+    ctx = ctxs[c.name]
+    n_key = int(rs.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4097, 20000, 40000]))
+    n_key = min(n_key, 40000)
+    xy = pools[c.name][:n_key]
+    w = int(rs.choice([0, 0, 0, 2, 3, 5, 8, 10, 13, 15, 16, 17, 19]))
+    flags = int(rs.choice([1, 2]))
+    ctx.set_window(w)
+    ck = CommitterKey.load(ctx, xy, None, flags)
+    kind = str(rs.choice(["uniform", "few", "sparse", "top"]))
+    mode = str(rs.choice(["single", "batch", "multi", "grouped"]))
+    off = int(rs.randint(0, n_key)) if rs.rand() < 0.3 else 0
+    n = int(rs.randint(1, n_key - off + 1))
+    tag = (c.name, n_key, w, flags, kind, mode, off, n)
+    if mode == "single":
+        sc = scalars(c, n, kind)
+        out, inf = VariableBaseMSM.multi_scalar_mul(ck, sc, base_off=off)
+        ref, rinf = cref.msm(c.curve_id, xy[off:off + n], sc, threads=4)
+        assert inf == rinf and np.array_equal(out, ref), tag
+    elif mode == "batch":
+        vs = [scalars(c, n, kind) for _ in range(int(rs.randint(1, 6)))]
+        outs, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(v) for v in vs], mont=False, base_off=off)
+        for j, v in enumerate(vs):
+            ref, rinf = cref.msm(c.curve_id, xy[off:off + n], v, threads=4)
+            assert bool(infs[j]) == rinf and np.array_equal(outs[j], ref), (tag, j)
+    elif mode == "multi":
+        jobs = []
+        for _ in range(int(rs.randint(1, 5))):
+            o2 = int(rs.randint(0, n_key))
+            n2 = int(rs.randint(1, n_key - o2 + 1))
+            jobs.append((o2, scalars(c, n2, kind)))
+        outs, infs = VariableBaseMSM.multi_scalar_mul_multi(ck, [(o2, ctx.upload(v)) for o2, v in jobs], mont=False)
+        for j, (o2, v) in enumerate(jobs):
+            ref, rinf = cref.msm(c.curve_id, xy[o2:o2 + len(v)], v, threads=4)
+            assert bool(infs[j]) == rinf and np.array_equal(outs[j], ref), (tag, j)
+    else:
+        sc = scalars(c, n, kind)
+        shift = int(rs.randint(0, 12))
+        outs, infs = VariableBaseMSM.multi_scalar_mul_grouped(ck, ctx.upload(sc), shift, mont=False, base_off=off)
+        idx = np.arange(n)
+        for g in (0, 1):
+            m = sc.copy()
+            m[((idx >> shift) & 1) != g] = 0
+            ref, rinf = cref.msm(c.curve_id, xy[off:off + n], m, threads=4)
+            assert bool(infs[g]) == rinf and np.array_equal(outs[g], ref), (tag, g)
+    ck.free()
+    ctx.set_window(0)
+    n_cases += 1
+print(f"fuzz ok: {n_cases} cases in {budget:.0f} s (seed {seed})")
