@@ -119,6 +119,17 @@ class Sha256Sponge {
     return r;
   }
 
+  // domain-separated child sponge (the reference forks per protocol, src/r1cs_nark_as/mod.rs:112-125)
+  Sha256Sponge fork(const char* domain) const {
+    std::vector<uint8_t> m(state_.begin(), state_.end());
+    m.push_back('F');
+    m.insert(m.end(), domain, domain + strlen(domain));
+    Sha256Sponge c;
+    c.state_ = Sha256::digest(m);
+    c.ctr_ = 0;
+    return c;
+  }
+
  private:
   static void push_u64(std::vector<uint8_t>& v, uint64_t x) {
     for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i)));
@@ -162,6 +173,29 @@ struct FrOps {
   Fr one() const { return to_mont(Fr{1, 0, 0, 0}); }
   Fr zero() const { return Fr{0, 0, 0, 0}; }
 };
+
+// host: sum_i scalars[i] * points[i] -> affine (scalars in Montgomery form); the O(#inputs) point arithmetic of the
+// verifiers (`combine_commitments`, src/hp_as/mod.rs:391-406)
+inline Affine host_lincomb(Context& ctx, const std::vector<const Affine*>& points, const std::vector<Fr>& scalars) {
+  size_t k = points.size(), w = 2 * (size_t)ctx.fq_limbs();
+  Affine out;
+  out.xy.assign(w, 0);
+  out.infinity = true;
+  if (k == 0) return out;
+  std::vector<uint64_t> xy(k * w);
+  std::vector<uint8_t> inf(k);
+  for (size_t i = 0; i < k; i++) {
+    std::copy(points[i]->xy.begin(), points[i]->xy.end(), xy.begin() + (long)(i * w));
+    inf[i] = points[i]->infinity ? 1 : 0;
+  }
+  uint8_t oinf = 0;
+  check(amsm_host_lincomb(amsm_ctx_curve(ctx.get()), xy.data(), inf.data(), reinterpret_cast<const uint64_t*>(scalars.data()), k,
+                          out.xy.data(), &oinf),
+        "amsm_host_lincomb");
+  out.infinity = oinf != 0;
+  if (out.infinity) std::fill(out.xy.begin(), out.xy.end(), 0);
+  return out;
+}
 
 // ---- data structures (src/hp_as/data_structures.rs) ------------------------------------------------------------
 struct InputInstance {  // :14-33
