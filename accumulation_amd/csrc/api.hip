@@ -952,6 +952,8 @@ static void fr_map2(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* ou
   }
 AMSM_FR_OP(amsm_fr_mul_impl, host::h_mul<F>(x, y))
 AMSM_FR_OP(amsm_fr_add_impl, host::h_add<F>(x, y))
+AMSM_FR_OP(amsm_fr_sub_impl, host::h_sub<F>(x, y))
+AMSM_FR_OP(amsm_fr_inv_impl, host::h_inv<F>(x))
 AMSM_FR_OP(amsm_fr_to_mont_impl, host::h_to_mont<F>(x))
 AMSM_FR_OP(amsm_fr_from_mont_impl, host::h_from_mont<F>(x))
 extern "C" {
@@ -1277,6 +1279,13 @@ int amsm_fr_mul(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_
 int amsm_fr_add(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_t n, uint64_t* out_mont) {
   if (n && !b_mont) return AMSM_E_INVALID_ARG;
   return amsm_fr_add_impl(curve, a_mont, b_mont, n, out_mont);
+}
+int amsm_fr_sub(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_t n, uint64_t* out_mont) {
+  if (n && !b_mont) return AMSM_E_INVALID_ARG;
+  return amsm_fr_sub_impl(curve, a_mont, b_mont, n, out_mont);
+}
+int amsm_fr_inv(int curve, const uint64_t* a_mont, size_t n, uint64_t* out_mont) {
+  return amsm_fr_inv_impl(curve, a_mont, nullptr, n, out_mont);
 }
 int amsm_fr_to_mont(int curve, const uint64_t* canonical, size_t n, uint64_t* out_mont) {
   return amsm_fr_to_mont_impl(curve, canonical, nullptr, n, out_mont);

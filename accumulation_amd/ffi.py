@@ -68,6 +68,8 @@ SIGNATURES = {
     "amsm_host_lincomb": (C.c_int, [C.c_int, _vp, _vp, _vp, _sz, _vp, _vp]),
     "amsm_fr_mul": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),
     "amsm_fr_add": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),
+    "amsm_fr_sub": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),
+    "amsm_fr_inv": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_fr_to_mont": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_fr_from_mont": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_vec_fill": (C.c_int, [_vp, _vp, _sz, _vp]),

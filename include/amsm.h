@@ -208,6 +208,8 @@ int amsm_hp_t_vecs(amsm_ctx* ctx, const void* const* d_a, const size_t* a_lens, 
  * canonical value must be < r for amsm_fr_to_mont. */
 int amsm_fr_mul(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_t n, uint64_t* out_mont);
 int amsm_fr_add(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_t n, uint64_t* out_mont);
+int amsm_fr_sub(int curve, const uint64_t* a_mont, const uint64_t* b_mont, size_t n, uint64_t* out_mont);
+int amsm_fr_inv(int curve, const uint64_t* a_mont, size_t n, uint64_t* out_mont); /* 0 -> 0 */
 int amsm_fr_to_mont(int curve, const uint64_t* canonical, size_t n, uint64_t* out_mont);
 int amsm_fr_from_mont(int curve, const uint64_t* a_mont, size_t n, uint64_t* out_canonical);
 

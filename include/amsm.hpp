@@ -71,6 +71,14 @@ class FrVector {
     if (p_) amsm_dev_free(ctx_->get(), p_);
   }
   FrVector(FrVector&& o) noexcept : ctx_(o.ctx_), n_(o.n_), p_(o.p_) { o.p_ = nullptr; }
+  FrVector& operator=(FrVector&& o) noexcept {
+    if (this != &o) {
+      if (p_) amsm_dev_free(ctx_->get(), p_);
+      ctx_ = o.ctx_, n_ = o.n_, p_ = o.p_;
+      o.p_ = nullptr;
+    }
+    return *this;
+  }
   FrVector(const FrVector&) = delete;
   FrVector& operator=(const FrVector&) = delete;
   size_t len() const { return n_; }

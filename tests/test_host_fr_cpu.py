@@ -32,4 +32,9 @@ def test_host_fr_helpers(built_lib, c):
     ffi.check(lib.amsm_fr_add(c.curve_id, _ptr(am), _ptr(bm), n, _ptr(summ)), "add")
     assert h.np_to_ints(prod) == [x * y * R % c.r for x, y in zip(vals_a, vals_b)]
     assert h.np_to_ints(summ) == [(x + y) * R % c.r for x, y in zip(vals_a, vals_b)]
+    diff, inv = np.zeros_like(a), np.zeros_like(a)
+    ffi.check(lib.amsm_fr_sub(c.curve_id, _ptr(am), _ptr(bm), n, _ptr(diff)), "sub")
+    ffi.check(lib.amsm_fr_inv(c.curve_id, _ptr(am), n, _ptr(inv)), "inv")
+    assert h.np_to_ints(diff) == [(x - y) * R % c.r for x, y in zip(vals_a, vals_b)]
+    assert h.np_to_ints(inv) == [(pow(x, -1, c.r) if x else 0) * R % c.r for x in vals_a]
     assert lib.amsm_fr_mul(7, _ptr(am), _ptr(bm), n, _ptr(prod)) == ffi.AMSM_E_INVALID_ARG
