@@ -195,6 +195,37 @@ def run_template(env, num_inputs_per_iteration, make_zk, num_iterations=NUM_ITER
 
 
 @pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
+def test_ipa_pc_as_bls12_381(make_zk):
+    """BASELINE config 2's curve (384-bit base field, 255-bit scalars): the commitment against the oracle, open / check and
+    the accumulation template's busiest scenario."""
+    from accumulation_amd import Context, ffi
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
+    from accumulation_amd.scalar_field import Fr
+    c = o.BLS12_381_G1
+    ctx = Context(ffi.AMSM_BLS12_381_G1)
+    fr = Fr(ctx.curve)
+    pp = IpaPC.setup(ctx, DEGREE, seed=0xB15)
+    ck, vk = IpaPC.trim(pp, DEGREE)
+    rng = SchemeRng(1234)
+    coeffs = [rng.field() % c.r for _ in range(DEGREE + 1)]
+    poly = ctx.upload(fr.to_limbs_many(coeffs))
+    comm, rand = IpaPC.commit(ck, poly, make_zk, rng)
+    xy, _ = ck.comm_key.read()
+    gens = [h.np_to_point(c, xy[i], 0) for i in range(16)]
+    exp = o.msm_naive(c, gens[:12], coeffs)
+    if make_zk:
+        exp = o.add(c, exp, o.mul(c, rand, h.np_to_point(c, ck.s[0], 0)))
+    assert h.np_to_point(c, *comm.comm) == exp
+    point = rng.field() % c.r
+    value = sum(cf * pow(point, i, c.r) for i, cf in enumerate(coeffs)) % c.r
+    proof = IpaPC.open(ck, poly, comm, point, rand, make_zk, rng)
+    assert IpaPC.check(vk, comm, point, value, proof)
+    assert not IpaPC.check(vk, comm, point, (value + 1) % c.r, proof)
+    assert run_template((ctx, pp), [1, 1, 2, 3], make_zk, num_iterations=1)
+    ctx.close()
+
+
+@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
 class TestASForIpaPC:
     def test_single_input_init(self, env, make_zk):
         assert run_template(env, [1], make_zk)
