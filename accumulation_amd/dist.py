@@ -30,7 +30,7 @@ class HipEngine:
         import torch
         self.ctx, self.ck = ctx, ck
         self.record_bytes = int(ctx._lib.amsm_partial_bytes(ctx._h))
-        self._partial = torch.zeros(self.record_bytes, dtype=torch.uint8, device=f"cuda:{ctx.device}")
+        self._partial = torch.empty(self.record_bytes, dtype=torch.uint8, device=f"cuda:{ctx.device}")
 
     def partial(self, scalars, mont: bool):
         """scalars: FrVector (this rank's slice).  Returns a uint8 CUDA tensor holding the record."""
@@ -55,7 +55,8 @@ class HipEngine:
         import torch
         from . import ffi
         k = len(vecs)
-        out = torch.zeros(max(k, 1) * self.record_bytes, dtype=torch.uint8, device=f"cuda:{self.ctx.device}")
+        # torch.empty: no fill kernel on torch's stream that could land after the engine's write on its own stream
+        out = torch.empty(max(k, 1) * self.record_bytes, dtype=torch.uint8, device=f"cuda:{self.ctx.device}")
         ptrs = (C.c_void_p * max(k, 1))(*[v.ptr for v in vecs])
         ffi.check(self.ctx._lib.amsm_msm_partial_batch_device(self.ctx._h, self.ck._h, 0, ptrs, k, vecs[0].n if k else 0,
                                                               1 if mont else 0, C.c_void_p(out.data_ptr())),
@@ -84,6 +85,14 @@ class ShardedMSM:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._gathered = None
 
+    @staticmethod
+    def _settle(t):
+        """The engine reads the gathered records on ITS stream: finish torch's (the collective and the regrouping copy
+        are ordered on torch's current stream) before handing the buffer over."""
+        if t.is_cuda:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+
     def msm(self, local_scalars, mont: bool = True):
         import torch
         import torch.distributed as dist
@@ -93,6 +102,7 @@ class ShardedMSM:
         if self._gathered is None or self._gathered.numel() != part.numel() * self.world:
             self._gathered = torch.empty(part.numel() * self.world, dtype=torch.uint8, device=part.device)
         dist.all_gather_into_tensor(self._gathered, part, group=self.group)
+        self._settle(self._gathered)
         return self.engine.combine(self._gathered, self.world)
 
     def msm_batch(self, local_vecs, mont: bool = True):
@@ -113,6 +123,7 @@ class ShardedMSM:
             dist.all_gather_into_tensor(gathered, parts.contiguous(), group=self.group)
             # [rank][msm][record] -> [msm][rank][record]
             grouped = gathered.view(self.world, k, rec).permute(1, 0, 2).contiguous().view(-1)
+            self._settle(grouped)
         else:
             grouped = parts
         if hasattr(self.engine, "combine_batch"):
