@@ -83,7 +83,6 @@ class ShardedMSM:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self._gathered = None
 
     @staticmethod
     def _settle(t):
@@ -93,17 +92,27 @@ class ShardedMSM:
             import torch
             torch.cuda.current_stream(t.device).synchronize()
 
-    def msm(self, local_scalars, mont: bool = True):
+    def _all_gather(self, parts):
+        """All ranks' records, rank-major.  RCCL gathers device tensors in place; a CPU-only backend (gloo: the
+        2-process tests on one GPU) is fed through host memory."""
         import torch
         import torch.distributed as dist
+        if parts.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = parts.cpu()
+            out = torch.empty(host.numel() * self.world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, host, group=self.group)
+            return out.to(parts.device)
+        out = torch.empty(parts.numel() * self.world, dtype=torch.uint8, device=parts.device)
+        dist.all_gather_into_tensor(out, parts, group=self.group)
+        return out
+
+    def msm(self, local_scalars, mont: bool = True):
         part = self.engine.partial(local_scalars, mont)
         if self.world == 1:
             return self.engine.combine(part, 1)
-        if self._gathered is None or self._gathered.numel() != part.numel() * self.world:
-            self._gathered = torch.empty(part.numel() * self.world, dtype=torch.uint8, device=part.device)
-        dist.all_gather_into_tensor(self._gathered, part, group=self.group)
-        self._settle(self._gathered)
-        return self.engine.combine(self._gathered, self.world)
+        gathered = self._all_gather(part)
+        self._settle(gathered)
+        return self.engine.combine(gathered, self.world)
 
     def msm_batch(self, local_vecs, mont: bool = True):
         """len(local_vecs) whole-job MSMs with ONE exchange: every rank runs its slices back to back (pipelined on
@@ -119,8 +128,7 @@ class ShardedMSM:
             parts = torch.cat([self.engine.partial(v, mont).clone() for v in local_vecs]) if k else \
                 torch.zeros(0, dtype=torch.uint8)
         if self.world > 1:
-            gathered = torch.empty(self.world * k * rec, dtype=torch.uint8, device=parts.device)
-            dist.all_gather_into_tensor(gathered, parts.contiguous(), group=self.group)
+            gathered = self._all_gather(parts.contiguous())
             # [rank][msm][record] -> [msm][rank][record]
             grouped = gathered.view(self.world, k, rec).permute(1, 0, 2).contiguous().view(-1)
             self._settle(grouped)
@@ -134,3 +142,73 @@ class ShardedMSM:
             outs.append(o_)
             infs.append(i_)
         return np.array(outs, dtype=np.uint64), np.array(infs, dtype=bool)
+
+
+class ShardedCommitterKey:
+    """A committer key whose generators are spread over the ranks: rank r holds [lo_r, hi_r) (`shard_bounds`) as an
+    ordinary HBM-resident `engine.CommitterKey`, and every vector the schemes commit to is sharded the same way (rank r
+    holds elements [lo_r, hi_r)).  `VariableBaseMSM.multi_scalar_mul_batch` and `PedersenCommitment.commit` recognise
+    the type and go through `ShardedMSM` -- per-rank partial records, ONE all-gather per batch, identical fold on every
+    rank -- so the scheme drivers (hp_as: every O(len) step is elementwise, src/hp_as/mod.rs:278-349,482-512) run
+    unchanged on a slice and produce the accumulator instance of the unsharded run, bit for bit; the accumulator's
+    witness vectors stay sharded.  `supported_num_elems()` is the GLOBAL length (what the statement absorbs,
+    src/hp_as/mod.rs:747); `local_num_elems()` the slice.  Randomised runs need the same rng stream on every rank."""
+
+    def __init__(self, local_key, n_global: int, group=None):
+        self.local = local_key
+        self.ctx = local_key.ctx
+        self.hiding_generator = local_key.hiding_generator
+        self.n_global = int(n_global)
+        self.sharded = ShardedMSM(HipEngine(self.ctx, local_key), group)
+        lo, hi = shard_bounds(self.n_global, self.sharded.rank, self.sharded.world)
+        if hi - lo != len(local_key):
+            raise ValueError(f"rank {self.sharded.rank}: local key has {len(local_key)} generators, shard is [{lo}, {hi})")
+        self.lo, self.hi = lo, hi
+
+    @classmethod
+    def from_global(cls, ctx, xy_mont, hiding_generator=None, flags=None, group=None):
+        """Every rank passes the same global generator array (n x 2L u64) and keeps only its slice on the device."""
+        import torch.distributed as dist
+        from . import ffi
+        from .engine import CommitterKey
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        lo, hi = shard_bounds(len(xy_mont), rank, world)
+        local = CommitterKey.load(ctx, xy_mont[lo:hi], None, ffi.AMSM_BASES_DEFAULT if flags is None else flags,
+                                  hiding_generator=hiding_generator)
+        return cls(local, len(xy_mont), group)
+
+    def supported_num_elems(self) -> int:
+        return self.n_global
+
+    def local_num_elems(self) -> int:
+        return self.hi - self.lo
+
+    def __len__(self):
+        return self.n_global
+
+    def msm_batch(self, vectors, mont: bool = True):
+        """-> (k x 2L u64, k uint8): whole-job MSMs of the ranks' slices (all the same length on this rank)."""
+        outs, infs = self.sharded.msm_batch(list(vectors), mont)
+        return outs, np.asarray(infs, dtype=np.uint8)
+
+    def commit(self, elems, randomizer=None):
+        """PedersenCommitment::commit over the sharded key: msm + randomizer * hiding_generator (added once, on the host)."""
+        outs, infs = self.msm_batch([elems], True)
+        pt = (outs[0], bool(infs[0]))
+        if randomizer is None:
+            return pt
+        if self.hiding_generator is None:
+            raise ValueError("committer key has no hiding generator")
+        from . import ffi
+        from .engine import _ptr
+        from .scalar_field import Fr
+        ctx = self.ctx
+        xy = np.stack([np.asarray(pt[0], dtype=np.uint64), np.asarray(self.hiding_generator, dtype=np.uint64)])
+        infs = np.array([1 if pt[1] else 0, 0], dtype=np.uint8)
+        sc = np.stack([Fr(ctx.curve).to_limbs(1), np.ascontiguousarray(randomizer, dtype=np.uint64).reshape(4)])
+        out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+        inf = C.c_uint8(0)
+        ffi.check(ctx._lib.amsm_host_lincomb(ctx.curve, _ptr(xy), _ptr(infs), _ptr(sc), 2, _ptr(out), C.byref(inf)),
+                  "amsm_host_lincomb")
+        return out, bool(inf.value)

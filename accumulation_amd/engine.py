@@ -248,6 +248,10 @@ class CommitterKey:
         ffi.check(self.ctx._lib.amsm_bases_fold(self.ctx._h, self._h, n_half, _ptr(x), nbits, C.byref(h)), "amsm_bases_fold")
         return CommitterKey(self.ctx, h)
 
+    def local_num_elems(self) -> int:
+        """Generators resident on THIS rank (= supported_num_elems() unless the key is a dist.ShardedCommitterKey)."""
+        return self.supported_num_elems()
+
     def supported_num_elems(self) -> int:
         return int(self.ctx._lib.amsm_bases_len(self._h))
 
@@ -283,6 +287,10 @@ class VariableBaseMSM:
     @staticmethod
     def multi_scalar_mul(bases: CommitterKey, scalars, base_off: int = 0, mont: bool = False
                          ) -> Tuple[np.ndarray, bool]:
+        if hasattr(bases, "sharded"):  # dist.ShardedCommitterKey (device-resident slices only)
+            assert base_off == 0 and isinstance(scalars, FrVector)
+            outs, infs = bases.msm_batch([scalars], mont)
+            return outs[0], bool(infs[0])
         ctx = bases.ctx
         out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
         inf = C.c_uint8(0)
@@ -297,6 +305,9 @@ class VariableBaseMSM:
 
     @staticmethod
     def multi_scalar_mul_batch(bases: CommitterKey, vectors: Sequence[FrVector], mont: bool = True, base_off: int = 0):
+        if hasattr(bases, "sharded"):  # dist.ShardedCommitterKey: per-rank partials + one all-gather
+            assert base_off == 0
+            return bases.msm_batch(vectors, mont)
         ctx = bases.ctx
         k = len(vectors)
         n = vectors[0].n if k else 0
@@ -352,6 +363,8 @@ class PedersenCommitment:
     @staticmethod
     def commit(ck: CommitterKey, elems, randomizer: Optional[np.ndarray] = None) -> Tuple[np.ndarray, bool]:
         """commit(ck, &[F] (Montgomery), Option<F>) -> affine point."""
+        if hasattr(ck, "sharded"):  # dist.ShardedCommitterKey
+            return ck.commit(elems, randomizer)
         ctx = ck.ctx
         r = None if randomizer is None else np.ascontiguousarray(randomizer, dtype=np.uint64)
         hg = None

@@ -331,7 +331,7 @@ class ASForHadamardProducts:
         elif inputs:
             hp_vec_len = inputs[0].witness.a_vec.n
         else:
-            hp_vec_len = prover_key.supported_num_elems()
+            hp_vec_len = prover_key.local_num_elems()
         if num_all == 0:  # default input :685-696
             inputs.append(Accumulator(InputInstance.zero(ctx), InputWitness.zero(ctx, hp_vec_len)))
             num_all += 1
