@@ -33,16 +33,20 @@ CHALLENGE_SIZE = 128
 class Matrix:
     """Row-sparse matrix `Vec<Vec<(F, usize)>>` resident in HBM as CSR."""
 
-    def __init__(self, ctx: Context, rows: Sequence[Sequence[Tuple[int, int]]]):
-        """rows[r] = [(coeff as canonical int, column index), ...]"""
+    def __init__(self, ctx: Context, rows: Sequence[Sequence[Tuple[int, int]]], row_range: Optional[Tuple[int, int]] = None):
+        """rows[r] = [(coeff as canonical int, column index), ...].  row_range = (lo, hi): only those constraints are
+        loaded to THIS rank's device (the constraint-sharded layout of dist.ShardedCommitterKey: matrix_vec_mul then yields
+        the rank's slice of M z); the digest still covers every row."""
         self.ctx = ctx
         fr = Fr(ctx.curve)
         self.rows = [[(int(cf) % fr.r, int(i)) for cf, i in row] for row in rows]
-        row_ptr = np.zeros(len(rows) + 1, dtype=np.uint32)
+        lo, hi = row_range if row_range is not None else (0, len(rows))
+        dev_rows = self.rows[lo:hi]
+        row_ptr = np.zeros(len(dev_rows) + 1, dtype=np.uint32)
         cols: List[int] = []
         vals = []
         cache = {}
-        for r, row in enumerate(self.rows):
+        for r, row in enumerate(dev_rows):
             for coeff, idx in row:
                 if coeff not in cache:
                     cache[coeff] = fr.to_limbs(coeff)
@@ -53,10 +57,11 @@ class Matrix:
         val = np.array(vals, dtype=np.uint64).reshape(-1, 4)
         h = C.c_void_p()
         ffi.check(ctx._lib.amsm_matrix_load(ctx._h, _ptr(row_ptr), _ptr(col) if len(cols) else None,
-                                            _ptr(val) if len(cols) else None, len(rows), len(cols), C.byref(h)),
+                                            _ptr(val) if len(cols) else None, len(dev_rows), len(cols), C.byref(h)),
                   "amsm_matrix_load")
         self._h = h
-        self.n_rows = len(rows)
+        self.n_rows = len(dev_rows)      # rows resident on this rank
+        self.n_rows_global = len(rows)
 
     def serialize(self) -> bytes:
         out = [len(self.rows).to_bytes(8, "little")]
@@ -168,9 +173,12 @@ class Proof:
 
 def index(ctx: Context, a_rows, b_rows, c_rows, num_instance_variables: int, num_variables: int,
           ck: Optional[CommitterKey] = None, key_seed: int = 0x5EED1001) -> IndexProverKey:
-    """R1CSNark::index (:78-124): matrices + a Pedersen key with num_constraints generators."""
-    a, b, c = Matrix(ctx, a_rows), Matrix(ctx, b_rows), Matrix(ctx, c_rows)
-    n_con = a.n_rows
+    """R1CSNark::index (:78-124): matrices + a Pedersen key with num_constraints generators.  With a
+    dist.ShardedCommitterKey every rank keeps the constraints of its key slice: the prover, the verifier and the
+    accumulation scheme then run unchanged on slices of every constraint-length vector (the assignment is replicated)."""
+    rr = (ck.lo, ck.hi) if hasattr(ck, "sharded") else None
+    a, b, c = Matrix(ctx, a_rows, rr), Matrix(ctx, b_rows, rr), Matrix(ctx, c_rows, rr)
+    n_con = a.n_rows_global
     if ck is None:
         ck = PedersenCommitment.setup(ctx, n_con, seed=key_seed)
     info = IndexInfo(num_variables, n_con, num_instance_variables, hash_matrices(PROTOCOL_NAME, a, b, c))
