@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -728,18 +729,63 @@ int pedersen_device_impl(amsm_ctx* ctx, const amsm_bases* ck, const void* d_elem
   return AMSM_OK;
 }
 
+// Bases that recur with full-size scalars get a fixed-base table (HFixedBase) on their third use; a handful per thread
+// and field, least recently used evicted.  AMSM_HOST_FIXED_BASE=0 turns the cache off (A/B, tests).
+template <class Fq>
+struct FixedBaseCache {
+  static constexpr size_t SLOTS = 4;
+  static constexpr unsigned BUILD_AT = 3;
+  std::vector<host::HFixedBase<Fq>> entries;
+  uint64_t call = 0;  // entries touched by the current host_lincomb call (stamp == call) are never evicted
+  FixedBaseCache() { entries.reserve(SLOTS); }  // no reallocation: pointers handed out stay valid
+  const host::HFixedBase<Fq>* lookup(const uint64_t* xy, const host::HXYZZ<Fq>& p) {
+    constexpr int N = host::HFe<Fq>::N;
+    for (auto& c : entries)
+      if (memcmp(c.key, xy, 16 * N) == 0) {
+        c.stamp = call;
+        if (c.tab.empty() && ++c.uses >= BUILD_AT) c.build(p);
+        return c.tab.empty() ? nullptr : &c;
+      }
+    host::HFixedBase<Fq>* victim = nullptr;
+    if (entries.size() < SLOTS) {
+      entries.emplace_back();
+      victim = &entries.back();
+    } else {
+      for (auto& c : entries)
+        if (c.stamp != call && (!victim || c.stamp < victim->stamp)) victim = &c;
+      if (!victim) return nullptr;  // every slot is in use by this very call
+    }
+    memcpy(victim->key, xy, 16 * N);
+    victim->tab.clear();
+    victim->uses = 1;
+    victim->stamp = call;
+    return nullptr;
+  }
+};
+
 template <class Fq, class Fr>
 int host_lincomb_impl(const uint64_t* xy, const uint8_t* is_inf, const uint64_t* scalars_mont, size_t n,
                       uint64_t* out_xy, uint8_t* out_inf) {
   constexpr int N = host::HFe<Fq>::N;
-  host::HXYZZ<Fq> acc = host::hx_inf<Fq>();
+  std::vector<host::HXYZZ<Fq>> pts(n);
+  std::vector<std::array<uint64_t, 4>> ks(n);
+  std::vector<const host::HFixedBase<Fq>*> fixed(n, nullptr);
+  static const bool use_cache = [] {
+    const char* e = getenv("AMSM_HOST_FIXED_BASE");
+    return !(e && atoi(e) == 0);
+  }();
+  thread_local FixedBaseCache<Fq> cache;
+  cache.call++;
   for (size_t i = 0; i < n; i++) {
     host::HFe<Fr> s;
     memcpy(s.v, scalars_mont + 4 * i, 32);
     s = host::h_from_mont<Fr>(s);
-    host::HXYZZ<Fq> p = host::hx_from_affine<Fq>(xy + i * 2 * N, is_inf && is_inf[i]);
-    acc = host::hx_add<Fq>(acc, host::hx_mul<Fq>(p, s.v));
+    memcpy(ks[i].data(), s.v, 32);
+    pts[i] = host::hx_from_affine<Fq>(xy + i * 2 * N, is_inf && is_inf[i]);
+    if (use_cache && !host::hx_is_inf<Fq>(pts[i]) && host::hx_scalar_bits(s.v) > 128)
+      fixed[i] = cache.lookup(xy + i * 2 * N, pts[i]);
   }
+  host::HXYZZ<Fq> acc = host::hx_lincomb<Fq>(pts.data(), reinterpret_cast<const uint64_t(*)[4]>(ks.data()), n, fixed.data());
   write_affine<Fq>(acc, out_xy, out_inf);
   return AMSM_OK;
 }

@@ -8,6 +8,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "fp.h"
 
 namespace amsm {
@@ -260,15 +263,111 @@ inline void hx_to_affine(const HXYZZ<P>& p, u64* xy, uint8_t* is_inf) {
   memcpy(xy + N, y.v, 8 * N);
   *is_inf = 0;
 }
-// k * P, k = canonical 256-bit integer (4 u64), double-and-add MSB first
+// ---- scalar multiplication on the host (the O(#inputs) point algebra of the verifiers) -------------
+inline int hx_scalar_bits(const u64 k[4]) {
+  for (int i = 3; i >= 0; i--)
+    if (k[i]) return 64 * i + 64 - __builtin_clzll(k[i]);
+  return 0;
+}
+inline unsigned hx_nibble(const u64 k[4], int w) { return (unsigned)(k[w >> 4] >> ((w & 15) * 4)) & 15u; }
+
+// d * P for d = 0..15
+template <class P>
+inline void hx_small_multiples(const HXYZZ<P>& p, HXYZZ<P> tab[16]) {
+  tab[0] = hx_inf<P>();
+  tab[1] = p;
+  tab[2] = hx_dbl<P>(p);
+  for (int d = 3; d < 16; d++) tab[d] = hx_add<P>(tab[d - 1], p);
+}
+
+// k * P, k = canonical 256-bit integer (4 u64): 4-bit windows from the top non-zero one
 template <class P>
 inline HXYZZ<P> hx_mul(const HXYZZ<P>& p, const u64 k[4]) {
-  HXYZZ<P> acc = hx_inf<P>();
-  for (int i = 255; i >= 0; i--) {
-    acc = hx_dbl<P>(acc);
-    if ((k[i >> 6] >> (i & 63)) & 1) acc = hx_add<P>(acc, p);
+  int bits = hx_scalar_bits(k);
+  if (bits == 0 || hx_is_inf<P>(p)) return hx_inf<P>();
+  if (bits == 1) return p;
+  if (bits <= 8) {  // double-and-add: not worth a table
+    HXYZZ<P> acc = p;
+    for (int i = bits - 2; i >= 0; i--) {
+      acc = hx_dbl<P>(acc);
+      if ((k[0] >> i) & 1) acc = hx_add<P>(acc, p);
+    }
+    return acc;
+  }
+  HXYZZ<P> tab[16];
+  hx_small_multiples<P>(p, tab);
+  int w = (bits + 3) / 4 - 1;
+  HXYZZ<P> acc = tab[hx_nibble(k, w)];
+  for (w--; w >= 0; w--) {
+    for (int t = 0; t < 4; t++) acc = hx_dbl<P>(acc);
+    unsigned d = hx_nibble(k, w);
+    if (d) acc = hx_add<P>(acc, tab[d]);
   }
   return acc;
+}
+
+// Fixed-base table: d * 16^w * P for w < 64, d = 1..15 -> k * P is at most 64 additions, no doublings.  Building one
+// costs ~3.5 windowed multiplications; host_lincomb keeps a few for bases that recur with full-size scalars (the
+// h' = xi_0 * h of an IPA opening is multiplied 2 log2(d+1) times, ipa_pc ext under src/ipa_pc_as/mod.rs:454).
+template <class P>
+struct HFixedBase {
+  static constexpr int N = HFe<P>::N;
+  u64 key[2 * N];
+  std::vector<HXYZZ<P>> tab;  // [w * 15 + d - 1]; empty until the base has been seen often enough
+  unsigned uses = 0;
+  u64 stamp = 0;
+  void build(const HXYZZ<P>& p) {
+    tab.resize(64 * 15);
+    HXYZZ<P> base = p;
+    for (int w = 0; w < 64; w++) {
+      tab[w * 15] = base;
+      tab[w * 15 + 1] = hx_dbl<P>(base);
+      for (int d = 3; d < 16; d++) tab[w * 15 + d - 1] = hx_add<P>(tab[w * 15 + d - 2], base);
+      if (w < 63) base = hx_dbl<P>(tab[w * 15 + 7]);  // 16 * base = 2 * (8 * base)
+    }
+  }
+  HXYZZ<P> mul(const u64 k[4]) const {
+    HXYZZ<P> acc = hx_inf<P>();
+    for (int w = 0; w < 64; w++) {
+      unsigned d = hx_nibble(k, w);
+      if (d) acc = hx_add<P>(acc, tab[w * 15 + d - 1]);
+    }
+    return acc;
+  }
+};
+
+// sum_i k_i * P_i with shared doublings (Straus, 4-bit windows); k_i canonical.  `fixed` (may be null): per-point
+// fixed-base tables that replace the point's windows.
+template <class P>
+inline HXYZZ<P> hx_lincomb(const HXYZZ<P>* pts, const u64 (*ks)[4], size_t n, const HFixedBase<P>* const* fixed) {
+  HXYZZ<P> ones = hx_inf<P>();
+  std::vector<size_t> idx;
+  int top = -1;
+  for (size_t i = 0; i < n; i++) {
+    int bits = hx_scalar_bits(ks[i]);
+    if (bits == 0 || hx_is_inf<P>(pts[i])) continue;
+    if (bits == 1) {
+      ones = hx_add<P>(ones, pts[i]);
+    } else if (fixed && fixed[i]) {
+      ones = hx_add<P>(ones, fixed[i]->mul(ks[i]));
+    } else {
+      idx.push_back(i);
+      top = std::max(top, (bits + 3) / 4 - 1);
+    }
+  }
+  if (idx.empty()) return ones;
+  if (idx.size() == 1) return hx_add<P>(ones, hx_mul<P>(pts[idx[0]], ks[idx[0]]));
+  std::vector<HXYZZ<P>> tabs(idx.size() * 16);
+  for (size_t j = 0; j < idx.size(); j++) hx_small_multiples<P>(pts[idx[j]], &tabs[j * 16]);
+  HXYZZ<P> acc = hx_inf<P>();
+  for (int w = top; w >= 0; w--) {
+    for (int t = 0; t < 4; t++) acc = hx_dbl<P>(acc);
+    for (size_t j = 0; j < idx.size(); j++) {
+      unsigned d = hx_nibble(ks[idx[j]], w);
+      if (d) acc = hx_add<P>(acc, tabs[j * 16 + d]);
+    }
+  }
+  return hx_add<P>(acc, ones);
 }
 // device XYZZ record (4*L u32, little-endian) -> host
 template <class P>

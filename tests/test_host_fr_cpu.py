@@ -38,3 +38,59 @@ def test_host_fr_helpers(built_lib, c):
     assert h.np_to_ints(diff) == [(x - y) * R % c.r for x, y in zip(vals_a, vals_b)]
     assert h.np_to_ints(inv) == [(pow(x, -1, c.r) if x else 0) * R % c.r for x in vals_a]
     assert lib.amsm_fr_mul(7, _ptr(am), _ptr(bm), n, _ptr(prod)) == ffi.AMSM_E_INVALID_ARG
+
+
+@pytest.mark.parametrize("c", [o.PALLAS, o.BLS12_381_G1], ids=lambda c: c.name)
+def test_host_lincomb_vs_oracle(built_lib, c):
+    """amsm_host_lincomb (windowed, shared doublings, fixed-base tables for recurring bases) against the big-int oracle:
+    scalar edge values, infinity inputs, P + P / P - P collisions, many terms, and one base reused often enough with
+    full-size scalars to be served from a fixed-base table (built on its third use)."""
+    import ctypes as C
+    from accumulation_amd import ffi
+    from accumulation_amd.engine import _ptr
+    lib = ffi.load()
+    g = o.generator(c)
+    pts = [o.mul(c, 3 + 5 * i, g) for i in range(12)]
+
+    def lincomb(points, scalars):
+        xy, inf = h.points_to_np(c, points)
+        sc = h.fr_mont_np(c, scalars)
+        out = np.zeros((2 * c.limbs,), dtype=np.uint64)
+        oinf = C.c_uint8(0)
+        ffi.check(lib.amsm_host_lincomb(c.curve_id, _ptr(xy), _ptr(inf), _ptr(sc), len(points), _ptr(out), C.byref(oinf)),
+                  "amsm_host_lincomb")
+        return h.np_to_point(c, out, oinf.value)
+
+    def expect(points, scalars):
+        acc = None
+        for P, s in zip(points, scalars):
+            acc = o.add(c, acc, o.mul(c, s % c.r, P))
+        return acc
+
+    edge = [0, 1, 2, 15, 16, 17, 255, 256, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 128, (1 << 129) + 1, c.r - 1, c.r - 2,
+            0xF0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0 % c.r]
+    for s in edge:
+        assert lincomb([pts[0]], [s]) == expect([pts[0]], [s]), hex(s)
+    assert lincomb([], []) is None
+    assert lincomb([None, pts[1]], [5, 0]) is None
+    assert lincomb([pts[2], pts[2]], [7, c.r - 7]) is None                      # P - P
+    assert lincomb([pts[2], pts[2]], [1, 1]) == o.mul(c, 2, pts[2])             # P + P through the "ones" path
+    assert lincomb([pts[2], o.neg(c, pts[2])], [9, 9]) is None
+    for trial in range(6):
+        k = [1, 2, 3, 7, 12, 12][trial]
+        sc = [o.rng_scalar(50 + trial, i) % c.r for i in range(k)]
+        if trial == 5:
+            sc = [s % (1 << 128) for s in sc]  # the schemes' 128-bit challenges
+        assert lincomb(pts[:k], sc) == expect(pts[:k], sc), trial
+    base = o.mul(c, 0xABCDEF, g)
+    for use in range(8):  # third use onwards: fixed-base table
+        s, t = o.rng_scalar(70, use) % c.r, o.rng_scalar(71, use) % c.r
+        assert lincomb([pts[use], base], [t, s]) == expect([pts[use], base], [t, s]), use
+    for s in (c.r - 1, (1 << 200) + 1, 1 << 252):
+        assert lincomb([base], [s]) == o.mul(c, s, base)
+    # more recurring bases than cache slots, several of them inside one call: eviction must never corrupt a result
+    bases = [o.mul(c, 1000 + 17 * i, g) for i in range(7)]
+    for rnd in range(12):
+        sel = [bases[(rnd + j) % 7] for j in range(1 + rnd % 6)]
+        sc = [o.rng_scalar(90 + rnd, j) % c.r for j in range(len(sel))]
+        assert lincomb(sel, sc) == expect(sel, sc), rnd
