@@ -29,6 +29,9 @@ from .scalar_field import Fr
 from .sponge import CryptographicSponge, Sha256Sponge
 
 CHALLENGE_SIZE = 128
+# (smallest log2(d+1) whose opening folds at all, fold while the key has more than 2^T generators), measured on MI355X:
+# Pallas 2^20 42 -> 34 ms, 2^18 19.0 -> 18.4, 2^16 better without; BLS12-381 2^20 89 -> 70 ms, 2^16 25 -> 23
+IPA_FOLD = {ffi.AMSM_PALLAS: (18, 15), ffi.AMSM_BLS12_381_G1: (16, 15)}
 _lincomb = ASForHadamardProducts._lincomb
 
 
@@ -198,29 +201,35 @@ class InnerProductArgPC:
             combined_comm = _lincomb(ctx, [combined_comm, hiding_comm, ck.s], [1, hch, (-proof_rand) % fr.r], fr)
         round_challenge = cls._challenge(fr, [combined_comm, point, combined_v])
         h_prime = _lincomb(ctx, [ck.h], [round_challenge], fr)
-        # The rounds never fold the key.  Round j's cross commitments L_j = <c_r, key_l>, R_j = <c_l, key_r> are
+        # Small and medium openings never fold the key.  Round j's cross commitments L_j = <c_r, key_l>, R_j = <c_l, key_r> are
         # expressed over the ORIGINAL (precomputed, HBM-resident) key: amsm_ipa_round_scalars expands the current
         # coefficients by the products of the previous challenges into ONE vector, and amsm_msm_grouped_device sums
         # its two index classes (the bit that separates key_l from key_r in round j) in one pass.  Folding instead costs n / 2^j 128-bit scalar multiplications
         # with an inversion each per round -- a ~0.8 ms dependency chain per round whatever the size (measured:
         # 13 of 30 ms at d + 1 = 2^16).  The final folded key is one more MSM with the check polynomial's
         # coefficients.  Points are identical to the reference's (ext, under src/ipa_pc_as/mod.rs:454).
+        # Large openings fold the key physically in their first rounds (the reference's own `key_l += key_r * xi`,
+        # amsm_bases_fold): a fold is n/2 128-bit scalar multiplications, ~9 MSM-rounds' worth of work, but it halves
+        # every later round, so it pays while many rounds remain and the halves are large enough to run at throughput
+        # (measured thresholds in _fold_rounds).  The remaining rounds use the expansion over the last folded key.
         key = ck.comm_key
-        n_full = n
         log_n = n.bit_length() - 1
         assert n == 1 << log_n
-        u_l = ctx.vector(n_full)
+        fold_rounds = cls._fold_rounds(ctx, log_n)
+        u_l = ctx.vector(n)
         xs: List[int] = []
         l_vec, r_vec = [], []
+        cur_key, log_key = key, log_n  # the key the current round's scalars are expressed over
         while n > 1:
             half = n // 2
             c_l, c_r = coeffs.view(0, half), coeffs.view(half, half)
             z_l, z_r = z.view(0, half), z.view(half, half)
-            xi = fr.to_limbs_many(xs) if xs else None
-            j = len(xs)
-            ffi.check(ctx._lib.amsm_ipa_round_scalars(ctx._h, _ptr(xi), j, log_n, coeffs.ptr, u_l.ptr, None),
+            j = len(xs) - (log_n - log_key)  # challenges since cur_key was formed
+            xi = fr.to_limbs_many(xs[len(xs) - j:]) if j else None
+            u = u_l.view(0, 1 << log_key)
+            ffi.check(ctx._lib.amsm_ipa_round_scalars(ctx._h, _ptr(xi), j, log_key, coeffs.ptr, u.ptr, None),
                       "amsm_ipa_round_scalars")
-            xy, inf = VariableBaseMSM.multi_scalar_mul_grouped(key, u_l, log_n - 1 - j, mont=True)
+            xy, inf = VariableBaseMSM.multi_scalar_mul_grouped(cur_key, u, log_key - 1 - j, mont=True)
             l_pt = _lincomb(ctx, [(xy[0], bool(inf[0])), h_prime], [1, cls._inner_product(ctx, fr, c_r, z_l)], fr)
             r_pt = _lincomb(ctx, [(xy[1], bool(inf[1])), h_prime], [1, cls._inner_product(ctx, fr, c_l, z_r)], fr)
             l_vec.append(l_pt)
@@ -230,16 +239,36 @@ class InnerProductArgPC:
             coeffs = combine_vectors(ctx, [c_l, c_r], np.stack([one, fr.to_limbs(inv)]))
             z = combine_vectors(ctx, [z_l, z_r], np.stack([one, fr.to_limbs(round_challenge)]))
             xs.append(round_challenge)
+            if len(xs) <= fold_rounds:  # physical fold: the next round sees a key of `half` generators
+                assert j == 0
+                folded = cur_key.fold(half, fr.to_limbs(round_challenge), CHALLENGE_SIZE)
+                if cur_key is not key:
+                    cur_key.free()
+                cur_key, log_key = folded, log_key - 1
             n = half
-        if xs:
-            s_vec = SuccinctCheckPolynomial(xs).compute_coeffs(ctx)
-            final_key, final_inf = VariableBaseMSM.multi_scalar_mul(key, s_vec, mont=True)
+        since = xs[log_n - log_key:]
+        if since:
+            s_vec = SuccinctCheckPolynomial(since).compute_coeffs(ctx)
+            final_key, final_inf = VariableBaseMSM.multi_scalar_mul(cur_key, s_vec, mont=True)
             assert not final_inf
         else:
-            fk, _ = key.read(0, 1)
+            fk, _ = cur_key.read(0, 1)
             final_key = fk[0]
+        if cur_key is not key:
+            cur_key.free()
         c = fr.from_limbs(coeffs.download()[0])
         return Proof(l_vec, r_vec, (final_key, not final_key.any()), c, hiding_comm, proof_rand)
+
+    @staticmethod
+    def _fold_rounds(ctx, log_n: int) -> int:
+        """Leading rounds that fold the key physically (IPA_FOLD; AMSM_IPA_FOLD_ABOVE=T overrides: fold while the key has
+        more than 2^T generators, 99 = never).  The proof does not depend on the choice."""
+        import os
+        env = int(os.environ.get("AMSM_IPA_FOLD_ABOVE", "0"))
+        if env:
+            return max(0, log_n - env)
+        min_log, t = IPA_FOLD.get(ctx.curve, (99, 99))
+        return max(0, log_n - t) if log_n >= min_log else 0
 
     @staticmethod
     def _inner_product(ctx, fr: Fr, a: FrVector, b: FrVector) -> int:

@@ -191,8 +191,12 @@ struct MsmBatch {
   }
   // two sums over the index classes ((i >> group_shift) & 1) of ONE scalar vector, in one pass
   static std::vector<Affine> grouped(const CommitterKey& bases, const FrVector& scalars, unsigned group_shift) {
+    return grouped(bases, scalars, scalars.len(), group_shift);
+  }
+  // ... over the first n entries of `scalars`
+  static std::vector<Affine> grouped(const CommitterKey& bases, const FrVector& scalars, size_t n, unsigned group_shift) {
     return run(bases, 2, [&](uint64_t* xy, uint8_t* inf) {
-      return amsm_msm_grouped_device(bases.ctx().get(), bases.get(), 0, scalars.ptr(), scalars.len(), 1, group_shift, xy, inf);
+      return amsm_msm_grouped_device(bases.ctx().get(), bases.get(), 0, scalars.ptr(), n, 1, group_shift, xy, inf);
     }, "amsm_msm_grouped_device");
   }
 

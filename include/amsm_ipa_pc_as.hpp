@@ -176,6 +176,16 @@ struct InnerProductArgPC {
     return {Commitment{c, {}}, rand};
   }
 
+  // Leading rounds that fold the key physically: (smallest log2(d+1) that folds at all, fold while the key has more than
+  // 2^T generators), measured on MI355X -- the same table as accumulation_amd/ipa_pc.py:IPA_FOLD.
+  static size_t fold_rounds(int curve, size_t log_n) {
+    size_t min_log = curve == AMSM_PALLAS ? 18 : 16, t = 15;
+    if (const char* e = getenv("AMSM_IPA_FOLD_ABOVE")) {
+      int v = atoi(e);
+      if (v > 0) return log_n > (size_t)v ? log_n - (size_t)v : 0;
+    }
+    return log_n >= min_log && log_n > t ? log_n - t : 0;
+  }
   static Fr inner_product(Context& ctx, const void* a, const void* b, size_t n) {
     Fr out;
     amsm::check(amsm_vec_inner_product(ctx.get(), a, b, n, out.data()), "amsm_vec_inner_product");
@@ -226,19 +236,26 @@ struct InnerProductArgPC {
     Fr rc_canon = Challenge(fr).point(combined_comm).scalar(point).scalar(combined_v).squeeze_canonical();
     Fr round_challenge = fr.to_mont(rc_canon);
     Affine h_prime = host_lincomb(ctx, {&ck.h}, {round_challenge});
-    // The rounds never fold the key: round j's cross commitments are expressed over the ORIGINAL key (see the header).
+    // Small and medium openings never fold the key: round j's cross commitments are expressed over the ORIGINAL key (see
+    // the header).  Large ones fold it physically in their first rounds (amsm_bases_fold, the reference's
+    // `key_l += key_r * xi`): a fold costs about nine MSM rounds but halves every later one (fold_rounds).  The proof
+    // does not depend on the choice.
     size_t log_n = 0;
     while (((size_t)1 << log_n) < n) log_n++;
+    const size_t n_fold = fold_rounds(amsm_ctx_curve(ctx.get()), log_n);
     FrVector u(ctx, n);
     std::vector<Fr> xs;
     Proof proof;
+    std::unique_ptr<amsm::CommitterKey> folded;  // the key the current round's scalars are expressed over, once folded
+    const amsm::CommitterKey* cur_key = &key;
+    size_t log_key = log_n;
     size_t cur = n;
     while (cur > 1) {
-      size_t half = cur / 2, j = xs.size();
-      amsm::check(amsm_ipa_round_scalars(ctx.get(), j ? reinterpret_cast<const uint64_t*>(xs.data()) : nullptr, j, log_n, coeffs.ptr(), u.ptr(),
-                                   nullptr),
-            "amsm_ipa_round_scalars");
-      auto lr = MsmBatch::grouped(key, u, (unsigned)(log_n - 1 - j));
+      size_t half = cur / 2, j = xs.size() - (log_n - log_key);  // challenges since cur_key was formed
+      amsm::check(amsm_ipa_round_scalars(ctx.get(), j ? reinterpret_cast<const uint64_t*>(xs.data() + (xs.size() - j)) : nullptr, j,
+                                         log_key, coeffs.ptr(), u.ptr(), nullptr),
+                  "amsm_ipa_round_scalars");
+      auto lr = MsmBatch::grouped(*cur_key, u, (size_t)1 << log_key, (unsigned)(log_key - 1 - j));
       Fr ip_l = inner_product(ctx, at(coeffs, half), at(z, 0), half);  // <c_r, z_l>
       Fr ip_r = inner_product(ctx, at(coeffs, 0), at(z, half), half);  // <c_l, z_r>
       Affine l_pt = host_lincomb(ctx, {&lr[0], &h_prime}, {one, ip_l});
@@ -253,13 +270,19 @@ struct InnerProductArgPC {
       coeffs = std::move(nc);
       z = std::move(nz);
       xs.push_back(round_challenge);
+      if (xs.size() <= n_fold) {  // physical fold: the next round sees a key of `half` generators
+        folded.reset(new amsm::CommitterKey(cur_key->fold(half, round_challenge, CHALLENGE_SIZE)));
+        cur_key = folded.get();
+        log_key--;
+      }
       cur = half;
     }
-    if (!xs.empty()) {
-      FrVector s_vec = SuccinctCheckPolynomial{xs}.compute_coeffs(ctx);
-      proof.final_comm_key = VariableBaseMSM::multi_scalar_mul(key, s_vec);
+    std::vector<Fr> since(xs.begin() + (long)(log_n - log_key), xs.end());
+    if (!since.empty()) {
+      FrVector s_vec = SuccinctCheckPolynomial{since}.compute_coeffs(ctx);
+      proof.final_comm_key = VariableBaseMSM::multi_scalar_mul(*cur_key, s_vec);
     } else {
-      proof.final_comm_key.xy = key.read(0, 1);
+      proof.final_comm_key.xy = cur_key->read(0, 1);
       proof.final_comm_key.infinity = false;
     }
     proof.c = coeffs.to_host().at(0);

@@ -107,6 +107,30 @@ int main() {
       bool bad_p = Ipa::check(ck, cr.first, fr.add(point, fr.one()), value, proof);
       printf("ipa_pc %s %d %d %d\n", zk ? "zk" : "no_zk", good, bad_v, bad_p);
     }
+    // the proof does not depend on how many leading rounds fold the key physically (forced at d + 1 = 64)
+    {
+      ipa_pc::CommitterKey pp64 = Ipa::setup(ctx, 63, 0xF01D);
+      bool same = true;
+      std::vector<ipa_pc::Proof> proofs;
+      for (const char* t : {"99", "5", "2", "1"}) {
+        setenv("AMSM_IPA_FOLD_ABOVE", t, 1);
+        SchemeRng rng(31);
+        hp_as::Rng prng([&rng]() { return rng.field(); });
+        std::vector<Fr> coeffs;
+        for (size_t k = 0; k < 50; k++) coeffs.push_back(fr.to_mont(rng.field()));
+        FrVector poly(ctx, coeffs);
+        auto cr = Ipa::commit(pp64, poly, true, prng);
+        Fr point = fr.to_mont(rng.field()), value = fr.zero();
+        for (size_t k = coeffs.size(); k-- > 0;) value = fr.add(fr.mul(value, point), coeffs[k]);
+        proofs.push_back(Ipa::open(pp64, poly, cr.first, point, cr.second, true, prng));
+        same = same && Ipa::check(pp64, cr.first, point, value, proofs.back());
+      }
+      unsetenv("AMSM_IPA_FOLD_ABOVE");
+      for (auto& p : proofs)
+        same = same && p.l_vec == proofs[0].l_vec && p.r_vec == proofs[0].r_vec && p.final_comm_key == proofs[0].final_comm_key &&
+               p.c == proofs[0].c && p.rand == proofs[0].rand;
+      printf("fold_invariance %d\n", same ? 1 : 0);
+    }
     struct Scenario {
       const char* name;
       std::vector<size_t> per_iteration;

@@ -39,6 +39,7 @@ def test_cpp_ipa_pc_as_template_and_python_cross_check(built_lib):
     lines = [ln.split() for ln in out.stdout.splitlines()]
     assert ["done"] in lines
     assert ["ipa_pc", "no_zk", "1", "0", "0"] in lines and ["ipa_pc", "zk", "1", "0", "0"] in lines
+    assert ["fold_invariance", "1"] in lines
     assert ["missing_rng", "raised"] in lines and ["malformed_input", "raised"] in lines
     ok = {(ln[1], ln[2]) for ln in lines if ln[0] == "scenario" and ln[3] == "ok"}
     names = ["single_input_init", "multiple_inputs_init", "simple_accumulation", "multiple_inputs_accumulation",

@@ -194,6 +194,37 @@ def run_template(env, num_inputs_per_iteration, make_zk, num_iterations=NUM_ITER
     return True
 
 
+@pytest.mark.parametrize("hiding", [False, True], ids=["plain", "hiding"])
+def test_open_does_not_depend_on_key_folding(monkeypatch, hiding):
+    """Large openings fold the key physically in their first rounds (ipa_pc.IPA_FOLD); the proof must not depend on how
+    many rounds do: every split between folded rounds and rounds expressed over the last folded key gives the same
+    points, the same final key and the same c (forced here at d + 1 = 64 through AMSM_IPA_FOLD_ABOVE)."""
+    from accumulation_amd import Context, ffi
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
+    from accumulation_amd.scalar_field import Fr
+    for curve, c in ((ffi.AMSM_PALLAS, o.PALLAS), (ffi.AMSM_BLS12_381_G1, o.BLS12_381_G1)):
+        ctx = Context(curve)
+        fr = Fr(ctx.curve)
+        pp = IpaPC.setup(ctx, 63, seed=0xF01D)
+        ck, vk = IpaPC.trim(pp, 63)
+        seen = []
+        for t in (99, 5, 4, 2, 1):  # never fold, 1 fold, 2 folds, 4 folds, 5 folds (of 6 rounds)
+            monkeypatch.setenv("AMSM_IPA_FOLD_ABOVE", str(t))
+            assert IpaPC._fold_rounds(ctx, 6) == max(0, 6 - t)
+            rng = SchemeRng(31)
+            coeffs = [rng.field() % c.r for _ in range(50)]
+            poly = ctx.upload(fr.to_limbs_many(coeffs))
+            comm, rand = IpaPC.commit(ck, poly, hiding, rng)
+            point = rng.field() % c.r
+            value = sum(cf * pow(point, i, c.r) for i, cf in enumerate(coeffs)) % c.r
+            proof = IpaPC.open(ck, poly, comm, point, rand, hiding, rng)
+            assert IpaPC.check(vk, comm, point, value, proof)
+            seen.append(([h.np_to_point(c, *p) for p in proof.l_vec + proof.r_vec + [proof.final_comm_key]], proof.c, proof.rand))
+        assert all(x == seen[0] for x in seen[1:])
+        monkeypatch.delenv("AMSM_IPA_FOLD_ABOVE")
+        ctx.close()
+
+
 @pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
 def test_ipa_pc_as_bls12_381(make_zk):
     """BASELINE config 2's curve (384-bit base field, 255-bit scalars): the commitment against the oracle, open / check and
