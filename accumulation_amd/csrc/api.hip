@@ -71,6 +71,7 @@ struct amsm_ctx {
   Slot slot[N_SLOTS];
   hipEvent_t fork = nullptr;
   DevBuf scalars;
+  DevBuf xyzz_scratch;  // unconverted sums of large key folds / precompute levels (launch.h: batch_affine_pays)
 };
 
 struct amsm_bases {
@@ -565,11 +566,18 @@ int bases_finish(amsm_ctx* ctx, amsm_bases* b, unsigned flags) {
     return AMSM_OK;  // not enough HBM for W copies: keep the plain key
   }
   HIP_TRY(hipMemcpyAsync(table, b->d_table, b->n * affine_bytes<Fq>(), hipMemcpyDeviceToDevice, ctx->stream));
+  u32* scratch = nullptr;
+  if (batch_affine_pays<Fq>((u32)b->n) && ensure(ctx->xyzz_scratch, b->n * xyzz_bytes<Fq>()) == AMSM_OK)
+    scratch = (u32*)ctx->xyzz_scratch.p;
   for (int w = 1; w < W; w++) {
-    launch_precompute_level<Fq>(ctx->stream, table, (u32)b->n, (u32)w, (u32)c);
+    launch_precompute_level<Fq>(ctx->stream, table, (u32)b->n, (u32)w, (u32)c, scratch);
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipGetLastError());
+  if (scratch) {  // a key-sized buffer: not worth keeping between the rare key loads
+    (void)hipFree(ctx->xyzz_scratch.p);
+    ctx->xyzz_scratch = DevBuf();
+  }
   HIP_TRY(hipFree(b->d_table));
   b->d_table = table;
   b->precomp = 1;
@@ -1106,6 +1114,7 @@ void amsm_ctx_destroy(amsm_ctx* c) {
   if (c->s_tail) (void)hipStreamDestroy(c->s_tail);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   if (c->scalars.p) (void)hipFree(c->scalars.p);
+  if (c->xyzz_scratch.p) (void)hipFree(c->xyzz_scratch.p);
   delete c;
 }
 
@@ -1490,6 +1499,15 @@ static void canonical_scalar(int curve, const uint64_t* x_mont, u32 out[8]) {
   }
 }
 
+// scratch for the unconverted sums of a large fold (null: the kernel converts in place); stream-ordered reuse is safe
+// because every user runs on the context's stream
+static u32* fold_scratch(amsm_ctx* c, size_t n) {
+  bool pays = c->curve == AMSM_PALLAS ? batch_affine_pays<PallasFq>((u32)n) : batch_affine_pays<Bls12381Fq>((u32)n);
+  size_t rec = c->curve == AMSM_PALLAS ? xyzz_bytes<PallasFq>() : xyzz_bytes<Bls12381Fq>();
+  if (!pays || ensure(c->xyzz_scratch, n * rec) != AMSM_OK) return nullptr;
+  return (u32*)c->xyzz_scratch.p;
+}
+
 int amsm_points_fold(amsm_ctx* c, const void* d_l, const void* d_r, size_t n, const uint64_t* x_mont, unsigned nbits,
                      void* d_out) {
   if (!c || !x_mont || (n && (!d_l || !d_r || !d_out)) || n >= (1ull << 32) || nbits > 256) return AMSM_E_INVALID_ARG;
@@ -1497,10 +1515,12 @@ int amsm_points_fold(amsm_ctx* c, const void* d_l, const void* d_r, size_t n, co
   if (!n) return AMSM_OK;
   u32 canon[8];
   canonical_scalar(c->curve, x_mont, canon);
+  u32* scratch = fold_scratch(c, n);
   if (c->curve == AMSM_PALLAS)
-    launch_points_fold<PallasFq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, canon, nbits, (u32*)d_out, true);
+    launch_points_fold<PallasFq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, canon, nbits, (u32*)d_out, true, scratch);
   else
-    launch_points_fold<Bls12381Fq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, canon, nbits, (u32*)d_out, true);
+    launch_points_fold<Bls12381Fq>(c->stream, (const u32*)d_l, (const u32*)d_r, (u32)n, canon, nbits, (u32*)d_out, true,
+                                   scratch);
   HIP_TRY(hipGetLastError());
   return AMSM_OK;
 }
@@ -1526,10 +1546,11 @@ int amsm_bases_fold(amsm_ctx* c, const amsm_bases* key, size_t n_half, const uin
   canonical_scalar(c->curve, x_mont, canon);
   const u32* l = key->d_table;  // level 0 of a precomputed table is the key itself
   const u32* r = (const u32*)((const char*)key->d_table + n_half * pb);
+  u32* scratch = fold_scratch(c, n_half);
   if (c->curve == AMSM_PALLAS)
-    launch_points_fold<PallasFq>(c->stream, l, r, (u32)n_half, canon, nbits, b->d_table, false);
+    launch_points_fold<PallasFq>(c->stream, l, r, (u32)n_half, canon, nbits, b->d_table, false, scratch);
   else
-    launch_points_fold<Bls12381Fq>(c->stream, l, r, (u32)n_half, canon, nbits, b->d_table, false);
+    launch_points_fold<Bls12381Fq>(c->stream, l, r, (u32)n_half, canon, nbits, b->d_table, false, scratch);
   if (hipGetLastError() != hipSuccess) {
     (void)hipFree(b->d_table);
     delete b;

@@ -27,7 +27,7 @@ void launch_bucket_reduce(hipStream_t st, u32 red_blocks, const u32* buckets, Ms
 template <class Fq>
 void launch_fold(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out);
 template <class Fq>
-void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c);
+void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c, u32* xyzz_scratch);
 template <class Fq>
 void launch_apply_inf(hipStream_t st, u32* table, const uint8_t* is_inf, u32 n);
 template <class Fq>
@@ -43,9 +43,13 @@ void launch_points_import(hipStream_t st, const u32* src, u32* dst, u32 n);
 template <class Fq>
 void launch_points_export(hipStream_t st, const u32* src, u32* dst, u32 n);
 
+// xyzz_scratch (n XYZZ records, may be null): large folds / precompute levels leave their sums there and convert them to
+// affine in a second kernel with one inversion per few points (batch_affine_pays(n) says when the scratch is used)
+template <class Fq>
+bool batch_affine_pays(u32 n);
 template <class Fq>
 void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const u32 x_canon[8], u32 nbits, u32* out,
-                        bool abi_radix);
+                        bool abi_radix, u32* xyzz_scratch);
 
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>

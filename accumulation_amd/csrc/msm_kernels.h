@@ -331,21 +331,67 @@ __global__ void __launch_bounds__(64) k_fold(const u32* __restrict__ in, u32 n, 
 // ---------------------------------------------------------------------------------------------
 // Key preparation
 // ---------------------------------------------------------------------------------------------
-// table[(level)*stride + i] = 2^c * table[(level-1)*stride + i]  (affine in, affine out)
-template <class Fq>
-__global__ void __launch_bounds__(256) k_precompute_level(u32* __restrict__ table, u32 stride, u32 level, u32 c) {
+// Batched XYZZ -> affine (Montgomery's trick): lane g converts points g, g + T, g + 2T, ... (T = lanes of the grid, so a
+// wave's loads stay coalesced), K per lane, with ONE field inversion: 9 multiplications per point + 1/K of the ~260-unit
+// (Pallas) / ~480-unit (BLS12-381) Fermat inversion, instead of 5 + a whole one.  Identity (ZZ = 0) -> (0, 0).
+// ABI: write the C-ABI radix.
+template <class Fq, int K, bool ABI>
+__global__ void __launch_bounds__(256) k_batch_to_affine(const u32* __restrict__ xyzz, u32 n, u32* __restrict__ out) {
+  const u32 T = gridDim.x * blockDim.x, g = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32* zz0 = xyzz + 2 * Fq::W;  // ZZ | ZZZ of point 0
+  Fe<Fq> prefix[K];
+  Fe<Fq> run = fe_one<Fq>();
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    u32 i = g + (u32)k * T;
+    prefix[k] = run;
+    if (i < n) {
+      const u32* q = zz0 + (size_t)i * (4 * Fq::W);
+      Fe<Fq> w = fe_mul<Fq>(fe_load<Fq>(q), fe_load<Fq>(q + Fq::W));
+      if (!fe_is_zero<Fq>(w)) run = fe_mul<Fq>(run, w);
+    }
+  }
+  Fe<Fq> inv = fe_inv<Fq>(run);
+#pragma unroll
+  for (int k = K - 1; k >= 0; k--) {
+    u32 i = g + (u32)k * T;
+    if (i < n) {
+      XYZZ<Fq> p = xyzz_load<Fq>(xyzz, i);
+      Fe<Fq> w = fe_mul<Fq>(p.zz, p.zzz);
+      Affine<Fq> r;
+      if (fe_is_zero<Fq>(w)) {
+        r.x = fe_zero<Fq>();
+        r.y = fe_zero<Fq>();
+      } else {
+        Fe<Fq> iw = fe_mul<Fq>(inv, prefix[k]);  // 1 / (ZZ * ZZZ) of this point
+        inv = fe_mul<Fq>(inv, w);
+        r.x = fe_mul<Fq>(p.x, fe_mul<Fq>(iw, p.zzz));
+        r.y = fe_mul<Fq>(p.y, fe_mul<Fq>(iw, p.zz));
+        if (ABI) r = affine_export<Fq>(r);
+      }
+      affine_store<Fq>(out, i, r);
+    }
+  }
+}
+
+// table[(level)*stride + i] = 2^c * table[(level-1)*stride + i]  (affine in, affine out).  XYZZ_OUT: leave the result
+// unconverted in xyzz_out[i] for k_batch_to_affine (large keys: the per-point inversion is 2/3 of this kernel).
+template <class Fq, bool XYZZ_OUT>
+__global__ void __launch_bounds__(256)
+    k_precompute_level(u32* __restrict__ table, u32 stride, u32 level, u32 c, u32* __restrict__ xyzz_out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= stride) return;
   Affine<Fq> p = affine_load<Fq>(table, (size_t)(level - 1) * stride + i);
-  Affine<Fq> r;
-  if (affine_is_inf<Fq>(p)) {
-    r = p;
-  } else {
-    XYZZ<Fq> a = xyzz_dbl_affine<Fq>(p);
+  XYZZ<Fq> a = xyzz_inf<Fq>();
+  if (!affine_is_inf<Fq>(p)) {
+    a = xyzz_dbl_affine<Fq>(p);
     for (u32 k = 1; k < c; k++) a = xyzz_dbl<Fq>(a);
-    r = xyzz_to_affine<Fq>(a);
   }
-  affine_store<Fq>(table, (size_t)level * stride + i, r);
+  if (XYZZ_OUT) {
+    xyzz_store<Fq>(xyzz_out, i, a);
+  } else {
+    affine_store<Fq>(table, (size_t)level * stride + i, affine_is_inf<Fq>(p) ? p : xyzz_to_affine<Fq>(a));
+  }
 }
 
 // out[i] = l[i] + x * r[i] for affine point vectors (the commitment-key fold `key_l += key_r * xi` of the IPA
@@ -356,22 +402,30 @@ struct Scalar256 {  // canonical scalar as a kernel argument
 };
 // ABI = true: l, r, out are caller-visible device buffers (C-ABI Montgomery radix in and out); false: key tables
 // (device radix, amsm_bases_fold)
-template <class Fq, bool ABI>
+// XYZZ_OUT: leave the sums unconverted in out (XYZZ records, internal radix) for k_batch_to_affine.
+template <class Fq, bool ABI, bool XYZZ_OUT>
 __global__ void __launch_bounds__(256)
-    k_points_fold(const u32* __restrict__ l, const u32* __restrict__ r, u32 n, Scalar256 x, u32 nbits,
+    k_points_fold(const u32* __restrict__ l, const u32* __restrict__ r, u32 n, Scalar256 pos, Scalar256 neg, u32 ndigits,
                   u32* __restrict__ out) {
+  // x in non-adjacent form (digits +1 / -1 / 0, a third non-zero: the host recodes it once, the digits are uniform
+  // over the grid): ndigits doublings and ~ndigits/3 mixed additions of +-r[i] instead of ndigits/2
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<Fq> pr = affine_load<Fq>(r, i);
   if (ABI) pr = affine_import<Fq>(pr);
   XYZZ<Fq> acc = xyzz_inf<Fq>();
-  for (int bit = (int)nbits - 1; bit >= 0; bit--) {
+  for (int bit = (int)ndigits - 1; bit >= 0; bit--) {
     acc = xyzz_dbl<Fq>(acc);
-    if ((x.w[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd<Fq>(acc, pr);
+    bool p = (pos.w[bit >> 5] >> (bit & 31)) & 1u, m = (neg.w[bit >> 5] >> (bit & 31)) & 1u;
+    if (p | m) xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pr, m));
   }
   Affine<Fq> pl = affine_load<Fq>(l, i);
   if (ABI) pl = affine_import<Fq>(pl);
   xyzz_madd<Fq>(acc, pl);
+  if (XYZZ_OUT) {
+    xyzz_store<Fq>(out, i, acc);
+    return;
+  }
   Affine<Fq> res = xyzz_to_affine<Fq>(acc);
   if (ABI) res = affine_export<Fq>(res);
   affine_store<Fq>(out, i, res);

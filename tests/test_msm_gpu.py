@@ -505,3 +505,46 @@ def test_bls12_381_vs_c_oracle(ctxs, cref, log2n):
     ref, rinf = cref.msm(c.curve_id, xy, dv.download(), threads=17)
     assert oinf == rinf and np.array_equal(out, ref)
     ck.free()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_large_key_precompute_and_fold_batched_affine(ctxs, cref, c):
+    """Keys and folds of >= 2^17 points convert their sums to affine in a second kernel with one inversion per four
+    points (k_batch_to_affine).  (1) a 2^17 precomputed key that contains identity points against the C oracle;
+    (2) the key fold l + x r at 2^17 through a size-independent property: an MSM over the folded key equals the MSM over
+    the original key with scalars [s ; x s] (identity results included: the pairs (identity, identity))."""
+    from accumulation_amd import CommitterKey, VariableBaseMSM
+    from accumulation_amd.scalar_field import Fr
+    ctx = ctxs[c.name]
+    fr = Fr(ctx.curve)
+    n = 1 << 18
+    half = n // 2
+    xy = cref.rng_points(c.curve_id, 0x717, n)
+    inf = np.zeros(n, dtype=np.uint8)
+    dead = [0, 5, half - 1]
+    for i in dead:                      # identity in BOTH halves -> identity in the folded key
+        inf[i] = inf[half + i] = 1
+    inf[7] = 1                          # identity on one side only
+    xy[inf.astype(bool)] = 0
+    ck = CommitterKey.load(ctx, xy, inf, 1)   # precomputed: 2^18 >= 2^17 -> batched conversion of every level
+    assert ck.precomputed
+    sc = cref.rng_scalars(0x718, n)
+    out, oinf = VariableBaseMSM.multi_scalar_mul(ck, ctx.upload(sc), mont=False)
+    ref, rinf = cref.msm(c.curve_id, xy, sc, threads=8)
+    assert bool(oinf) == rinf and np.array_equal(out, ref)
+    # fold with a 128-bit and with a full-size challenge
+    for x in (o.rng_scalar(0x719, 0) % (1 << 128), c.r - 12345):
+        nbits = 128 if x < (1 << 128) else 255
+        folded = ck.fold(half, fr.to_limbs(x), nbits)
+        fxy, finf = folded.read(0, 8)
+        for i in dead:
+            if i < 8:
+                assert finf[i] and not fxy[i].any()
+        s = [o.rng_scalar(0x71A, i) % c.r for i in range(64)]          # a few distinct scalars, tiled
+        s_half = (s * (half // 64))[:half]
+        got, ginf = VariableBaseMSM.multi_scalar_mul(folded, ctx.upload(h.scalars_to_np(s_half)), mont=False)
+        s_full = s_half + [(v * x) % c.r for v in s_half]
+        exp, einf = VariableBaseMSM.multi_scalar_mul(ck, ctx.upload(h.scalars_to_np(s_full)), mont=False)
+        assert bool(ginf) == bool(einf) and np.array_equal(got, exp), hex(x)
+        folded.free()
+    ck.free()
