@@ -326,7 +326,7 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   stage_mark(ctx, sl, ST_DIGITS, st);
   if (ctx->custom_prep && prep_supported(g)) {
     // 5-dispatch prep chain (prep_kernels.h); the stage marks keep their names: "sort" = scatter + local sort
-    TRY(ensure(sl->prep_small, 4 * (4096 + 1) * 4));
+    TRY(ensure(sl->prep_small, prep_small_words(g) * sizeof(u32)));
     PrepBuffers pb;
     pb.d_small = (u32*)sl->prep_small.p;
     pb.part = vals_a;

@@ -4,6 +4,7 @@
 #include "vec_kernels.h"
 #include "prep_kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace amsm {
@@ -40,8 +41,15 @@ static PrepGeom prep_geom(const MsmGeom& g) {
   // 1024-lane workgroup per CU) holds the ~32 k entries of one of 512 partitions at 2^20 pairs with 4 k to spare
   const u32 budget_words = 37888u, fixed_words = 2u * (1u << pg.SH) + 1024u;
   pg.CAP = budget_words > fixed_words + 4096u ? budget_words - fixed_words : 0u;
+  // heavy: several times the expected size AND big enough for 64 workgroups to beat one (below, one workgroup is fine)
+  pg.HEAVY = std::max<u32>(4u * (g.E / pg.P + 1u), 1u << 17);
+  if (const char* e = getenv("AMSM_PREP_HEAVY"))  // 0: one workgroup per partition whatever its size (A/B)
+    if (atoi(e) == 0) pg.HEAVY = 0xffffffffu;
   return pg;
 }
+// words per per-bucket array of the heavy-partition path (every partition's 2^SH buckets, padded)
+static size_t prep_heavy_words(const MsmGeom& g) { return (size_t)g.B + 4096 + 64; }
+size_t prep_small_words(const MsmGeom& g) { return 4 * (PREP_MAX_P + 1) + 1 + 3 * prep_heavy_words(g) + PREP_MAX_HEAVY; }
 static size_t prep_local_lds(const PrepGeom& pg) { return (2 * (size_t)(1u << pg.SH) + 1024 + pg.CAP) * sizeof(u32); }
 // more than 64 KiB of dynamic LDS needs the attribute once per process
 static bool prep_local_attr_done = false;
@@ -71,7 +79,14 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
     u32* part_start = b.d_small + (PREP_MAX_P + 1);                                                                  \
     u32* part_cursor = b.d_small + 2 * (PREP_MAX_P + 1);                                                             \
     u32* part_items = b.d_small + 3 * (PREP_MAX_P + 1);                                                              \
-    if (hipMemsetAsync(b.d_small, 0, 4 * (PREP_MAX_P + 1) * sizeof(u32), st) != hipSuccess) return -1;               \
+    PrepHeavy hv;                                                                                                    \
+    hv.n = b.d_small + 4 * (PREP_MAX_P + 1);                                                                         \
+    hv.cnt = hv.n + 1;                      /* zeroed with the words before it */                                    \
+    hv.ids = hv.cnt + prep_heavy_words(g);                                                                           \
+    hv.cur = hv.ids + PREP_MAX_HEAVY;                                                                                \
+    hv.end = hv.cur + prep_heavy_words(g);                                                                           \
+    if (hipMemsetAsync(b.d_small, 0, (4 * (PREP_MAX_P + 1) + 1 + prep_heavy_words(g)) * sizeof(u32), st) != hipSuccess) \
+      return -1;                                                                                                     \
     u32 blocks = cdiv_(g.n, pg.SPB);                                                                                 \
     u32 cap = pg.SPB * g.S;                                                                                          \
     size_t lds_scatter = (3 * pg.P + cap) * sizeof(u32) + cap * sizeof(uint16_t);                                    \
@@ -81,15 +96,21 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
       hipLaunchKernelGGL((k_prep_hist<FR>), dim3(cdiv_(g.n, 1024)), dim3(1024), pg.P * sizeof(u32), st, scalars,      \
                          mont, g, ph, part_total, b.err);                                                            \
     }                                                                                                                \
-    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P);                       \
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P, pg.HEAVY, hv);         \
     if (g.S <= 16u)                                                                                                  \
       hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1>), dim3(blocks), dim3(512), lds_scatter, st, scalars, mont, g, pg, \
                          part_start, part_cursor, b.part);                                                           \
     else                                                                                                             \
       hipLaunchKernelGGL((k_prep_scatter<FR, 32, 1>), dim3(blocks), dim3(256), lds_scatter, st, scalars, mont, g, pg, \
                          part_start, part_cursor, b.part);                                                           \
+    const size_t lds_heavy = 2 * (size_t)(1u << pg.SH) * sizeof(u32);                                                \
+    if (pg.HEAVY != 0xffffffffu)                                                                                     \
+      hipLaunchKernelGGL(k_prep_heavy_count, dim3(PREP_HEAVY_GRID), dim3(256), lds_heavy, st, part_start, b.part, pg, hv); \
     hipLaunchKernelGGL(k_prep_local, dim3(pg.P), dim3(1024), prep_local_lds(pg), st,                                 \
-                       part_start, b.part, g, pg, b.vals_sorted, b.start, b.items, b.item_off, part_items);          \
+                       part_start, b.part, g, pg, b.vals_sorted, b.start, b.items, b.item_off, part_items, hv);      \
+    if (pg.HEAVY != 0xffffffffu)                                                                                     \
+      hipLaunchKernelGGL(k_prep_heavy_place, dim3(PREP_HEAVY_GRID), dim3(256), lds_heavy, st, part_start, b.part, pg, hv, \
+                         b.vals_sorted);                                                                             \
     hipLaunchKernelGGL(k_prep_offsets, dim3(cdiv_(g.B, 256)), dim3(256), (pg.P + 256) * sizeof(u32), st, part_start, \
                        part_items, pg, g, b.start, b.items, b.item_off, b.vals_sorted);                              \
     return 0;                                                                                                        \

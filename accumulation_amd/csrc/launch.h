@@ -54,10 +54,12 @@ void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>
 void launch_digits(hipStream_t st, const u32* scalars, int mont, MsmGeom g, void* keys, bool keys16, u32* vals, u32* err);
-// Custom prep chain (prep_kernels.h): scalars -> sorted entry list + bucket table in 5 dispatches.  d_small holds
-// 4 * (4096 + 1) words (partition totals, starts, cursors, partial counts) and is zeroed by the launcher.
+// Custom prep chain (prep_kernels.h): scalars -> sorted entry list + bucket table in 7 dispatches.  d_small holds
+// prep_small_words(g) words (partition totals, starts, cursors, partial counts, the heavy-partition tables); the launcher
+// zeroes what needs it.
+size_t prep_small_words(const MsmGeom& g);
 struct PrepBuffers {
-  u32* d_small;       // >= 4 * (4096 + 1) words
+  u32* d_small;       // >= prep_small_words(g) words
   u32* part;          // E words: entries grouped by partition
   u32* vals_sorted;   // E + 16 words
   u32* start;         // B + 2 words

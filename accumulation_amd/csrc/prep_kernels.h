@@ -1,4 +1,5 @@
-// MSM "prep": scalars -> the bucket-sorted entry list accumulate L0 consumes, in FIVE dependent dispatches.
+// MSM "prep": scalars -> the bucket-sorted entry list accumulate L0 consumes, in SEVEN dependent dispatches (five that
+// do the work + two that only act on heavily skewed inputs).
 //
 // The first version of this stage was k_digits + rocPRIM radix_sort_pairs + k_bounds + rocPRIM exclusive_scan: 14
 // dependent dispatches.  Stand-alone that costs ~0.35 ms at 2^20 pairs, but in a batch it runs BESIDE the previous
@@ -19,7 +20,7 @@
 //
 // Entries with digit 0 are never emitted (the sort used to carry them to the end of the list).  Skewed inputs
 // (all-equal scalars put every entry of a window into ONE bucket) only make one partition large: its
-// workgroup loops over it, nothing overflows.
+// workgroup would loop over it; k_prep_heavy_count / k_prep_heavy_place split such partitions over 64 workgroups.
 #pragma once
 #include "fp.h"
 #include "msm_types.h"
@@ -32,6 +33,21 @@ struct PrepGeom {
   u32 SPB;  // scalars per workgroup of k_prep_hist / k_prep_scatter (256 lanes x 2)
   u32 IB;   // bits of a table index (entry word: negate | bucket id low bits << IB | index)
   u32 CAP;  // entries k_prep_local can assemble in LDS (larger partitions scatter straight to memory)
+  u32 HEAVY;  // partitions with more entries than this are split over PREP_HEAVY_SLICES workgroups (k_prep_heavy_*)
+};
+
+// A skewed digit distribution (the all-equal vectors the reference's harness commits to put a whole
+// window into ONE bucket) makes a few partitions hold millions of entries.  One workgroup streams at one CU's share of
+// the memory system (~30 GB/s: 0.45 ms per million entries for the two passes), so such partitions are listed by
+// k_prep_scan and processed by PREP_HEAVY_SLICES workgroups each: k_prep_heavy_count (per-bucket totals), k_prep_local
+// (offsets only) and k_prep_heavy_place (slices reserve runs in their buckets with one global atomicAdd per bucket).
+constexpr u32 PREP_HEAVY_SLICES = 64, PREP_HEAVY_GRID = 1024, PREP_MAX_HEAVY = 4096;
+struct PrepHeavy {
+  u32* n;      // number of heavy partitions (k_prep_scan)
+  u32* ids;    // their ids
+  u32* cnt;    // B words, zeroed by the launcher: entries per bucket (heavy partitions only)
+  u32* cur;    // B words: running cursor of every bucket of a heavy partition (offset inside the partition)
+  u32* end;    // B words: end offset of the bucket inside the partition
 };
 
 constexpr u32 PREP_ENTRY_LAST = 0x40000000u;  // == ENTRY_LAST of msm_kernels.h
@@ -178,9 +194,12 @@ AMSM_DEV void block_exclusive_scan(const u32* __restrict__ in, u32* __restrict__
   if (with_total && t == T - 1) out[n] = lds[T - 1];
 }
 
-__global__ void __launch_bounds__(1024) k_prep_scan(const u32* __restrict__ part_total, u32* __restrict__ part_start, u32 P) {
+__global__ void __launch_bounds__(1024)
+    k_prep_scan(const u32* __restrict__ part_total, u32* __restrict__ part_start, u32 P, u32 heavy_min, PrepHeavy hv) {
   __shared__ u32 lds[1024];
   block_exclusive_scan(part_total, part_start, P, true, lds);
+  for (u32 p = threadIdx.x; p < P; p += blockDim.x)  // *hv.n was zeroed by the launcher
+    if (part_total[p] > heavy_min) hv.ids[atomicAdd(hv.n, 1u)] = p;
 }
 
 // Entry word inside the partition buffers: bit 31 = negate, bits [IB, IB + SH) = bucket id low bits, bits [0, IB) =
@@ -277,7 +296,7 @@ __global__ void __launch_bounds__(512)
 __global__ void __launch_bounds__(1024)
     k_prep_local(const u32* __restrict__ part_start, const u32* __restrict__ part, MsmGeom g, PrepGeom pg,
                  u32* __restrict__ vals_sorted, u32* __restrict__ start, u32* __restrict__ items, u32* __restrict__ item_off,
-                 u32* __restrict__ part_items) {
+                 u32* __restrict__ part_items, PrepHeavy hv) {
   extern __shared__ u32 prep_lds[];
   const u32 NB = 1u << pg.SH;
   u32* cnt = prep_lds;       // entries per bucket of this partition, later the bucket's end offset
@@ -286,7 +305,8 @@ __global__ void __launch_bounds__(1024)
   const u32 p = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const u32 ps = part_start[p], pe = part_start[p + 1];
   const u32 low = NB - 1u, idx_mask = (1u << pg.IB) - 1u;
-  for (u32 k = t; k < NB; k += T) cnt[k] = 0;
+  const bool heavy = (pe - ps) > pg.HEAVY;  // uniform per workgroup; counted by k_prep_heavy_count
+  for (u32 k = t; k < NB; k += T) cnt[k] = heavy ? hv.cnt[(p << pg.SH) + k] : 0u;
   __syncthreads();
   // entries are read four at a time once the partition is long enough to care (skewed inputs make partitions of
   // millions of entries; one workgroup still owns each): head up to 16-byte alignment, uint4 body, tail
@@ -299,15 +319,17 @@ __global__ void __launch_bounds__(1024)
     if (skew) lds_count(cnt, k);
     else atomicAdd(&cnt[k], 1u);
   };
-  for (u32 j = ps + t; j < body_lo; j += T) count(part[j]);
-  for (u32 j = body_lo + 4u * t; j < body_hi; j += 4u * T) {
-    uint4 e4 = *reinterpret_cast<const uint4*>(part + j);
-    count(e4.x);
-    count(e4.y);
-    count(e4.z);
-    count(e4.w);
+  if (!heavy) {
+    for (u32 j = ps + t; j < body_lo; j += T) count(part[j]);
+    for (u32 j = body_lo + 4u * t; j < body_hi; j += 4u * T) {
+      uint4 e4 = *reinterpret_cast<const uint4*>(part + j);
+      count(e4.x);
+      count(e4.y);
+      count(e4.z);
+      count(e4.w);
+    }
+    for (u32 j = body_hi + t; j < pe; j += T) count(part[j]);
   }
-  for (u32 j = body_hi + t; j < pe; j += T) count(part[j]);
   __syncthreads();
   const u32 b0 = p << pg.SH;
   // exclusive prefix of the bucket sizes (entries) and of the bucket chunk counts (partials), lane t owns a slice
@@ -335,6 +357,10 @@ __global__ void __launch_bounds__(1024)
       items[b0 + k] = it;
     }
     cnt[k] = run + c;  // end offset of the bucket inside the partition
+    if (heavy) {
+      hv.cur[b0 + k] = run;
+      hv.end[b0 + k] = run + c;
+    }
     my_items += it;
     run += c;
   }
@@ -356,6 +382,7 @@ __global__ void __launch_bounds__(1024)
     }
   }
   if (t == T - 1) part_items[p] = sl[T - 1];
+  if (heavy) return;  // placed by k_prep_heavy_place
   __syncthreads();
   // final placement; the entry that lands on the last position of its bucket carries the flag
   // Partitions of the usual size are assembled in LDS and written out as one coalesced stream: 16.8 M scattered
@@ -392,6 +419,68 @@ __global__ void __launch_bounds__(1024)
     }
     for (u32 j = o_hi + t; j < pe; j += T) vals_sorted[j] = stage[j - ps];
     (void)n_p;
+  }
+}
+
+// Slice `s` of heavy partition hv.ids[h]: a contiguous run of its entries, one (partition, slice) pair per loop trip.
+// Both kernels run with a fixed small grid and return at once when no partition is heavy (the usual case).
+// dynamic LDS: 2 * 2^SH words.
+AMSM_DEV void prep_heavy_slice(u32 ps, u32 pe, u32 s, u32& lo, u32& hi) {
+  u32 per = ((pe - ps) + PREP_HEAVY_SLICES - 1u) / PREP_HEAVY_SLICES;
+  lo = min(ps + s * per, pe);
+  hi = min(lo + per, pe);
+}
+__global__ void __launch_bounds__(256)
+    k_prep_heavy_count(const u32* __restrict__ part_start, const u32* __restrict__ part, PrepGeom pg, PrepHeavy hv) {
+  extern __shared__ u32 prep_lds[];
+  const u32 NB = 1u << pg.SH, low = NB - 1u, t = threadIdx.x, T = blockDim.x;
+  u32* cnt = prep_lds;
+  const u32 work = *hv.n * PREP_HEAVY_SLICES;
+  for (u32 w = blockIdx.x; w < work; w += gridDim.x) {
+    const u32 p = hv.ids[w / PREP_HEAVY_SLICES];
+    u32 lo, hi;
+    prep_heavy_slice(part_start[p], part_start[p + 1], w % PREP_HEAVY_SLICES, lo, hi);
+    for (u32 k = t; k < NB; k += T) cnt[k] = 0;
+    __syncthreads();
+    for (u32 j = lo + t; j < hi; j += T) lds_count(cnt, (part[j] >> pg.IB) & low);
+    __syncthreads();
+    for (u32 k = t; k < NB; k += T)
+      if (cnt[k]) atomicAdd(&hv.cnt[(p << pg.SH) + k], cnt[k]);
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256)
+    k_prep_heavy_place(const u32* __restrict__ part_start, const u32* __restrict__ part, PrepGeom pg, PrepHeavy hv,
+                       u32* __restrict__ vals_sorted) {
+  extern __shared__ u32 prep_lds[];
+  const u32 NB = 1u << pg.SH, low = NB - 1u, idx_mask = (1u << pg.IB) - 1u, t = threadIdx.x, T = blockDim.x;
+  u32* cnt = prep_lds;        // entries of this slice per bucket, then the slice's cursor inside its run
+  u32* base = prep_lds + NB;  // start of the run this slice reserved in the bucket
+  const u32 work = *hv.n * PREP_HEAVY_SLICES;
+  for (u32 w = blockIdx.x; w < work; w += gridDim.x) {
+    const u32 p = hv.ids[w / PREP_HEAVY_SLICES], b0 = p << pg.SH;
+    const u32 ps = part_start[p];
+    u32 lo, hi;
+    prep_heavy_slice(ps, part_start[p + 1], w % PREP_HEAVY_SLICES, lo, hi);
+    for (u32 k = t; k < NB; k += T) cnt[k] = 0;
+    __syncthreads();
+    for (u32 j = lo + t; j < hi; j += T) lds_count(cnt, (part[j] >> pg.IB) & low);
+    __syncthreads();
+    for (u32 k = t; k < NB; k += T) {
+      u32 c = cnt[k];
+      base[k] = c ? atomicAdd(&hv.cur[b0 + k], c) : 0u;
+      cnt[k] = 0;
+    }
+    __syncthreads();
+    for (u32 j = lo + t; j < hi; j += T) {
+      u32 e = part[j];
+      u32 k = (e >> pg.IB) & low;
+      u32 pos = base[k] + lds_count(cnt, k);
+      u32 v = (e & 0x80000000u) | (e & idx_mask);
+      if (pos + 1 == hv.end[b0 + k]) v |= PREP_ENTRY_LAST;
+      vals_sorted[ps + pos] = v;
+    }
+    __syncthreads();
   }
 }
 
