@@ -372,6 +372,33 @@ class PedersenCommitment:
         return out
 
     @staticmethod
+    def commit_batch(ck: CommitterKey, vectors: Sequence["FrVector"], randomizers: Sequence[Optional[np.ndarray]]):
+        """Several independent commitments to device vectors of one length as ONE pipelined MSM batch; the hiding terms
+        randomizer * hiding_generator are added on the host.  Same points as len(vectors) calls of commit()."""
+        ctx = ck.ctx
+        pts, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, list(vectors), mont=True)
+        out = []
+        one = None
+        for i, r in enumerate(randomizers):
+            if r is None:
+                out.append((pts[i], bool(infs[i])))
+                continue
+            if ck.hiding_generator is None:
+                raise ValueError("committer key has no hiding generator")
+            if one is None:
+                one = np.zeros(4, dtype=np.uint64)
+                ffi.check(ctx._lib.amsm_fr_to_mont(ctx.curve, _ptr(np.array([1, 0, 0, 0], dtype=np.uint64)), 1, _ptr(one)), "to_mont")
+            xy = np.stack([np.asarray(pts[i], dtype=np.uint64), np.asarray(ck.hiding_generator, dtype=np.uint64)])
+            inf = np.array([1 if infs[i] else 0, 0], dtype=np.uint8)
+            sc = np.stack([one, np.ascontiguousarray(r, dtype=np.uint64).reshape(4)])
+            o = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+            oinf = C.c_uint8(0)
+            ffi.check(ctx._lib.amsm_host_lincomb(ctx.curve, _ptr(xy), _ptr(inf), _ptr(sc), 2, _ptr(o), C.byref(oinf)),
+                      "amsm_host_lincomb")
+            out.append((o, bool(oinf.value)))
+        return out
+
+    @staticmethod
     def commit(ck: CommitterKey, elems, randomizer: Optional[np.ndarray] = None) -> Tuple[np.ndarray, bool]:
         """commit(ck, &[F] (Montgomery), Option<F>) -> affine point."""
         if hasattr(ck, "sharded"):  # dist.ShardedCommitterKey

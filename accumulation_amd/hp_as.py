@@ -289,14 +289,13 @@ class ASForHadamardProducts:
         a = ctx.fill(fr.to_limbs(a_val), hp_vec_len)
         b = ctx.fill(fr.to_limbs(b_val), hp_vec_len)
         rands = InputWitnessRandomness(rng.field(), rng.field(), rng.field())
-        commit = PedersenCommitment.commit
-        comm_1 = commit(pk, a, fr.to_limbs(rands.rand_1))
-        comm_2 = commit(pk, b, fr.to_limbs(rands.rand_2))
         rand_prod_1 = compute_hp(ctx, a, witnesses[0].b_vec)
         rand_prod_2 = compute_hp(ctx, witnesses[-1].a_vec, b)
         one = fr.to_limbs(1)
         rand_prods_sum = combine_vectors(ctx, [rand_prod_1, rand_prod_2], np.stack([one, one]))
-        comm_3 = commit(pk, rand_prods_sum, fr.to_limbs(rands.rand_3))
+        # the three commitments are independent: one pipelined batch (same points as three commit() calls, :196-214)
+        comm_1, comm_2, comm_3 = PedersenCommitment.commit_batch(
+            pk, [a, b, rand_prods_sum], [fr.to_limbs(rands.rand_1), fr.to_limbs(rands.rand_2), fr.to_limbs(rands.rand_3)])
         return (a, b), rands, ProofHidingCommitments(comm_1, comm_2, comm_3)
 
     @staticmethod
@@ -416,8 +415,7 @@ class ASForHadamardProducts:
         if rnd is None:
             c = decide_commitments(decider_key, w.a_vec, w.b_vec)
         else:
-            c = [commit(decider_key, w.a_vec, fr.to_limbs(rnd.rand_1)),
-                 commit(decider_key, w.b_vec, fr.to_limbs(rnd.rand_2)),
-                 commit(decider_key, product, fr.to_limbs(rnd.rand_3))]
+            c = PedersenCommitment.commit_batch(decider_key, [w.a_vec, w.b_vec, product],
+                                                [fr.to_limbs(rnd.rand_1), fr.to_limbs(rnd.rand_2), fr.to_limbs(rnd.rand_3)])
         inst = accumulator.instance
         return _pt_eq(c[0], inst.comm_1) and _pt_eq(c[1], inst.comm_2) and _pt_eq(c[2], inst.comm_3)

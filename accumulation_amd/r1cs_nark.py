@@ -218,19 +218,15 @@ def prove(ipk: IndexProverKey, input: Sequence[int], witness: FrVector, make_zk:
     r_b = matrix_vec_mul(ipk.b, zeros, r)
     r_c = matrix_vec_mul(ipk.c, zeros, r)
     a_bl, b_bl, c_bl = rng.field(), rng.field(), rng.field()
-    comm_a = commit(ipk.ck, z_a, fr.to_limbs(a_bl))
-    comm_b = commit(ipk.ck, z_b, fr.to_limbs(b_bl))
-    comm_c = commit(ipk.ck, z_c, fr.to_limbs(c_bl))
     ra_bl, rb_bl, rc_bl = rng.field(), rng.field(), rng.field()
-    comm_r_a = commit(ipk.ck, r_a, fr.to_limbs(ra_bl))
-    comm_r_b = commit(ipk.ck, r_b, fr.to_limbs(rb_bl))
-    comm_r_c = commit(ipk.ck, r_c, fr.to_limbs(rc_bl))
     one = fr.to_limbs(1)
     cross = combine_vectors(ctx, [compute_hp(ctx, z_a, r_b), compute_hp(ctx, z_b, r_a)], np.stack([one, one]))
     bl1 = rng.field()
-    comm_1 = commit(ipk.ck, cross, fr.to_limbs(bl1))
     bl2 = rng.field()
-    comm_2 = commit(ipk.ck, compute_hp(ctx, r_a, r_b), fr.to_limbs(bl2))
+    # the eight commitments are independent: one pipelined MSM batch (same points as eight commit() calls, :216-261)
+    comm_a, comm_b, comm_c, comm_r_a, comm_r_b, comm_r_c, comm_1, comm_2 = PedersenCommitment.commit_batch(
+        ipk.ck, [z_a, z_b, z_c, r_a, r_b, r_c, cross, compute_hp(ctx, r_a, r_b)],
+        [fr.to_limbs(v) for v in (a_bl, b_bl, c_bl, ra_bl, rb_bl, rc_bl, bl1, bl2)])
     first = FirstRoundMessage(comm_a, comm_b, comm_c,
                               FirstRoundMessageRandomness(comm_r_a, comm_r_b, comm_r_c, comm_1, comm_2))
     gamma = compute_challenge(fr, ipk.index_info.matrices_hash, input, first, sponge)
@@ -256,9 +252,10 @@ def verify(ivk: IndexProverKey, input: Sequence[int], proof: Proof, sponge: Opti
     zc = matrix_vec_mul(ivk.c, d_input, second.blinded_witness)
     rnd = second.randomness
     lim = (lambda v: fr.to_limbs(v)) if rnd is not None else (lambda v: None)
-    lhs = [commit(ivk.ck, za, lim(rnd.sigma_a) if rnd else None), commit(ivk.ck, zb, lim(rnd.sigma_b) if rnd else None),
-           commit(ivk.ck, zc, lim(rnd.sigma_c) if rnd else None),
-           commit(ivk.ck, compute_hp(ctx, za, zb), lim(rnd.sigma_o) if rnd else None)]
+    lhs = PedersenCommitment.commit_batch(  # four independent commitments, one pipelined batch (:375-403)
+        ivk.ck, [za, zb, zc, compute_hp(ctx, za, zb)],
+        [lim(rnd.sigma_a) if rnd else None, lim(rnd.sigma_b) if rnd else None, lim(rnd.sigma_c) if rnd else None,
+         lim(rnd.sigma_o) if rnd else None])
     L = ASForHadamardProducts._lincomb
     from .hp_as import _pt_eq
     if rnd is None:

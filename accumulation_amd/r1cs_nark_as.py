@@ -245,10 +245,9 @@ class ASForR1CSNark:
             r1, r2, r3 = rng.field(), rng.field(), rng.field()
             d_rin = ctx.fill(fr.to_limbs(r_in_val), in_len)
             d_rwit = ctx.fill(fr.to_limbs(r_wit_val), wit_len)
-            commit = PedersenCommitment.commit
-            cra = commit(ipk.ck, matrix_vec_mul(ipk.a, d_rin, d_rwit), fr.to_limbs(r1))
-            crb = commit(ipk.ck, matrix_vec_mul(ipk.b, d_rin, d_rwit), fr.to_limbs(r2))
-            crc = commit(ipk.ck, matrix_vec_mul(ipk.c, d_rin, d_rwit), fr.to_limbs(r3))
+            cra, crb, crc = PedersenCommitment.commit_batch(
+                ipk.ck, [matrix_vec_mul(m, d_rin, d_rwit) for m in (ipk.a, ipk.b, ipk.c)],
+                [fr.to_limbs(r1), fr.to_limbs(r2), fr.to_limbs(r3)])
             proof_randomness = ProofRandomness([r_in_val] * in_len, cra, crb, crc)
             prover_wit_rand = (d_rwit, r1, r2, r3)
         input_instances = [i.instance for i in inputs]
@@ -342,9 +341,8 @@ class ASForR1CSNark:
         zb = matrix_vec_mul(dk.b, d_in, wit.r1cs_blinded_witness)
         zc = matrix_vec_mul(dk.c, d_in, wit.r1cs_blinded_witness)
         rnd = wit.randomness
-        commit = PedersenCommitment.commit
-        ca = commit(dk.ck, za, None if rnd is None else fr.to_limbs(rnd.sigma_a))
-        cb = commit(dk.ck, zb, None if rnd is None else fr.to_limbs(rnd.sigma_b))
-        cc = commit(dk.ck, zc, None if rnd is None else fr.to_limbs(rnd.sigma_c))
+        ca, cb, cc = PedersenCommitment.commit_batch(
+            dk.ck, [za, zb, zc], [None if rnd is None else fr.to_limbs(v) for v in
+                                  ((rnd.sigma_a, rnd.sigma_b, rnd.sigma_c) if rnd is not None else (0, 0, 0))])
         comm_check = _pt_eq(ca, inst.comm_a) and _pt_eq(cb, inst.comm_b) and _pt_eq(cc, inst.comm_c)
         return bool(comm_check and ASForHadamardProducts.decide(dk.ck, HPAccumulator(inst.hp_instance, wit.hp_witness), None))

@@ -174,31 +174,60 @@ def bench_vec(log2n):
     ctx.close()
 
 
-def bench_hp_as(log2n, reps=3):
+class _Rng:
+    """MakeZK::Enabled(rng) stand-in: .field() -> scalar < 2^254."""
+
+    def __init__(self, seed):
+        self.s = seed
+
+    def field(self):
+        import hashlib
+        self.s += 1
+        return int.from_bytes(hashlib.sha256(self.s.to_bytes(8, "little")).digest(), "little") >> 2
+
+
+def bench_hp_as(log2n, reps=3, zk=False, constant_vectors=False):
+    """cfg5.  constant_vectors: inputs generated like the reference's harness (a, b = vec![rand; len], src/hp_as/mod.rs:991-992):
+    every MSM then sees all-equal scalars.  zk: MakeZK::Enabled -- 3 more commitments per accumulation, two of them to the
+    prover's CONSTANT hiding vectors (:179-230)."""
+    from accumulation_amd.hp_as import InputWitnessRandomness
     ctx = Context(ffi.AMSM_PALLAS)
+    fr = Fr(ctx.curve)
     n = 1 << log2n
     ck = PedersenCommitment.setup(ctx, n, seed=0x5EED1001, flags=ffi.AMSM_BASES_PRECOMPUTE)
     pk, vk, dk = AS.index(ck)
+    rng = _Rng(99) if zk else None
 
     def make_input(seed):
-        a = ctx.random_vector(seed, n, mont=True)
-        b = ctx.random_vector(seed + 1, n, mont=True)
-        pts, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [a, b, compute_hp(ctx, a, b)], mont=True)
-        return Accumulator(InputInstance(*[(pts[i], bool(infs[i])) for i in range(3)]), InputWitness(a, b, None))
+        if constant_vectors:
+            a = ctx.fill(fr.to_limbs(_Rng(seed).field()), n)
+            b = ctx.fill(fr.to_limbs(_Rng(seed + 1).field()), n)
+        else:
+            a = ctx.random_vector(seed, n, mont=True)
+            b = ctx.random_vector(seed + 1, n, mont=True)
+        if not zk:
+            pts, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [a, b, compute_hp(ctx, a, b)], mont=True)
+            return Accumulator(InputInstance(*[(pts[i], bool(infs[i])) for i in range(3)]), InputWitness(a, b, None))
+        rnd = InputWitnessRandomness(rng.field(), rng.field(), rng.field())
+        c = [PedersenCommitment.commit(ck, v, fr.to_limbs(r))
+             for v, r in zip((a, b, compute_hp(ctx, a, b)), (rnd.rand_1, rnd.rand_2, rnd.rand_3))]
+        return Accumulator(InputInstance(*c), InputWitness(a, b, rnd))
 
     inp0, inp1 = make_input(100), make_input(200)
-    acc0, _ = AS.prove(pk, [inp0], [], None, None)           # warm-up accumulation (like examples/scaling-as.rs:81-88)
+    acc0, _ = AS.prove(pk, [inp0], [], rng, None)           # warm-up accumulation (like examples/scaling-as.rs:81-88)
     ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        acc, proof = AS.prove(pk, [inp1], [acc0], None, None)  # timed: 1 input + 1 old accumulator => 2 MSMs
+        acc, proof = AS.prove(pk, [inp1], [acc0], rng, None)  # timed: 1 input + 1 old accumulator => 2 MSMs (+3 zk)
     dt = (time.perf_counter() - t0) / reps
     ok = AS.verify(ctx, vk, [inp1.instance], [acc0.instance], acc.instance, proof, None)
-    t1 = time.perf_counter()
     dec = AS.decide(dk, acc, None)
+    t1 = time.perf_counter()
+    dec = dec and AS.decide(dk, acc, None)
     t_dec = time.perf_counter() - t1
-    emit(kind="hp_as", log2n=log2n, n_all=2, zk=False, accumulations_per_s=1 / dt, prove_ms=dt * 1e3,
-         decide_ms=t_dec * 1e3, verify_ok=bool(ok), decide_ok=bool(dec), msms_per_prove=2)
+    emit(kind="hp_as", log2n=log2n, n_all=2, zk=zk, inputs="constant vectors (reference harness)" if constant_vectors else "uniform",
+         accumulations_per_s=1 / dt, prove_ms=dt * 1e3, decide_ms=t_dec * 1e3, verify_ok=bool(ok), decide_ok=bool(dec),
+         msms_per_prove=5 if zk else 2)
     ctx.close()
 
 
@@ -214,6 +243,8 @@ if __name__ == "__main__":
             bench_msm(ffi.AMSM_PALLAS, 22, reps=6)
     bench_vec(20 if quick else 22)
     bench_hp_as(18 if quick else 22)
+    bench_hp_as(18 if quick else 22, constant_vectors=True)
+    bench_hp_as(18 if quick else 22, zk=True)
     bench_degenerate(16 if quick else 20)
     bench_r1cs_nark_as(12 if quick else 18)
     bench_ipa(10 if quick else 16)
