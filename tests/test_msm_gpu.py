@@ -548,3 +548,41 @@ def test_large_key_precompute_and_fold_batched_affine(ctxs, cref, c):
         assert bool(ginf) == bool(einf) and np.array_equal(got, exp), hex(x)
         folded.free()
     ck.free()
+
+
+@pytest.mark.parametrize("mode", ["precomp", "plain"])
+def test_skewed_scalars_heavy_partitions_vs_c_oracle(ctxs, cref, mode):
+    """Constant vectors at a size where one bucket holds more than 2^17 entries: the prep stage then splits the partition
+    over 64 workgroups (k_prep_heavy_count / k_prep_heavy_place).  All-equal, all-one, two values, and a constant vector
+    with a uniform tenth mixed in (giant and ordinary buckets inside one partition), bit-exact against the CPU oracle;
+    the grouped form as well."""
+    from accumulation_amd import CommitterKey, VariableBaseMSM
+    c = o.PALLAS
+    ctx = ctxs[c.name]
+    n = 1 << 18
+    xy = cref.rng_points(c.curve_id, 0x5E1, n)
+    ck = CommitterKey.load(ctx, xy, None, FLAGS[mode])
+    uni = cref.rng_scalars(0x5E2, n)
+    x, y = uni[0].copy(), uni[1].copy()
+    cases = {"all_equal": np.tile(x, (n, 1)), "all_one": np.tile(h.scalars_to_np([1]), (n, 1)),
+             "all_r_minus_1": np.tile(h.scalars_to_np([c.r - 1]), (n, 1))}
+    two = np.tile(x, (n, 1))
+    two[1::2] = y
+    cases["two_values"] = two
+    mixed = np.tile(x, (n, 1))
+    mixed[::10] = uni[::10]
+    cases["mostly_equal"] = mixed
+    for name, sc in cases.items():
+        sc = np.ascontiguousarray(sc)
+        out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
+        ref, rinf = cref.msm(c.curve_id, xy, sc, threads=8)
+        assert oinf == rinf and np.array_equal(out, ref), (mode, name)
+    # grouped: two sums over the index classes of bit 17 (= halves), constant scalars
+    sc = np.ascontiguousarray(cases["mostly_equal"])
+    out, inf = VariableBaseMSM.multi_scalar_mul_grouped(ck, ctx.upload(sc), 17, mont=False)
+    for g in (0, 1):
+        masked = sc.copy()
+        masked[(np.arange(n) >> 17) & 1 != g] = 0
+        ref, rinf = cref.msm(c.curve_id, xy, masked, threads=8)
+        assert bool(inf[g]) == rinf and np.array_equal(out[g], ref), (mode, "grouped", g)
+    ck.free()
