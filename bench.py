@@ -16,7 +16,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/un
                   with hipEvents on the engine's stream inside the timed region;
   "cpu_baseline": the plain-C ark-ec-style restatement (oracle/ark_msm.c, kind "port") timed on this
                   box's host cores on the same inputs (rank 0, N = 1 only), and used to check the GPU
-                  result bit-for-bit.
+                  result bit-for-bit;
+  "accumulations": accumulations/sec (the metric's second half) of hp_as at 2^22, r1cs_nark_as at 2^18 constraints and
+                  ipa_pc_as at d + 1 = 2^16, measured after and outside the timed region (N = 1 only; --no-schemes skips).
 """
 from __future__ import annotations
 
@@ -45,6 +47,7 @@ def main() -> int:
     ap.add_argument("--curve", default="pallas", choices=["pallas", "bls12_381_g1"])
     ap.add_argument("--no-precompute", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-schemes", action="store_true", help="skip the accumulations/sec lines (second half of the metric)")
     ap.add_argument("--sync", action="store_true", help="one synchronous MSM call per step (no MSMs overlapped)")
     ap.add_argument("--cpu-log2n", type=int, default=None, help="sample size of the CPU baseline (default: log2n)")
     args = ap.parse_args()
@@ -193,11 +196,39 @@ def main() -> int:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ctx, ck, scalars, curve_id, args, out.copy(), bool(inf.value),
                                                   last["xy"], last["inf"])
+        if world == 1 and not args.no_schemes and args.log2n == 20 and args.curve == "pallas":
+            result["accumulations"] = scheme_rates()
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def scheme_rates():
+    """accumulations/sec (one `prove` = one accumulation; BASELINE.json's second metric) of the three schemes at the
+    sizes of configs 1, 3 and 4, after the timed region and outside it: tools/bench_configs.py's workloads (1 input + 1 old
+    accumulator, no zk), each verified and decided.  Never fails the bench line: an error is reported in place."""
+    import importlib.util
+    out = {}
+    try:
+        spec = importlib.util.spec_from_file_location("amsm_bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+        bc = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bc)
+        got = []
+        bc.emit = lambda **kw: got.append(kw)
+        for name, fn in (("hp_as_2^22", lambda: bc.bench_hp_as(22)), ("r1cs_nark_as_2^18", lambda: bc.bench_r1cs_nark_as(18)),
+                         ("ipa_pc_as_2^16", lambda: bc.bench_ipa(16))):
+            try:
+                fn()
+                r = got[-1]
+                out[name] = {"accumulations_per_s": round(r["accumulations_per_s"], 2), "prove_ms": round(r["prove_ms"], 3),
+                             "decide_ms": round(r["decide_ms"], 3), "verified": bool(r["verify_ok"] and r["decide_ok"])}
+            except Exception as e:  # noqa: BLE001
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 ALU_PEAK_GMADD = {"pallas": 18.7, "bls12_381_g1": 6.95}  # isolated xyzz_madd, all SIMDs busy (tools/fp_bench.hip)
