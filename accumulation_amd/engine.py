@@ -29,6 +29,8 @@ def _ptr(a: Optional[np.ndarray]):
     costs ~50 us per call on average and tens of ms when a full collection hits (measured: 13 of 26 ms of an IPA opening)."""
     if a is None:
         return None
+    if not a.flags.c_contiguous:
+        raise ValueError("the C ABI takes contiguous arrays")
     p = _ArrayPtr(a.__array_interface__["data"][0])
     p._keep = a
     return p
