@@ -21,7 +21,9 @@ rs = np.random.RandomState(seed)
 t_end = time.time() + budget
 n_cases = 0
 ctxs = {c.name: Context(c.curve_id) for c in (o.PALLAS, o.BLS12_381_G1)}
-pools = {c.name: cref.rng_points(c.curve_id, 1000 + seed, 40000) for c in (o.PALLAS, o.BLS12_381_G1)}
+BIG = 1 << 18  # a few cases per minute at sizes where skewed scalars make heavy prep partitions and keys fold in batches
+pools = {c.name: cref.rng_points(c.curve_id, 1000 + seed, BIG) for c in (o.PALLAS, o.BLS12_381_G1)}
+n_big = n_fold = 0
 
 
 def scalars(c, n, kind):
@@ -45,6 +47,57 @@ def scalars(c, n, kind):
 while time.time() < t_end:
     c = o.PALLAS if rs.rand() < 0.7 else o.BLS12_381_G1
     ctx = ctxs[c.name]
+    roll = rs.rand()
+    if roll < 0.02:
+        # large and skewed: constant / few-valued / mostly-constant scalars over >= 2^17 points (heavy prep partitions,
+        # batched affine conversion of the precomputed levels)
+        n = int(rs.randint(1 << 17, BIG + 1))
+        xy = pools[c.name][:n]
+        ck = CommitterKey.load(ctx, xy, None, int(rs.choice([1, 2])))
+        sc = scalars(c, n, str(rs.choice(["few", "uniform", "top"])))
+        if rs.rand() < 0.5:
+            step = int(rs.randint(2, 50))  # a uniform fraction mixed in
+            sc[::step] = cref.rng_scalars(int(rs.randint(1 << 30)), n)[::step]
+        out, inf = VariableBaseMSM.multi_scalar_mul(ck, sc)
+        ref, rinf = cref.msm(c.curve_id, xy, sc, threads=8)
+        assert inf == rinf and np.array_equal(out, ref), ("big", c.name, n)
+        ck.free()
+        n_big += 1
+        n_cases += 1
+        continue
+    if roll < 0.05:
+        # key fold l + x r (NAF ladder; batched conversion above 2^17 points) through MSM linearity:
+        # msm(fold(key), s) == msm(key, [s ; x s])
+        from accumulation_amd.scalar_field import Fr
+        fr = Fr(ctx.curve)
+        half = int(rs.choice([1, 2, 7, 64, 1000, 5000, (1 << 17) - 1, 1 << 17]))
+        if rs.rand() < 0.3:
+            half = int(rs.randint(1, BIG // 2 + 1))
+        xy = pools[c.name][: 2 * half]
+        ck = CommitterKey.load(ctx, xy, None, int(rs.choice([1, 2])))
+        x = int(o.rng_scalar(int(rs.randint(1 << 30)), 0)) % c.r
+        nbits = 255
+        if rs.rand() < 0.6:
+            x %= 1 << 128
+            nbits = 128
+        if rs.rand() < 0.1:
+            x = int(rs.choice([0, 1, 2, 3])) if nbits == 128 else c.r - int(rs.randint(1, 4))
+        folded = ck.fold(half, fr.to_limbs(x), nbits)
+        base = [int(o.rng_scalar(int(rs.randint(1 << 30)), i)) % c.r for i in range(16)]
+        s_half = (base * (half // 16 + 1))[:half]
+        got, ginf = VariableBaseMSM.multi_scalar_mul(folded, ctx.upload(h.scalars_to_np(s_half)), mont=False)
+        s_full = s_half + [(v * x) % c.r for v in s_half]
+        sc_full = h.scalars_to_np(s_full)
+        if 2 * half <= 40000:  # small enough for the CPU oracle: pins the identity's right-hand side too
+            exp, einf = cref.msm(c.curve_id, xy, sc_full, threads=4)
+        else:
+            exp, einf = VariableBaseMSM.multi_scalar_mul(ck, ctx.upload(sc_full), mont=False)
+        assert bool(ginf) == bool(einf) and np.array_equal(got, exp), ("fold", c.name, half, hex(x), nbits)
+        folded.free()
+        ck.free()
+        n_fold += 1
+        n_cases += 1
+        continue
     n_key = int(rs.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4097, 20000, 40000]))
     n_key = min(n_key, 40000)
     xy = pools[c.name][:n_key]
@@ -91,4 +144,4 @@ while time.time() < t_end:
     ck.free()
     ctx.set_window(0)
     n_cases += 1
-print(f"fuzz ok: {n_cases} cases in {budget:.0f} s (seed {seed})")
+print(f"fuzz ok: {n_cases} cases ({n_big} large skewed, {n_fold} key folds) in {budget:.0f} s (seed {seed})")
