@@ -325,7 +325,7 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   HIP_TRY(hipMemsetAsync(sl->misc.p, 0, 64, st));
   stage_mark(ctx, sl, ST_DIGITS, st);
   if (ctx->custom_prep && prep_supported(g)) {
-    // 5-dispatch prep chain (prep_kernels.h); the stage marks keep their names: "sort" = scatter + local sort
+    // short prep chain (prep_kernels.h: 5 dispatches + 2 for skewed inputs); the stage marks keep their names: "sort" = scatter + local sort
     TRY(ensure(sl->prep_small, prep_small_words(g) * sizeof(u32)));
     PrepBuffers pb;
     pb.d_small = (u32*)sl->prep_small.p;

@@ -7,7 +7,7 @@
 //   prep     : (prep_kernels.h) scalars -> signed c-bit digits (halves the buckets) -> one entry per non-zero digit
 //              (value = sign | index into the pre-multiplied generator table) -> the entries grouped by bucket:
 //              partition histogram, scatter into ~512 partitions, per-partition counting sort, bucket table
-//              (start[], number of K0-sized work items, last-of-bucket flags).  Five dispatches; the first version
+//              (start[], number of K0-sized work items, last-of-bucket flags).  Five dispatches (+2 for skewed inputs); the first version
 //              (k_digits + rocPRIM radix sort + k_bounds + rocPRIM scan, 14 dispatches) is kept as a fallback.
 //   accum L0 : one lane per work item: <= K0 mixed additions (XYZZ, 8M+2S) gathered from the table.
 //              Work items are equal sized, so wave64 lanes stay converged whatever the digit

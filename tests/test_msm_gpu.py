@@ -455,7 +455,7 @@ def test_top_of_field_scalars(cref, prep):
 
 @pytest.mark.parametrize("prep", ["rocprim", "custom"])
 def test_prep_chain_variants_agree(cref, prep):
-    """The 5-dispatch prep chain (prep_kernels.h) and its fallback (digits + rocPRIM sort + bounds + scan) feed
+    """The custom prep chain (prep_kernels.h) and its fallback (digits + rocPRIM sort + bounds + scan) feed
     accumulate L0 the same buckets: both must reproduce the CPU oracle on uniform, all-equal and sparse scalars, with
     precomputed and plain keys, on both curves."""
     import os
