@@ -244,6 +244,33 @@ struct PedersenCommitment {
     out.infinity = inf != 0;
     return out;
   }
+  // Several independent commitments to vectors of one length as ONE pipelined MSM batch; the hiding terms
+  // randomizer * hiding_generator are added on the host.  Same points as vecs.size() calls of commit().
+  static std::vector<Affine> commit_batch(const CommitterKey& ck, const std::vector<const FrVector*>& vecs,
+                                          const std::vector<const Fr*>& randomizers) {
+    Context& ctx = ck.ctx();
+    std::vector<Affine> out = MsmBatch::same_bases(ck, vecs);
+    const size_t w = 2 * (size_t)ctx.fq_limbs();
+    const int curve = amsm_ctx_curve(ctx.get());
+    for (size_t i = 0; i < out.size(); i++) {
+      const Fr* r = i < randomizers.size() ? randomizers[i] : nullptr;
+      if (!r) continue;
+      if (ck.hiding_generator.empty()) throw Error(AMSM_E_INVALID_ARG, "commit_batch: key has no hiding generator");
+      std::vector<uint64_t> xy(out[i].xy);
+      xy.insert(xy.end(), ck.hiding_generator.begin(), ck.hiding_generator.end());
+      uint8_t infs[2] = {(uint8_t)(out[i].infinity ? 1 : 0), 0};
+      Fr sc[2] = {Fr{1, 0, 0, 0}, *r};
+      check(amsm_fr_to_mont(curve, sc[0].data(), 1, sc[0].data()), "amsm_fr_to_mont");
+      Affine sum;
+      sum.xy.assign(w, 0);
+      uint8_t inf = 0;
+      check(amsm_host_lincomb(curve, xy.data(), infs, reinterpret_cast<const uint64_t*>(sc), 2, sum.xy.data(), &inf),
+            "amsm_host_lincomb");
+      sum.infinity = inf != 0;
+      out[i] = sum;
+    }
+    return out;
+  }
 };
 
 // The scalar-field vector loops of ASForHadamardProducts (src/hp_as/mod.rs).

@@ -303,13 +303,12 @@ class ASForHadamardProducts {
       hid_a = filled(ctx, a_val, hp_vec_len);
       hid_b = filled(ctx, b_val, hp_vec_len);
       hid_r = InputWitnessRandomness{fr.to_mont(rng()), fr.to_mont(rng()), fr.to_mont(rng())};
-      Affine c1 = PedersenCommitment::commit(pk, *hid_a, &hid_r.rand_1);
-      Affine c2 = PedersenCommitment::commit(pk, *hid_b, &hid_r.rand_2);
       FrVector p1 = compute_hp(*hid_a, *witnesses.front()->b_vec);
       FrVector p2 = compute_hp(*witnesses.back()->a_vec, *hid_b);
       FrVector sum = combine_vectors(ctx, {&p1, &p2}, {fr.one(), fr.one()});
-      Affine c3 = PedersenCommitment::commit(pk, sum, &hid_r.rand_3);
-      hiding_comms = ProofHidingCommitments{c1, c2, c3};
+      // three independent commitments: one pipelined batch (same points as three commit() calls, :196-214)
+      auto c = PedersenCommitment::commit_batch(pk, {hid_a.get(), hid_b.get(), &sum}, {&hid_r.rand_1, &hid_r.rand_2, &hid_r.rand_3});
+      hiding_comms = ProofHidingCommitments{c[0], c[1], c[2]};
     }
     absorb_statement(sponge, pk.supported_num_elems(), instances, hiding_comms);  // step 4
     std::vector<Fr> mu = squeeze_mu(sponge, fr, num_all, make_zk);
@@ -400,9 +399,11 @@ class ASForHadamardProducts {
       c2 = c[1];
       c3 = c[2];
     } else {
-      c1 = PedersenCommitment::commit(dk, *w.a_vec, &w.randomness->rand_1);
-      c2 = PedersenCommitment::commit(dk, *w.b_vec, &w.randomness->rand_2);
-      c3 = PedersenCommitment::commit(dk, product, &w.randomness->rand_3);
+      auto c = PedersenCommitment::commit_batch(dk, {w.a_vec.get(), w.b_vec.get(), &product},
+                                                {&w.randomness->rand_1, &w.randomness->rand_2, &w.randomness->rand_3});
+      c1 = c[0];
+      c2 = c[1];
+      c3 = c[2];
     }
     return c1 == acc.instance.comm_1 && c2 == acc.instance.comm_2 && c3 == acc.instance.comm_3;
   }

@@ -250,20 +250,17 @@ struct R1CSNark {
     FrVector zeros(ctx, std::vector<Fr>(input.size(), fr.zero()));
     FrVector r_a = ipk.a->vec_mul(zeros, r), r_b = ipk.b->vec_mul(zeros, r), r_c = ipk.c->vec_mul(zeros, r);
     Fr a_bl = fr.to_mont(rng()), b_bl = fr.to_mont(rng()), c_bl = fr.to_mont(rng());
-    Affine comm_a = PedersenCommitment::commit(ck, z_a, &a_bl);
-    Affine comm_b = PedersenCommitment::commit(ck, z_b, &b_bl);
-    Affine comm_c = PedersenCommitment::commit(ck, z_c, &c_bl);
     Fr ra_bl = fr.to_mont(rng()), rb_bl = fr.to_mont(rng()), rc_bl = fr.to_mont(rng());
-    Affine comm_r_a = PedersenCommitment::commit(ck, r_a, &ra_bl);
-    Affine comm_r_b = PedersenCommitment::commit(ck, r_b, &rb_bl);
-    Affine comm_r_c = PedersenCommitment::commit(ck, r_c, &rc_bl);
     FrVector x1 = hp_as::compute_hp(z_a, r_b), x2 = hp_as::compute_hp(z_b, r_a);
     FrVector cross = hp_as::combine_vectors(ctx, {&x1, &x2}, {fr.one(), fr.one()});
     Fr bl1 = fr.to_mont(rng());
-    Affine comm_1 = PedersenCommitment::commit(ck, cross, &bl1);
     Fr bl2 = fr.to_mont(rng());
     FrVector rr = hp_as::compute_hp(r_a, r_b);
-    Affine comm_2 = PedersenCommitment::commit(ck, rr, &bl2);
+    // eight independent commitments: one pipelined MSM batch (same points as eight commit() calls, :216-261)
+    auto cm = PedersenCommitment::commit_batch(ck, {&z_a, &z_b, &z_c, &r_a, &r_b, &r_c, &cross, &rr},
+                                               {&a_bl, &b_bl, &c_bl, &ra_bl, &rb_bl, &rc_bl, &bl1, &bl2});
+    const Affine &comm_a = cm[0], &comm_b = cm[1], &comm_c = cm[2], &comm_r_a = cm[3], &comm_r_b = cm[4], &comm_r_c = cm[5],
+                 &comm_1 = cm[6], &comm_2 = cm[7];
     FirstRoundMessage first{comm_a, comm_b, comm_c, FirstRoundMessageRandomness{comm_r_a, comm_r_b, comm_r_c, comm_1, comm_2}};
     Fr gamma = compute_challenge(fr, ipk.index_info.matrices_hash, input, first, sponge);
     auto blinded = std::make_shared<FrVector>(hp_as::combine_vectors(ctx, {witness.get(), &r}, {fr.one(), gamma}));  // w + gamma r
@@ -290,10 +287,9 @@ struct R1CSNark {
              zc = ivk.c->vec_mul(d_input, *second.blinded_witness);
     FrVector zab = hp_as::compute_hp(za, zb);
     const SecondRoundMessageRandomness* rnd = second.randomness ? &*second.randomness : nullptr;
-    Affine lhs[4] = {PedersenCommitment::commit(ck, za, rnd ? &rnd->sigma_a : nullptr),
-                     PedersenCommitment::commit(ck, zb, rnd ? &rnd->sigma_b : nullptr),
-                     PedersenCommitment::commit(ck, zc, rnd ? &rnd->sigma_c : nullptr),
-                     PedersenCommitment::commit(ck, zab, rnd ? &rnd->sigma_o : nullptr)};
+    std::vector<Affine> lhs = PedersenCommitment::commit_batch(  // four independent commitments, one batch (:375-403)
+        ck, {&za, &zb, &zc, &zab},
+        {rnd ? &rnd->sigma_a : nullptr, rnd ? &rnd->sigma_b : nullptr, rnd ? &rnd->sigma_c : nullptr, rnd ? &rnd->sigma_o : nullptr});
     Affine rhs[4];
     if (!rnd) {
       rhs[0] = first.comm_a;

@@ -161,8 +161,8 @@ class ASForR1CSNark {
       auto d_rin = hp_as::filled(ctx, fr.to_mont(r_in_val), in_len);
       d_rwit = hp_as::filled(ctx, fr.to_mont(r_wit_val), wit_len);
       FrVector za = ipk.a->vec_mul(*d_rin, *d_rwit), zb = ipk.b->vec_mul(*d_rin, *d_rwit), zc = ipk.c->vec_mul(*d_rin, *d_rwit);
-      proof_randomness = ProofRandomness{std::vector<Fr>(in_len, r_in_val), PedersenCommitment::commit(ck, za, &r1),
-                                         PedersenCommitment::commit(ck, zb, &r2), PedersenCommitment::commit(ck, zc, &r3)};
+      auto cr = PedersenCommitment::commit_batch(ck, {&za, &zb, &zc}, {&r1, &r2, &r3});
+      proof_randomness = ProofRandomness{std::vector<Fr>(in_len, r_in_val), cr[0], cr[1], cr[2]};
     }
     std::vector<const InputInstance*> input_instances;
     for (auto& i : inputs) input_instances.push_back(&i.instance);
@@ -274,9 +274,9 @@ class ASForR1CSNark {
     const FrVector& w = *acc.witness.r1cs_blinded_witness;
     FrVector za = dk.a->vec_mul(d_in, w), zb = dk.b->vec_mul(d_in, w), zc = dk.c->vec_mul(d_in, w);
     const AccumulatorWitnessRandomness* rnd = acc.witness.randomness ? &*acc.witness.randomness : nullptr;
-    Affine ca = PedersenCommitment::commit(ck, za, rnd ? &rnd->sigma_a : nullptr);
-    Affine cb = PedersenCommitment::commit(ck, zb, rnd ? &rnd->sigma_b : nullptr);
-    Affine cc = PedersenCommitment::commit(ck, zc, rnd ? &rnd->sigma_c : nullptr);
+    auto cd = PedersenCommitment::commit_batch(
+        ck, {&za, &zb, &zc}, {rnd ? &rnd->sigma_a : nullptr, rnd ? &rnd->sigma_b : nullptr, rnd ? &rnd->sigma_c : nullptr});
+    const Affine &ca = cd[0], &cb = cd[1], &cc = cd[2];
     bool comm_check = ca == acc.instance.comm_a && cb == acc.instance.comm_b && cc == acc.instance.comm_c;
     return comm_check && HP::decide(ck, hp_as::Accumulator{acc.instance.hp_instance, acc.witness.hp_witness});
   }
