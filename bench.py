@@ -238,8 +238,8 @@ def alu_roofline(args, ck, n, kernel_ms):
     """Mixed additions per second of accumulate L0 against the isolated-ALU ceiling of the same formula."""
     if kernel_ms <= 0 or not ck.precomputed:
         return None
-    windows = 16 if args.curve == "pallas" else None
-    if args.log2n != 20 or windows is None:
+    windows = 16  # both curves have 255-bit scalars: c = 16, W = 16 at 2^20
+    if args.log2n != 20:
         return None
     madds = n * windows  # one gathered mixed addition per (pair, window); c = 16, W = 16 at 2^20
     achieved = madds / (kernel_ms * 1e-3) / 1e9
