@@ -1,0 +1,32 @@
+#!/bin/bash
+# AddressSanitizer run of the library's HOST side (amsm_host_lincomb with its fixed-base cache, amsm_fr_*): the four
+# translation units are compiled host-only (`--offload-host-only`, no device code, so no GPU ASAN / xnack is involved),
+# the device fat binaries they reference are stubbed, and tests/test_host_fr_cpu.py runs against that build.
+# Usage (from the repo root, CPU only): bash tools/asan_host.sh
+set -eu
+R=$(pwd)
+D=$R/build/asan
+mkdir -p $D
+cd $D
+for u in api kern_pallas kern_bls12_381 kern_fr; do
+  hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 --offload-host-only -fsanitize=address -fno-omit-frame-pointer \
+    -Wno-unused-result -Wno-pass-failed -c $R/accumulation_amd/csrc/$u.hip -o $u.o &
+done
+wait
+hipcc -shared -fPIC -fsanitize=address --offload-host-only -o libamsm_asan.so api.o kern_pallas.o kern_bls12_381.o kern_fr.o 2>/dev/null || true
+nm -u api.o kern_pallas.o kern_bls12_381.o kern_fr.o | awk '/__hip_fatbin_/ {print $2}' | sort -u > fatbins.txt
+for s in $(cat fatbins.txt); do echo "__attribute__((aligned(4096))) const char $s[4096] = {0};"; done > stub.c
+gcc -shared -fPIC -o libstub.so stub.c
+hipcc -shared -fPIC -fsanitize=address --offload-host-only -o libamsm_asan.so api.o kern_pallas.o kern_bls12_381.o kern_fr.o \
+  -L. -lstub -Wl,-rpath,$D
+cat > run_host_tests.py <<PY
+import sys
+sys.path.insert(0, "$R")
+import accumulation_amd.ffi as ffi
+ffi.LIB_PATH = "$D/libamsm_asan.so"
+import pytest
+sys.exit(pytest.main(["-x", "-q", "$R/tests/test_host_fr_cpu.py", "-p", "no:cacheprovider"]))
+PY
+cd $R
+ASAN_LIB=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+LD_PRELOAD=$ASAN_LIB ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 python $D/run_host_tests.py
