@@ -269,6 +269,53 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// ---- quad-cooperative tail (ec.h: xyzz_add_quad / xyzz_dbl_quad): logical lane = an aligned quad of lanes ----
+// butterfly over the 16 quads of a wave; every quad ends with the wave's sum
+template <class Fq>
+AMSM_DEV void wave_reduce_xyzz_quad(XYZZ<Fq>& acc) {
+#pragma unroll 1
+  for (int m = 32; m >= 4; m >>= 1) {
+    XYZZ<Fq> o;
+#pragma unroll
+    for (int i = 0; i < Fq::L; i++) {
+      o.x.v[i] = __shfl_xor(acc.x.v[i], m, 64);
+      o.y.v[i] = __shfl_xor(acc.y.v[i], m, 64);
+      o.zz.v[i] = __shfl_xor(acc.zz.v[i], m, 64);
+      o.zzz.v[i] = __shfl_xor(acc.zzz.v[i], m, 64);
+    }
+    bool low = (threadIdx.x & m) == 0;  // both quads add in the same order
+    XYZZ<Fq> a = low ? acc : o;
+    XYZZ<Fq> b2 = low ? o : acc;
+    xyzz_add_quad<Fq>(a, b2);
+    acc = a;
+  }
+}
+// lds: one XYZZ record per wave of the workgroup.  Result valid in the first quad of the workgroup.
+template <class Fq>
+AMSM_DEV void block_reduce_xyzz_quad(XYZZ<Fq>& acc, u32* lds) {
+  wave_reduce_xyzz_quad<Fq>(acc);
+  u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) xyzz_store<Fq>(lds, wave, acc);
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    for (u32 w = 1; w < (blockDim.x >> 6); w++) {
+      XYZZ<Fq> o = xyzz_load<Fq>(lds, w);
+      xyzz_add_quad<Fq>(acc, o);
+    }
+  }
+}
+template <class Fq>
+AMSM_DEV XYZZ<Fq> xyzz_mul_small_quad(const XYZZ<Fq>& p, u32 k) {
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  if (k == 0) return acc;
+  int top = 31 - __clz(k);
+  for (int i = top; i >= 0; i--) {
+    acc = xyzz_dbl_quad<Fq>(acc);
+    if ((k >> i) & 1) xyzz_add_quad<Fq>(acc, p);
+  }
+  return acc;
+}
+
 // k * p for a small non-negative integer k (double-and-add, MSB first)
 template <class Fq>
 AMSM_DEV XYZZ<Fq> xyzz_mul_small(const XYZZ<Fq>& p, u32 k) {
@@ -319,6 +366,47 @@ __global__ void __launch_bounds__(64) k_fold(const u32* __restrict__ in, u32 n, 
   wave_reduce_xyzz<Fq>(acc);
   if (threadIdx.x == 0) {
     // the folded record leaves the device: C-ABI Montgomery radix from here on (identity on saturated fields)
+    XYZZ<Fq> e;
+    e.x = fe_export<Fq>(acc.x);
+    e.y = fe_export<Fq>(acc.y);
+    e.zz = fe_export<Fq>(acc.zz);
+    e.zzz = fe_export<Fq>(acc.zzz);
+    xyzz_store<Fq>(out, blockIdx.x, e);
+  }
+}
+
+// The same two kernels with a quad of lanes per logical lane (the tail of a blocking MSM call is a chain of ~45 dependent
+// point operations on a few waves: 0.24 ms; the quad schedule cuts the depth of each).  grid.x = 4x k_bucket_reduce's.
+template <class Fq>
+__global__ void __launch_bounds__(256)
+    k_bucket_reduce_quad(const u32* __restrict__ buckets, MsmGeom g, u32* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
+  u32 set = blockIdx.y;
+  u32 t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;  // logical lane: owns buckets [t*s, (t+1)*s)
+  XYZZ<Fq> total = xyzz_inf<Fq>();
+  if (t < g.red_threads) {
+    u32 lo = t * g.red_s;
+    XYZZ<Fq> run = xyzz_inf<Fq>(), sum = xyzz_inf<Fq>();
+    for (int k = (int)g.red_s - 1; k >= 0; k--) {
+      XYZZ<Fq> bk = xyzz_load<Fq>(buckets, (size_t)set * g.nb + lo + k);
+      xyzz_add_quad<Fq>(run, bk);
+      xyzz_add_quad<Fq>(sum, run);
+    }
+    total = xyzz_mul_small_quad<Fq>(run, lo);
+    xyzz_add_quad<Fq>(total, sum);
+  }
+  block_reduce_xyzz_quad<Fq>(total, lds);
+  if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)set * gridDim.x + blockIdx.x, total);
+}
+template <class Fq>
+__global__ void __launch_bounds__(64) k_fold_quad(const u32* __restrict__ in, u32 n, u32* __restrict__ out) {
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  for (u32 k = threadIdx.x >> 2; k < n; k += 16) {  // 16 quads
+    XYZZ<Fq> p = xyzz_load<Fq>(in, (size_t)blockIdx.x * n + k);
+    xyzz_add_quad<Fq>(acc, p);
+  }
+  wave_reduce_xyzz_quad<Fq>(acc);
+  if (threadIdx.x == 0) {
     XYZZ<Fq> e;
     e.x = fe_export<Fq>(acc.x);
     e.y = fe_export<Fq>(acc.y);
