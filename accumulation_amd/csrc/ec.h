@@ -195,12 +195,12 @@ AMSM_DEV Affine<P> affine_neg_if(const Affine<P>& p, bool negate) {
 // xyzz_dbl above (same primitives on the same values -> same bounds, same limbs); only the schedule differs.  A lone
 // product on a lane of a fused level is written as the two-product form with a zero second product.
 // All four lanes of the quad must be active and hold equal operands.
-template <class P>
-AMSM_DEV Fe<P> quad_bcast(const Fe<P>& v, u32 k) {
+template <class P, int K>
+AMSM_DEV Fe<P> quad_bcast(const Fe<P>& v) {  // lane K of the quad -> all four lanes: one v_mov_b32 quad_perm per limb
   Fe<P> r;
-  const int src = (int)((__lane_id() & ~3u) | k);
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);  // DPP quad_perm:[K,K,K,K]
 #pragma unroll
-  for (int i = 0; i < P::L; i++) r.v[i] = (u32)__shfl((int)v.v[i], src, 64);
+  for (int i = 0; i < P::L; i++) r.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)v.v[i], ctrl, 0xf, 0xf, false);
   return r;
 }
 template <class P>
@@ -222,21 +222,21 @@ AMSM_DEV XYZZ<P> xyzz_dbl_quad(const XYZZ<P>& p) {
   const Fe<P> zero = fe_zero<P>();
   Fe<P> u = fe_dbl<P>(p.y);
   Fe<P> sq = fe_sqr<P>(fe_sel<P>(k == 1u, p.x, u));  // lane 0: v = u^2, lane 1: xx = x^2
-  Fe<P> v = quad_bcast<P>(sq, 0), xx = quad_bcast<P>(sq, 1);
+  Fe<P> v = quad_bcast<P, 0>(sq), xx = quad_bcast<P, 1>(sq);
   Fe<P> m = fe_triple<P>(xx);
   // lane 0: w = u v, lane 1: s = x v, lane 2: zz3 = v zz
   Fe<P> m2 = fe_mul<P>(fe_sel4<P>(k, u, p.x, v, v), fe_sel4<P>(k, v, v, p.zz, p.zz));
   Fe<P> mm = fe_sqr<P>(m);
-  Fe<P> w = quad_bcast<P>(m2, 0), s = quad_bcast<P>(m2, 1);
+  Fe<P> w = quad_bcast<P, 0>(m2), s = quad_bcast<P, 1>(m2);
   XYZZ<P> r;
-  r.zz = quad_bcast<P>(m2, 2);
+  r.zz = quad_bcast<P, 2>(m2);
   r.x = fe_sub_bcc_k<P, 4>(mm, zero, s);
   Fe<P> t = fe_sub_k<P, 8>(s, r.x);
   // lane 0: y3 = m t + (4p - y) w, lane 1: zzz3 = w zzz (+ 0)
   Fe<P> m3 = fe_mul_sub_mul_k<P, 4>(fe_sel<P>(k == 0u, m, w), fe_sel<P>(k == 0u, t, p.zzz), fe_sel<P>(k == 0u, p.y, zero),
                                     fe_sel<P>(k == 0u, w, zero));
-  r.y = quad_bcast<P>(m3, 0);
-  r.zzz = quad_bcast<P>(m3, 1);
+  r.y = quad_bcast<P, 0>(m3);
+  r.zzz = quad_bcast<P, 1>(m3);
   return r;
 }
 
@@ -251,7 +251,7 @@ AMSM_DEV void xyzz_add_quad(XYZZ<P>& acc, const XYZZ<P>& q) {
   const Fe<P> zero = fe_zero<P>();
   // lane 0: u1 = X1 ZZ2, lane 1: u2 = X2 ZZ1, lane 2: s1 = Y1 ZZZ2, lane 3: s2 = Y2 ZZZ1
   Fe<P> m1 = fe_mul<P>(fe_sel4<P>(k, acc.x, q.x, acc.y, q.y), fe_sel4<P>(k, q.zz, acc.zz, q.zzz, acc.zzz));
-  Fe<P> u1 = quad_bcast<P>(m1, 0), u2 = quad_bcast<P>(m1, 1), s1 = quad_bcast<P>(m1, 2), s2 = quad_bcast<P>(m1, 3);
+  Fe<P> u1 = quad_bcast<P, 0>(m1), u2 = quad_bcast<P, 1>(m1), s1 = quad_bcast<P, 2>(m1), s2 = quad_bcast<P, 3>(m1);
   Fe<P> p = fe_sub_k<P, 2>(u2, u1);
   Fe<P> r = fe_sub_k<P, 2>(s2, s1);
   if (fe_is_zero_mod<P, 4>(p)) {  // uniform over the quad: replicated operands
@@ -261,20 +261,20 @@ AMSM_DEV void xyzz_add_quad(XYZZ<P>& acc, const XYZZ<P>& q) {
   }
   Fe<P> sq = fe_sqr<P>(fe_sel<P>(k == 1u, r, p));                                                      // lane 0: pp, lane 1: rr
   Fe<P> m2 = fe_mul<P>(fe_sel<P>(k == 3u, acc.zzz, acc.zz), fe_sel<P>(k == 3u, q.zzz, q.zz));        // lane 2: ZZ1 ZZ2, lane 3: ZZZ1 ZZZ2
-  Fe<P> pp = quad_bcast<P>(sq, 0), rr = quad_bcast<P>(sq, 1);
-  Fe<P> zz12 = quad_bcast<P>(m2, 2), zzz12 = quad_bcast<P>(m2, 3);
+  Fe<P> pp = quad_bcast<P, 0>(sq), rr = quad_bcast<P, 1>(sq);
+  Fe<P> zz12 = quad_bcast<P, 2>(m2), zzz12 = quad_bcast<P, 3>(m2);
   // lane 0: ppp = p pp, lane 1: qq = u1 pp, lane 2: zz3 = zz12 pp
   Fe<P> m3 = fe_mul<P>(fe_sel4<P>(k, p, u1, zz12, zz12), pp);
-  Fe<P> ppp = quad_bcast<P>(m3, 0), qq = quad_bcast<P>(m3, 1);
-  acc.zz = quad_bcast<P>(m3, 2);
+  Fe<P> ppp = quad_bcast<P, 0>(m3), qq = quad_bcast<P, 1>(m3);
+  acc.zz = quad_bcast<P, 2>(m3);
   Fe<P> x3 = fe_sub_bcc_k<P, 4>(rr, ppp, qq);
   Fe<P> t = fe_sub_k<P, 8>(qq, x3);
   // lane 0: y3 = r t + (2p - s1) ppp, lane 1: zzz3 = zzz12 ppp (+ 0)
   Fe<P> m4 = fe_mul_sub_mul_k<P, 2>(fe_sel<P>(k == 0u, r, zzz12), fe_sel<P>(k == 0u, t, ppp), fe_sel<P>(k == 0u, s1, zero),
                                     fe_sel<P>(k == 0u, ppp, zero));
   acc.x = x3;
-  acc.y = quad_bcast<P>(m4, 0);
-  acc.zzz = quad_bcast<P>(m4, 1);
+  acc.y = quad_bcast<P, 0>(m4);
+  acc.zzz = quad_bcast<P, 1>(m4);
 }
 
 // XYZZ -> affine with one field inversion (off the hot path: key precomputation only).
