@@ -113,3 +113,33 @@ def test_pieces_vs_oracle(env):
     assert not AS.verify(ctx, vk, insts, [], acc.instance, bad, None)
     acc.witness.coeffs[0] = (acc.witness.coeffs[0] + 1) % c.r
     assert not AS.decide(dk, acc, None)
+
+
+def test_config0_size_degree_1023(cref):
+    """BASELINE.json config 0 (examples/scaling-as.rs:62-63,91-104): trivial_pc_as on Pallas at degree 2^10 - 1, one input
+    accumulated into two old accumulators -- 3 MSMs of <= 1023 points in prove, one of 1024 in decide -- with the
+    commitments and the accumulator's commitment checked against the CPU oracle."""
+    from accumulation_amd import Context, ffi
+    from accumulation_amd.scalar_field import Fr
+    from accumulation_amd.trivial_pc_as import ASForTrivialPC as AS, TrivialPC
+    d = (1 << 10) - 1
+    ctx = Context(ffi.AMSM_PALLAS)
+    c = o.PALLAS
+    fr = Fr(ctx.curve)
+    pp = TrivialPC.setup(ctx, d)
+    ck, _ = TrivialPC.trim(pp, d)
+    pk, vk, dk = AS.index(pp, d)
+    rng = SchemeRng(4242)
+    ins = generate_inputs((ctx, pp), ck, 3, rng)
+    xy, _ = ck.read()
+    for x in ins:  # the input commitments are the MSMs the CPU oracle computes
+        ref, rinf = cref.msm(c.curve_id, xy[: d + 1], h.scalars_to_np([v % c.r for v in x.witness.coeffs]), threads=2)
+        assert bool(x.instance.commitment.elem[1]) == rinf and np.array_equal(np.asarray(x.instance.commitment.elem[0]), ref)
+    acc_a, pa = AS.prove(pk, [ins[0]], [], None, None)
+    acc_b, pb = AS.prove(pk, [ins[1]], [], None, None)
+    acc, proof = AS.prove(pk, [ins[2]], [acc_a, acc_b], None, None)   # 1 input + 2 old accumulators
+    assert AS.verify(ctx, vk, [ins[2].instance], [acc_a.instance, acc_b.instance], acc.instance, proof, None)
+    assert AS.decide(dk, acc, None)
+    ref, rinf = cref.msm(c.curve_id, xy[: d + 1], h.scalars_to_np([v % c.r for v in acc.witness.coeffs]), threads=2)
+    assert bool(acc.instance.commitment.elem[1]) == rinf and np.array_equal(np.asarray(acc.instance.commitment.elem[0]), ref)
+    ctx.close()

@@ -174,6 +174,40 @@ def bench_vec(log2n):
     ctx.close()
 
 
+def bench_trivial_pc_as(log2d, reps=5):
+    """cfg0 (examples/scaling-as.rs:62-63,91-104): trivial_pc_as at degree 2^log2d - 1, one input accumulated into two old
+    accumulators: 3 MSMs of <= 2^log2d points in prove (witness polynomials), one in decide.  The reference runs it on the
+    CPU; here it goes through the same GPU path (no CPU fallback exists) -- far too small to fill the device."""
+    from accumulation_amd.trivial_pc_as import ASForTrivialPC as TAS, Input as TInput, InputInstance as TInst, LabeledPolynomial, TrivialPC
+    ctx = Context(ffi.AMSM_PALLAS)
+    fr = Fr(ctx.curve)
+    d = (1 << log2d) - 1
+    pp = TrivialPC.setup(ctx, d)
+    ck, _ = TrivialPC.trim(pp, d)
+    pk, vk, dk = TAS.index(pp, d)
+    rng = _Rng(5)
+
+    def make_input():
+        poly = LabeledPolynomial([rng.field() % fr.r for _ in range(d + 1)])
+        point = rng.field() % fr.r
+        return TInput(TInst(TrivialPC.commit(ck, poly), point, poly.evaluate(fr, point)), poly)
+
+    a0, _ = TAS.prove(pk, [make_input()], [], None, None)
+    a1, _ = TAS.prove(pk, [make_input()], [], None, None)
+    inp = make_input()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        acc, proof = TAS.prove(pk, [inp], [a0, a1], None, None)
+    dt = (time.perf_counter() - t0) / reps
+    ok = TAS.verify(ctx, vk, [inp.instance], [a0.instance, a1.instance], acc.instance, proof, None)
+    t0 = time.perf_counter()
+    dec = TAS.decide(dk, acc, None)
+    t_dec = time.perf_counter() - t0
+    emit(kind="trivial_pc_as", log2_degree_plus_1=log2d, accumulations_per_s=1 / dt, prove_ms=dt * 1e3, decide_ms=t_dec * 1e3,
+         verify_ok=bool(ok), decide_ok=bool(dec))
+    ctx.close()
+
+
 class _Rng:
     """MakeZK::Enabled(rng) stand-in: .field() -> scalar < 2^254."""
 
@@ -247,5 +281,6 @@ if __name__ == "__main__":
     bench_hp_as(18 if quick else 22, zk=True)
     bench_degenerate(16 if quick else 20)
     bench_r1cs_nark_as(12 if quick else 18)
+    bench_trivial_pc_as(10)
     bench_ipa(10 if quick else 16)
     bench_ipa(10 if quick else 20, curve=ffi.AMSM_BLS12_381_G1)
