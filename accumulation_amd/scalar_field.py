@@ -25,7 +25,13 @@ class Fr:
         return np.array([(m >> (64 * i)) & _M64 for i in range(4)], dtype=np.uint64)
 
     def to_limbs_many(self, xs) -> np.ndarray:
-        return np.stack([self.to_limbs(x) for x in xs]) if len(xs) else np.zeros((0, 4), dtype=np.uint64)
+        """canonical ints -> (n, 4) uint64 Montgomery limbs (one bytes join instead of n small arrays: the O(d) host
+        loops of trivial_pc_as and the NARK's assignment uploads convert thousands of scalars per call)"""
+        if not len(xs):
+            return np.zeros((0, 4), dtype=np.uint64)
+        r = self.r
+        buf = b"".join(((int(x) % r) * _R % r).to_bytes(32, "little") for x in xs)
+        return np.frombuffer(buf, dtype="<u8").reshape(-1, 4).copy()
 
     def from_limbs(self, limbs) -> int:
         m = 0
