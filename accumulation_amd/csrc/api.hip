@@ -847,6 +847,48 @@ int msm_grouped_impl(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, co
   return AMSM_OK;
 }
 
+// One IPA opening round with ONE synchronisation: the round's scalar expansion, the grouped MSM over the key and the two
+// inner products <c_r, z_l>, <c_l, z_r>; the inner-product kernels are queued behind accumulate L0 on the context's
+// stream and run beside the MSM's tail.
+template <class Fq, class Fr>
+int ipa_round_impl(amsm_ctx* ctx, const amsm_bases* key, const uint64_t* xi_mont, size_t j, size_t log_key, const void* d_coeffs,
+                   const void* d_z, size_t half, void* d_u, uint64_t* out_lr_xy, uint8_t* out_lr_inf, uint64_t* out_ip_mont) {
+  const size_t n = (size_t)1 << log_key;
+  if (n > key->n) return AMSM_E_INVALID_ARG;
+  launch_ipa_round_scalars<Fr>(ctx->stream, (const u32*)xi_mont, (u32)j, (u32)log_key, (const u32*)d_coeffs, (u32*)d_u, nullptr);
+  HIP_TRY(hipGetLastError());
+  const u32 blocks = std::min<u32>(1024u, cdiv((u32)half, 256));
+  TRY(ensure(ctx->scalars, (size_t)2 * blocks * 32 + 4096));
+  Slot* aux = &ctx->slot[1];  // only its pinned buffer: slot 1 carries no MSM during a single-MSM call
+  TRY(ensure_pinned(aux, (size_t)2 * blocks * 32));
+  std::vector<host::HXYZZ<Fq>> r(2, host::hx_inf<Fq>());
+  stage_begin(ctx);
+  TRY(prep_fork(ctx));
+  TRY((msm_enqueue<Fq, Fr>(ctx, &ctx->slot[0], key, 0, d_u, n, 1, (int)(log_key - 1 - j))));
+  const u32* co = (const u32*)d_coeffs;
+  const u32* z = (const u32*)d_z;
+  u32* part = (u32*)ctx->scalars.p;
+  launch_vec_inner_product<Fr>(ctx->stream, co + half * 8, z, (u32)half, blocks, part);               // <c_r, z_l>
+  launch_vec_inner_product<Fr>(ctx->stream, co, z + half * 8, (u32)half, blocks, part + blocks * 8);  // <c_l, z_r>
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(aux->h_pinned, part, (size_t)2 * blocks * 32, hipMemcpyDeviceToHost, ctx->stream));
+  int rc = msm_collect<Fq>(ctx, &ctx->slot[0], r.data());
+  stage_end(ctx);
+  if (rc != AMSM_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  write_affine_batch<Fq>(r, out_lr_xy, out_lr_inf);
+  const u64* h = (const u64*)aux->h_pinned;
+  for (int k = 0; k < 2; k++) {
+    host::HFe<Fr> acc = host::h_zero<Fr>(), t;
+    for (u32 i = 0; i < blocks; i++) {
+      memcpy(t.v, h + 4 * ((size_t)k * blocks + i), 32);
+      acc = host::h_add<Fr>(acc, t);
+    }
+    memcpy(out_ip_mont + 4 * k, acc.v, 32);
+  }
+  return AMSM_OK;
+}
+
 // groups of `count` consecutive records -> one affine point per group (one D2H copy, one batched normalisation)
 template <class Fq>
 int partials_combine_batch_impl(amsm_ctx* ctx, const void* d_partials, size_t n_groups, size_t count, uint64_t* out_xy,
@@ -1646,6 +1688,19 @@ int amsm_ipa_round_scalars(amsm_ctx* c, const uint64_t* xi_mont, size_t j, size_
                                          (u32*)d_out_l, (u32*)d_out_r);
   HIP_TRY(hipGetLastError());
   return AMSM_OK;
+}
+
+int amsm_ipa_round(amsm_ctx* c, const amsm_bases* key, const uint64_t* xi_mont, size_t j, size_t log_key, const void* d_coeffs,
+                   const void* d_z, void* d_u, uint64_t* out_lr_xy, uint8_t* out_lr_inf, uint64_t* out_ip_mont) {
+  if (!c || !key || !d_coeffs || !d_z || !d_u || !out_lr_xy || !out_ip_mont || (j && !xi_mont) || log_key == 0 || log_key > 30 ||
+      j >= log_key || key->curve != c->curve || key->device != c->device)
+    return AMSM_E_INVALID_ARG;
+  TRY(bind_device(c));
+  const size_t half = (size_t)1 << (log_key - j - 1);
+  return DISPATCH(c, (ipa_round_impl<PallasFq, PallasFr>(c, key, xi_mont, j, log_key, d_coeffs, d_z, half, d_u, out_lr_xy, out_lr_inf,
+                                                          out_ip_mont)),
+                  (ipa_round_impl<Bls12381Fq, Bls12381Fr>(c, key, xi_mont, j, log_key, d_coeffs, d_z, half, d_u, out_lr_xy,
+                                                          out_lr_inf, out_ip_mont)));
 }
 
 int amsm_matrix_load(amsm_ctx* c, const uint32_t* row_ptr, const uint32_t* col_idx, const uint64_t* vals, size_t n_rows,

@@ -226,12 +226,14 @@ class InnerProductArgPC:
             z_l, z_r = z.view(0, half), z.view(half, half)
             j = len(xs) - (log_n - log_key)  # challenges since cur_key was formed
             xi = fr.to_limbs_many(xs[len(xs) - j:]) if j else None
-            u = u_l.view(0, 1 << log_key)
-            ffi.check(ctx._lib.amsm_ipa_round_scalars(ctx._h, _ptr(xi), j, log_key, coeffs.ptr, u.ptr, None),
-                      "amsm_ipa_round_scalars")
-            xy, inf = VariableBaseMSM.multi_scalar_mul_grouped(cur_key, u, log_key - 1 - j, mont=True)
-            l_pt = _lincomb(ctx, [(xy[0], bool(inf[0])), h_prime], [1, cls._inner_product(ctx, fr, c_r, z_l)], fr)
-            r_pt = _lincomb(ctx, [(xy[1], bool(inf[1])), h_prime], [1, cls._inner_product(ctx, fr, c_l, z_r)], fr)
+            # one library call per round: scalar expansion, grouped MSM and both inner products, one synchronisation
+            xy = np.zeros((2, 2 * ctx.fq_limbs), dtype=np.uint64)
+            inf = np.zeros((2,), dtype=np.uint8)
+            ips = np.zeros((2, 4), dtype=np.uint64)
+            ffi.check(ctx._lib.amsm_ipa_round(ctx._h, cur_key._h, _ptr(xi), j, log_key, coeffs.ptr, z.ptr, u_l.ptr, _ptr(xy),
+                                              _ptr(inf), _ptr(ips)), "amsm_ipa_round")
+            l_pt = _lincomb(ctx, [(xy[0], bool(inf[0])), h_prime], [1, fr.from_limbs(ips[0])], fr)   # + <c_r, z_l> h'
+            r_pt = _lincomb(ctx, [(xy[1], bool(inf[1])), h_prime], [1, fr.from_limbs(ips[1])], fr)   # + <c_l, z_r> h'
             l_vec.append(l_pt)
             r_vec.append(r_pt)
             round_challenge = cls._challenge(fr, [round_challenge.to_bytes(16, "little"), l_pt, r_pt])

@@ -244,6 +244,14 @@ int amsm_vec_powers(amsm_ctx* ctx, const uint64_t* point_mont, size_t n, void* d
  * one pass. */
 int amsm_ipa_round_scalars(amsm_ctx* ctx, const uint64_t* xi_mont, size_t j, size_t log_n, const void* d_coeffs,
                            void* d_out_l, void* d_out_r);
+/* One whole opening round with one synchronisation (ext, under src/ipa_pc_as/mod.rs:454): the scalars of round j over
+ * `key` (2^log_key generators; amsm_ipa_round_scalars with d_out_r = NULL into the scratch d_u, 2^log_key scalars), the
+ * grouped MSM (L_j, R_j without their h' terms -> out_lr_xy[2][2L], out_lr_inf[2]) and the two inner products
+ * out_ip_mont[0] = <c_r, z_l>, out_ip_mont[1] = <c_l, z_r> of the current coefficient / evaluation vectors (length
+ * 2^(log_key - j) each), which run beside the MSM's tail.  xi_mont: the j challenges since `key` was formed. */
+int amsm_ipa_round(amsm_ctx* ctx, const amsm_bases* key, const uint64_t* xi_mont, size_t j, size_t log_key,
+                   const void* d_coeffs, const void* d_z, void* d_u, uint64_t* out_lr_xy, uint8_t* out_lr_inf,
+                   uint64_t* out_ip_mont);
 /* d_out[p] (p < 2^k) = coefficients of prod_{i=1..k} (1 + xi_i X^(2^(k-i))):
  * `SuccinctCheckPolynomial::compute_coeffs` (ext), call sites src/ipa_pc_as/mod.rs:400 and under :836. k <= 32. */
 int amsm_ipa_check_poly_coeffs(amsm_ctx* ctx, const uint64_t* xi_mont, size_t k, void* d_out);

@@ -252,12 +252,20 @@ struct InnerProductArgPC {
     size_t cur = n;
     while (cur > 1) {
       size_t half = cur / 2, j = xs.size() - (log_n - log_key);  // challenges since cur_key was formed
-      amsm::check(amsm_ipa_round_scalars(ctx.get(), j ? reinterpret_cast<const uint64_t*>(xs.data() + (xs.size() - j)) : nullptr, j,
-                                         log_key, coeffs.ptr(), u.ptr(), nullptr),
-                  "amsm_ipa_round_scalars");
-      auto lr = MsmBatch::grouped(*cur_key, u, (size_t)1 << log_key, (unsigned)(log_key - 1 - j));
-      Fr ip_l = inner_product(ctx, at(coeffs, half), at(z, 0), half);  // <c_r, z_l>
-      Fr ip_r = inner_product(ctx, at(coeffs, 0), at(z, half), half);  // <c_l, z_r>
+      // one library call per round: scalar expansion, grouped MSM and both inner products, one synchronisation
+      const size_t w = 2 * (size_t)ctx.fq_limbs();
+      std::vector<uint64_t> lr_xy(2 * w);
+      uint8_t lr_inf[2] = {0, 0};
+      Fr ips[2];
+      amsm::check(amsm_ipa_round(ctx.get(), cur_key->get(), j ? reinterpret_cast<const uint64_t*>(xs.data() + (xs.size() - j)) : nullptr, j,
+                                 log_key, coeffs.ptr(), z.ptr(), u.ptr(), lr_xy.data(), lr_inf, reinterpret_cast<uint64_t*>(ips)),
+                  "amsm_ipa_round");
+      Affine lr[2];
+      for (int g = 0; g < 2; g++) {
+        lr[g].xy.assign(lr_xy.begin() + (long)(g * w), lr_xy.begin() + (long)((g + 1) * w));
+        lr[g].infinity = lr_inf[g] != 0;
+      }
+      const Fr &ip_l = ips[0], &ip_r = ips[1];  // <c_r, z_l>, <c_l, z_r>
       Affine l_pt = host_lincomb(ctx, {&lr[0], &h_prime}, {one, ip_l});
       Affine r_pt = host_lincomb(ctx, {&lr[1], &h_prime}, {one, ip_r});
       proof.l_vec.push_back(l_pt);

@@ -284,3 +284,39 @@ def test_sponge_argument_is_refused(env):
     pk, vk, dk = AS.index(pp, DEGREE)
     with pytest.raises(NotImplementedError):  # src/ipa_pc_as/mod.rs:566-570
         AS.prove(pk, [], [], None, Sha256Sponge())
+
+
+def test_ipa_round_entry_point_equals_its_parts(env):
+    """amsm_ipa_round (scalar expansion + grouped MSM + both inner products, one synchronisation) against the separate
+    entry points it fuses, which are themselves pinned to the oracle above: rounds 0, 1 and 3 of a 64-point key."""
+    from accumulation_amd import CommitterKey, VariableBaseMSM, ffi
+    from accumulation_amd.engine import _ptr
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
+    from accumulation_amd.scalar_field import Fr
+    ctx, _ = env
+    c = o.PALLAS
+    fr = Fr(ctx.curve)
+    log_key = 6
+    key = CommitterKey.load(ctx, h.points_to_np(c, o.rng_points(c, 0x1F, 64))[0], None, ffi.AMSM_BASES_DEFAULT)
+    xs_all = [o.rng_scalar(0x2F, i) % (1 << 128) for i in range(3)]
+    for j in (0, 1, 3):
+        m = 1 << (log_key - j)  # current length of the coefficient / evaluation vectors
+        half = m // 2
+        coeffs = ctx.upload(h.fr_mont_np(c, [o.rng_scalar(0x3F + j, i) % c.r for i in range(m)]))
+        z = ctx.upload(h.fr_mont_np(c, [o.rng_scalar(0x4F + j, i) % c.r for i in range(m)]))
+        xi = fr.to_limbs_many(xs_all[:j]) if j else None
+        u = ctx.vector(64)
+        xy = np.zeros((2, 2 * ctx.fq_limbs), dtype=np.uint64)
+        inf = np.zeros((2,), dtype=np.uint8)
+        ips = np.zeros((2, 4), dtype=np.uint64)
+        ffi.check(ctx._lib.amsm_ipa_round(ctx._h, key._h, _ptr(xi), j, log_key, coeffs.ptr, z.ptr, u.ptr, _ptr(xy), _ptr(inf),
+                                          _ptr(ips)), "amsm_ipa_round")
+        u2 = ctx.vector(64)
+        ffi.check(ctx._lib.amsm_ipa_round_scalars(ctx._h, _ptr(xi), j, log_key, coeffs.ptr, u2.ptr, None), "round_scalars")
+        exy, einf = VariableBaseMSM.multi_scalar_mul_grouped(key, u2, log_key - 1 - j, mont=True)
+        assert np.array_equal(xy, exy) and np.array_equal(inf, einf), j
+        assert fr.from_limbs(ips[0]) == IpaPC._inner_product(ctx, fr, coeffs.view(half, half), z.view(0, half)), j
+        assert fr.from_limbs(ips[1]) == IpaPC._inner_product(ctx, fr, coeffs.view(0, half), z.view(half, half)), j
+    assert ctx._lib.amsm_ipa_round(ctx._h, key._h, None, 0, 7, coeffs.ptr, z.ptr, u.ptr, _ptr(xy), _ptr(inf), _ptr(ips)) == \
+        ffi.AMSM_E_INVALID_ARG  # 2^7 generators asked of a 64-point key
+    key.free()
