@@ -1,0 +1,50 @@
+"""bench.py's contract on a GPU box: the default N = 1 line carries every field the driver reads (plus `roofline`,
+`cpu_baseline` and `accumulations`), and the N > 1 branch -- launched exactly like the driver launches it, but with both
+ranks on the one GPU of the test box and gloo instead of RCCL -- runs through its barrier / max-over-ranks timing / sharded
+MSM path and prints one line with n_gpus = 2."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"]
+
+
+def _line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_line_n1(built_lib):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3"], capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in KEYS + ["cpu_baseline", "accumulations"]:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["metric"].startswith("MSM throughput") and d["unit"] == "pairs/s" and d["value"] > 1e8
+    assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(d["roofline"])
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_result_bit_exact_vs_cpu"] is True
+    assert all(v.get("verified") for v in d["accumulations"].values()), d["accumulations"]
+    assert "workload" in d["config"]
+
+
+def test_two_rank_branch_on_one_gpu(built_lib):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+                        "--warmup", "2", "--backend", "gloo", "--one-gpu"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 1e7
+    assert "point-sharded x2" in d["config"]["parallelism"]
