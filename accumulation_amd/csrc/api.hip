@@ -9,7 +9,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <dlfcn.h>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <rocprim/rocprim.hpp>
 #include <vector>
 
@@ -48,6 +54,55 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   bool busy = false;
 };
 
+struct ShardWorker {  // one persistent host thread per non-primary shard
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, stop = false, idle = true;
+  ShardWorker() {
+    th = std::thread([this] {
+      for (;;) {
+        std::function<void()> j;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return has_job || stop; });
+          if (stop) return;
+          j = std::move(job);
+          has_job = false;
+        }
+        j();
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          idle = true;
+        }
+        cv.notify_all();
+      }
+    });
+  }
+  void submit(std::function<void()> j) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = std::move(j);
+      has_job = true;
+      idle = false;
+    }
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return idle; });
+  }
+  ~ShardWorker() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+
 struct amsm_ctx {
   int curve = 0;
   int device = 0;
@@ -61,6 +116,10 @@ struct amsm_ctx {
   bool custom_prep = true;  // AMSM_PREP=rocprim: digits + rocPRIM radix sort + bounds + rocPRIM scan instead (A/B, fallback)
   int window_override = 0;
   int K0 = 0;          // 0 = automatic (see make_geom)
+  int cu_count = 256;
+  u32 l0_lds_pad = 0;  // AMSM_L0_LDS_PAD: dynamic LDS bytes per accumulate-L0 workgroup that only cap its residency
+  int K0_max = 24;     // automatic choice: largest chunk (AMSM_K0_MAX)
+  bool two_phase = true;  // automatic choice: two chunk sizes so that the grid is a whole number of rounds (AMSM_K0_2PHASE=0: A/B)
   int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x resident 256-lane blocks per CU x 4
   int K1 = 1024;  // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew only)
   int red_s = 4;
@@ -73,6 +132,16 @@ struct amsm_ctx {
   hipEvent_t fork = nullptr;
   DevBuf scalars;
   DevBuf xyzz_scratch;  // unconverted sums of large key folds / precompute levels (launch.h: batch_affine_pays)
+  // ---- multi-device (amsm_ctx_create_multi) ----
+  // shard_ctx[0] == this (the primary); shard_ctx[g >= 1] are owned single-device contexts, each served by one host
+  // worker thread so that the blocking single-device pipeline runs on all devices at once.
+  std::vector<amsm_ctx*> shard_ctx;
+  std::vector<ShardWorker*> workers;  // workers[g - 1] drives shard_ctx[g]
+  amsm_ctx* parent = nullptr;
+  int collective = 0;            // 0 none, 1 RCCL all-gather, 2 peer copies
+  void** rccl_comms = nullptr;   // ncclComm_t per shard
+  DevBuf rec_send, rec_recv, stage;  // per device: this shard's partial records / the gathered ones / scalar slices
+  hipEvent_t multi_fork = nullptr;
 };
 
 struct amsm_bases {
@@ -83,7 +152,18 @@ struct amsm_bases {
   int c = 0;  // window bits fixed at creation when precomputed
   int W = 0;
   u32* d_table = nullptr;          // device-internal Montgomery radix (launch.h: device_internal_radix)
-  mutable u32* d_abi = nullptr;    // C-ABI-radix copy of generators [0, n), made on the first amsm_bases_device_ptr
+  // C-ABI-radix copy of generators [0, n), made on the first amsm_bases_device_ptr (under abi_mu: the handle is
+  // shareable between threads)
+  mutable u32* d_abi = nullptr;
+  mutable std::mutex abi_mu;
+  // recorded by amsm_bases_fold behind the kernel that writes d_table (it returns without synchronising): consumers that
+  // are not ordered behind the folding context's stream (amsm_bases_device_ptr) wait for it
+  hipEvent_t ready = nullptr;
+  // sharded key of a multi-device context: shard g (a single-device key on shard_ctx[g]'s device) holds generators
+  // [bound[g], bound[g + 1]); n is the total, d_table stays null
+  std::vector<amsm_bases*> shards;
+  std::vector<size_t> bound;
+  const amsm_ctx* owner = nullptr;
 };
 
 struct amsm_matrix {
@@ -241,17 +321,48 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   // chunk length of accumulate L0: the grid should be a whole number of rounds of the resident wave
   // slots (queried from the kernel's occupancy), so that no SIMD idles while a partial last round drains
   if (ctx->K0 > 0) {
-    g.K0 = (u32)ctx->K0;
+    g.K0 = ((u32)ctx->K0 + 3u) & ~3u;  // accumulate L0 reads entries in groups of 4
+    g.K0b = g.K0;
+    g.nA = 0xffffff00u;
   } else {
-    // <= 24 entries per lane per round of resident waves, rounds equalised: measured best on MI355X for batches of
-    // MSMs (tools/ab_pipeline.py, 2^20 Pallas: K0 = 24 -> 761-769, 32 -> 749, 20 -> 750, 44 -> 727, 64 -> 715
-    // Mpairs/s): shorter chunks let the other MSMs' prep / tail kernels in sooner, longer ones save partials
-    unsigned long long lanes = (unsigned long long)ctx->wave_slots * 64ull;
-    unsigned long long rounds = (g.E + lanes * 24ull - 1) / (lanes * 24ull);
-    unsigned long long k = (g.E + lanes * rounds - 1) / (lanes * rounds);
-    g.K0 = (u32)std::min<unsigned long long>(std::max<unsigned long long>(k, 12ull), 24ull);  // 2^16: 12 -> 0.57 ms per blocking call, 16 -> 0.59
+    // <= K0_max entries per lane per round of resident waves (24 measured best on MI355X for batches of MSMs,
+    // tools/ab_pipeline.py: shorter chunks let the other MSMs' prep / tail kernels in sooner, longer ones save partials),
+    // and the grid a WHOLE number of rounds: every resident lane gets `rounds` chunks whose sizes (multiples of 4: the
+    // entries are read 16 bytes at a time) add up to its share of the list -- ra rounds of kb + 4 entries, then
+    // rounds - ra of kb.  One size for all rounds left the last round of a 2^20-pair launch 56 % full.
+    const unsigned long long lanes = (unsigned long long)ctx->wave_slots * 64ull;
+    const unsigned long long kmax = (unsigned long long)std::max(4, ctx->K0_max);
+    const unsigned long long share = (g.E + lanes - 1) / lanes;  // entries per resident lane
+    const unsigned long long rounds = std::max<unsigned long long>(1, (share + kmax - 1) / kmax);
+    unsigned long long kb = (share / rounds) & ~3ull;
+    if (!ctx->two_phase || kb < 12ull) {  // small problems: one size, at least 12 (2^16: 12 -> 0.57 ms per blocking call, 16 -> 0.59)
+      unsigned long long k = (share + rounds - 1) / rounds;
+      g.K0 = ((u32)std::min<unsigned long long>(std::max<unsigned long long>(k, 12ull), kmax) + 3u) & ~3u;
+      g.K0b = g.K0;
+      g.nA = 0xffffff00u;
+    } else {
+      const unsigned long long ra = (share - rounds * kb + 3ull) / 4ull;  // rounds that take 4 more entries (<= rounds)
+      g.K0 = (u32)(kb + 4ull);
+      g.K0b = (u32)kb;
+      g.nA = (u32)(ra * lanes);  // lanes = 64 * wave_slots, wave_slots a multiple of 4: a multiple of 256
+      if (ra >= rounds) {
+        g.K0b = g.K0;
+        g.nA = 0xffffff00u;
+      }
+    }
   }
-  g.K0 = (g.K0 + 3u) & ~3u;  // accumulate L0 reads entries in groups of 4
+  {
+    unsigned long long t0 = (unsigned long long)g.nA * g.K0;
+    if (t0 >= g.E) {  // phase A covers everything
+      g.nA = (g.E + g.K0 - 1) / g.K0;
+      g.nA = (g.nA + 255u) & ~255u;
+      g.T0 = g.nA * g.K0;  // < E + 256 * K0: fits
+      g.n_chunks = (g.E + g.K0 - 1) / g.K0;
+    } else {
+      g.T0 = (u32)t0;
+      g.n_chunks = g.nA + (g.E - g.T0 + g.K0b - 1) / g.K0b;
+    }
+  }
   g.K1 = (u32)ctx->K1;
   g.red_s = std::min<u32>((u32)ctx->red_s, g.nb);
   g.red_threads = g.nb / g.red_s;
@@ -265,9 +376,15 @@ void stage_mark(amsm_ctx* ctx, Slot* sl, int idx, hipStream_t st) {
 
 // lanes cooperating on one bucket in accumulate L1 (tree over partials): more lanes = lower latency,
 // but only worth it when buckets have several partials each
-u32 l1_lanes(const MsmGeom& g) {
-  double avg = ((double)g.E / g.K0) / g.B;
-  return avg >= 24.0 ? 16u : (avg >= 3.0 ? 4u : 1u);
+// `hidden`: the tail runs behind the next MSM's accumulation (inside a batch): what counts is its ALU work, not its
+// depth -- one lane per bucket does no butterfly additions at all when there are buckets enough to fill the lanes.
+// Measured (round 2, 2^20 Pallas, stand-alone kernel): 16 lanes per bucket 0.23 ms, 4 lanes 0.107 ms for ~21-26 partials per
+// bucket -- the wide tree only pays when there are too few buckets to occupy the chip with 4 lanes each.
+u32 l1_lanes(const MsmGeom& g, bool hidden) {
+  double avg = (double)g.n_chunks / g.B;
+  if (hidden && g.B >= 16384u) return avg >= 48.0 ? 4u : 1u;
+  if (avg >= 24.0 && g.B * 16ull <= 65536ull) return 16u;
+  return avg >= 3.0 ? 4u : 1u;
 }
 
 // AMSM_DEBUG=1: synchronise after every stage of the pipeline and report it on stderr (finds the faulting kernel)
@@ -304,7 +421,7 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   sl->geom = g;
   hipStream_t st = ctx->s_prep;  // digits / sort / bounds
   hipStream_t sm = ctx->stream;  // accumulate L0
-  const u32 max_items = g.E / g.K0 + g.B + 1;
+  const u32 max_items = g.n_chunks + g.B + 1;
   const u32 red_blocks = cdiv(g.red_threads * (quad ? 4u : 1u), 256);
   TRY(ensure(sl->vals_a, (size_t)g.E * 4 + 64));
   TRY(ensure(sl->vals_b, (size_t)g.E * 4 + 64));  // read in groups of 4 entries
@@ -388,13 +505,13 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   HIP_TRY(hipStreamWaitEvent(sm, sl->prep_done, 0));
   stage_mark(ctx, sl, ST_ACCUM_L0, sm);
   launch_accum_l0<Fq>(sm, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)sl->start.p,
-                      (const u32*)sl->item_off.p, g, (u32*)sl->partials.p);
+                      (const u32*)sl->item_off.p, g, (u32*)sl->partials.p, ctx->l0_lds_pad);
   AMSM_DBG("l0");
   HIP_TRY(hipEventRecord(sl->l0_done, sm));
   hipStream_t tl = ctx->s_tail;
   HIP_TRY(hipStreamWaitEvent(tl, sl->l0_done, 0));
   if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_ACCUM_L12], tl);
-  launch_accum_l1<Fq>(tl, l1_lanes(g), (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
+  launch_accum_l1<Fq>(tl, l1_lanes(g, !exposed_tail), (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
                       g, (u32*)sl->buckets.p, d_heavy_count, (u32*)sl->heavy.p);
   AMSM_DBG("l1");
   launch_accum_l2<Fq>(tl, (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
@@ -649,7 +766,7 @@ int bases_load_impl(amsm_ctx* ctx, const uint64_t* xy, const uint8_t* is_inf, si
 }
 
 template <class Fq, class Fr>
-int bases_generate_impl(amsm_ctx* ctx, uint64_t seed, size_t n, unsigned flags, amsm_bases** out) {
+int bases_generate_impl(amsm_ctx* ctx, uint64_t seed, size_t n, unsigned flags, amsm_bases** out, size_t first = 0) {
   amsm_bases* b = new (std::nothrow) amsm_bases();
   if (!b) return AMSM_E_OOM;
   b->curve = ctx->curve;
@@ -663,7 +780,7 @@ int bases_generate_impl(amsm_ctx* ctx, uint64_t seed, size_t n, unsigned flags, 
   int s = AMSM_OK;
   if (n) {
     std::vector<u32> gen = generator_mont<Fq>(ctx->curve);
-    launch_generate_bases<Fq>(ctx->stream, b->d_table, seed, (u32)n, gen.data());
+    launch_generate_bases<Fq>(ctx->stream, b->d_table, seed, (u32)first, (u32)n, gen.data());
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) s = AMSM_E_HIP;
     if (s == AMSM_OK) s = bases_finish<Fq, Fr>(ctx, b, flags);
   }
@@ -1025,6 +1142,212 @@ int t_vecs_impl(amsm_ctx* ctx, const void* const* d_a, const size_t* a_lens, con
   return AMSM_OK;
 }
 
+// =============================================================================================
+// Multi-device contexts: ONE process drives the GPUs of a node.  The key is sharded over the devices by contiguous ranges
+// (the split of accumulation_amd/dist.py: shard_bounds); every device runs the ordinary single-device pipeline on its
+// shard, driven by its own host thread; the per-device partial sums (one folded XYZZ record per MSM) are gathered on the
+// primary device with one RCCL all-gather (raw bytes: EC addition is not an RCCL reduce op) or peer copies, folded and
+// normalised once.
+// =============================================================================================
+// RCCL is bound at run time (dlopen): libamsm.so carries no link-time dependency on it, a process that already loaded a
+// copy (PyTorch ships its own) keeps using that one, and a box without RCCL still gets the peer-copy exchange.
+struct RcclApi {
+  typedef int (*comm_init_all_t)(void** comms, int ndev, const int* devlist);
+  typedef int (*comm_destroy_t)(void* comm);
+  typedef int (*all_gather_t)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t st);
+  typedef int (*group_t)();
+  typedef const char* (*err_t)(int);
+  comm_init_all_t comm_init_all = nullptr;
+  comm_destroy_t comm_destroy = nullptr;
+  all_gather_t all_gather = nullptr;
+  group_t group_start = nullptr, group_end = nullptr;
+  err_t error_string = nullptr;
+  bool ok = false;
+  static const RcclApi& get() {
+    static RcclApi api = [] {
+      RcclApi a;
+      void* h = nullptr;
+      const char* names[] = {"librccl.so", "librccl.so.1"};
+      for (const char* n : names)  // a copy that is already in the process first
+        if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+      for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (!h) return a;
+      a.comm_init_all = (comm_init_all_t)dlsym(h, "ncclCommInitAll");
+      a.comm_destroy = (comm_destroy_t)dlsym(h, "ncclCommDestroy");
+      a.all_gather = (all_gather_t)dlsym(h, "ncclAllGather");
+      a.group_start = (group_t)dlsym(h, "ncclGroupStart");
+      a.group_end = (group_t)dlsym(h, "ncclGroupEnd");
+      a.error_string = (err_t)dlsym(h, "ncclGetErrorString");
+      a.ok = a.comm_init_all && a.comm_destroy && a.all_gather && a.group_start && a.group_end;
+      return a;
+    }();
+    return api;
+  }
+};
+constexpr int kNcclUint8 = 1;  // rccl.h: ncclUint8
+
+inline size_t n_shards(const amsm_ctx* c) { return c->shard_ctx.empty() ? 1 : c->shard_ctx.size(); }
+inline bool key_sharded(const amsm_bases* b) { return !b->shards.empty(); }
+
+// dist.shard_bounds: the first n % world shards get one extra element
+std::vector<size_t> shard_bounds(size_t n, size_t world) {
+  std::vector<size_t> b(world + 1);
+  size_t q = n / world, r = n % world;
+  for (size_t g = 0; g <= world; g++) b[g] = g * q + std::min(g, r);
+  return b;
+}
+
+// Run job(g) for every shard: shard 0 on the calling thread, the others on their workers.  Returns the first error.
+template <class F>
+int for_each_shard(amsm_ctx* c, F&& job) {
+  const size_t N = n_shards(c);
+  std::vector<int> rc(N, AMSM_OK);
+  for (size_t g = 1; g < N; g++) c->workers[g - 1]->submit([&, g] { rc[g] = job(g); });
+  rc[0] = job(0);
+  for (size_t g = 1; g < N; g++) c->workers[g - 1]->wait();
+  (void)hipSetDevice(c->device);
+  for (size_t g = 0; g < N; g++)
+    if (rc[g] != AMSM_OK) return rc[g];
+  return AMSM_OK;
+}
+
+enum SliceKind {
+  SLICE_HOST,     // srcs[v]: host scalars of vector v (whole vector)
+  SLICE_PRIMARY,  // srcs[v]: device pointer on the primary device (whole vector)
+  SLICE_SHARDED   // srcs[v * N + g]: shard g's slice of vector v, resident on device g
+};
+
+// n_vecs MSMs over generators [base_off, base_off + n) of a sharded key -> one XYZZ per vector on the host.
+template <class Fq, class Fr>
+int msm_sharded(amsm_ctx* c, const amsm_bases* key, size_t base_off, size_t n, size_t n_vecs, int mont, SliceKind kind,
+                const void* const* srcs, std::vector<host::HXYZZ<Fq>>* out) {
+  const size_t N = n_shards(c);
+  out->assign(n_vecs, host::hx_inf<Fq>());
+  if (base_off > key->n) return AMSM_E_INVALID_ARG;
+  const size_t n_eff = std::min(n, key->n - base_off);
+  if (n_vecs == 0 || n_eff == 0) return AMSM_OK;
+  const size_t rec = xyzz_bytes<Fq>(), per = n_vecs * rec;
+  if (kind == SLICE_PRIMARY) HIP_TRY(hipEventRecord(c->multi_fork, c->stream));  // the producers of the vectors
+  const bool rccl = c->collective == 1;
+  TRY(for_each_shard(c, [&](size_t g) -> int {
+    amsm_ctx* cg = c->shard_ctx[g];
+    HIP_TRY(hipSetDevice(cg->device));
+    const size_t lo = std::max(key->bound[g], base_off), hi = std::min(key->bound[g + 1], base_off + n_eff);
+    const size_t cnt = hi > lo ? hi - lo : 0;
+    TRY(ensure(cg->rec_send, per));
+    if (rccl) TRY(ensure(cg->rec_recv, N * per));
+    if (cnt == 0) {  // this shard holds none of the range: identity records (ZZ = 0)
+      HIP_TRY(hipMemsetAsync(cg->rec_send.p, 0, per, cg->stream));
+      HIP_TRY(hipStreamSynchronize(cg->stream));
+      return AMSM_OK;
+    }
+    std::vector<const void*> ptrs(n_vecs);
+    const size_t skip = (lo - base_off) * 32, bytes = cnt * 32;
+    if (kind == SLICE_SHARDED) {
+      for (size_t v = 0; v < n_vecs; v++) ptrs[v] = srcs[v * N + g];
+    } else if (kind == SLICE_PRIMARY && g == 0) {
+      for (size_t v = 0; v < n_vecs; v++) ptrs[v] = (const char*)srcs[v] + skip;
+    } else {
+      TRY(ensure(cg->stage, n_vecs * bytes));
+      if (kind == SLICE_PRIMARY) HIP_TRY(hipStreamWaitEvent(cg->stream, c->multi_fork, 0));
+      for (size_t v = 0; v < n_vecs; v++) {
+        char* dst = (char*)cg->stage.p + v * bytes;
+        const char* src = (const char*)srcs[v] + skip;
+        if (kind == SLICE_HOST)
+          HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cg->stream));
+        else
+          HIP_TRY(hipMemcpyPeerAsync(dst, cg->device, src, c->device, bytes, cg->stream));
+        ptrs[v] = dst;
+      }
+    }
+    return msm_partial_batch_impl<Fq, Fr>(cg, key->shards[g], lo - key->bound[g], ptrs.data(), n_vecs, cnt, mont,
+                                          cg->rec_send.p);
+  }));
+  // exchange: every shard's records -> the primary (rank-major: record (g, v) at (g * n_vecs + v) * rec)
+  TRY(ensure(c->rec_recv, N * per));
+  if (rccl) {
+    const RcclApi& api = RcclApi::get();
+    int e = api.group_start();
+    for (size_t g = 0; g < N && e == 0; g++) {
+      amsm_ctx* cg = c->shard_ctx[g];
+      HIP_TRY(hipSetDevice(cg->device));
+      e = api.all_gather(cg->rec_send.p, cg->rec_recv.p, per, kNcclUint8, c->rccl_comms[g], cg->stream);
+    }
+    int e2 = api.group_end();
+    (void)hipSetDevice(c->device);
+    if (e != 0 || e2 != 0) {
+      fprintf(stderr, "[amsm] RCCL all-gather failed: %s\n", api.error_string ? api.error_string(e ? e : e2) : "?");
+      return AMSM_E_RCCL;
+    }
+  } else {
+    for (size_t g = 0; g < N; g++) {
+      amsm_ctx* cg = c->shard_ctx[g];  // its records are complete: msm_partial_batch_impl synchronised cg's stream
+      HIP_TRY(hipMemcpyPeerAsync((char*)c->rec_recv.p + g * per, c->device, cg->rec_send.p, cg->device, per, c->stream));
+    }
+  }
+  Slot* sl = &c->slot[0];
+  TRY(ensure_pinned(sl, N * per + 64));
+  HIP_TRY(hipMemcpyAsync(sl->h_pinned, c->rec_recv.p, N * per, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const u32* h = (const u32*)sl->h_pinned;
+  for (size_t v = 0; v < n_vecs; v++)
+    for (size_t g = 0; g < N; g++)
+      (*out)[v] = host::hx_add<Fq>((*out)[v], host::hx_from_device<Fq>(h + (g * n_vecs + v) * (rec / 4)));
+  return AMSM_OK;
+}
+
+// A sharded key: make_shard(g, ctx_g, lo, cnt, &shard) builds shard g on its device.
+template <class F>
+int bases_create_sharded(amsm_ctx* c, size_t n, amsm_bases** out, F&& make_shard) {
+  const size_t N = n_shards(c);
+  amsm_bases* b = new (std::nothrow) amsm_bases();
+  if (!b) return AMSM_E_OOM;
+  b->curve = c->curve;
+  b->device = c->device;
+  b->n = n;
+  b->owner = c;
+  b->bound = shard_bounds(n, N);
+  b->shards.assign(N, nullptr);
+  int rc = for_each_shard(c, [&](size_t g) -> int {
+    amsm_ctx* cg = c->shard_ctx[g];
+    HIP_TRY(hipSetDevice(cg->device));
+    return make_shard(g, cg, b->bound[g], b->bound[g + 1] - b->bound[g], &b->shards[g]);
+  });
+  if (rc != AMSM_OK) {
+    for (amsm_bases* s : b->shards) amsm_bases_free(s);
+    delete b;
+    return rc;
+  }
+  b->precomp = 1;
+  for (amsm_bases* s : b->shards) b->precomp &= s->precomp;
+  *out = b;
+  return AMSM_OK;
+}
+
+// Does (ctx, key) form a valid pair?  A sharded key needs the multi-device context that made it.
+inline bool key_matches(const amsm_ctx* c, const amsm_bases* b) {
+  if (b->curve != c->curve) return false;
+  if (key_sharded(b)) return b->owner == c && b->shards.size() == n_shards(c);
+  return b->device == c->device;
+}
+
+// commit(ck, v, r) over a sharded key: the sharded MSM, then + r * hiding_generator on the host (a11)
+template <class Fq, class Fr>
+int pedersen_sharded_impl(amsm_ctx* c, const amsm_bases* ck, size_t n, SliceKind kind, const void* const* src,
+                                 const uint64_t* rand_mont, const uint64_t* hiding_xy, uint64_t* out_xy, uint8_t* out_inf) {
+  std::vector<host::HXYZZ<Fq>> r;
+  TRY((msm_sharded<Fq, Fr>(c, ck, 0, n, 1, 1, kind, src, &r)));
+  host::HXYZZ<Fq> acc = r[0];
+  if (rand_mont && hiding_xy) {
+    host::HFe<Fr> k;
+    memcpy(k.v, rand_mont, 32);
+    k = host::h_from_mont<Fr>(k);
+    acc = host::hx_add<Fq>(acc, host::hx_mul<Fq>(host::hx_from_affine<Fq>(hiding_xy, false), k.v));
+  }
+  write_affine<Fq>(acc, out_xy, out_inf);
+  return AMSM_OK;
+}
 #define DISPATCH(ctx, CALL_P, CALL_B)                   \
   ((ctx)->curve == AMSM_PALLAS ? (CALL_P) : (CALL_B))
 
@@ -1078,6 +1401,7 @@ const char* amsm_strerror(int s) {
     case AMSM_E_UNSUPPORTED: return "unsupported size or configuration";
     case AMSM_E_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
     case AMSM_E_SCALAR_RANGE: return "scalar out of range (not a canonical into_repr value)";
+    case AMSM_E_RCCL: return "RCCL collective failed";
     default: return "unknown error";
   }
 }
@@ -1133,12 +1457,18 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
-      int per_cu = curve == AMSM_PALLAS ? accum_l0_blocks_per_cu<PallasFq>() : accum_l0_blocks_per_cu<Bls12381Fq>();
+      c->cu_count = prop.multiProcessorCount;
+      if (const char* e = getenv("AMSM_L0_LDS_PAD")) c->l0_lds_pad = (u32)std::max(0, atoi(e));
+      int per_cu = curve == AMSM_PALLAS ? accum_l0_blocks_per_cu<PallasFq>(c->l0_lds_pad)
+                                        : accum_l0_blocks_per_cu<Bls12381Fq>(c->l0_lds_pad);
+      if (getenv("AMSM_DEBUG")) fprintf(stderr, "[amsm] accumulate L0: %d workgroups per CU\n", per_cu);
       c->wave_slots = prop.multiProcessorCount * std::max(1, per_cu) * 4;
     }
   }
   if (const char* e = getenv("AMSM_PREP")) c->custom_prep = strcmp(e, "rocprim") != 0;
   if (const char* e = getenv("AMSM_K0")) c->K0 = std::max(0, atoi(e));
+  if (const char* e = getenv("AMSM_K0_MAX")) c->K0_max = std::max(4, atoi(e));
+  if (const char* e = getenv("AMSM_K0_2PHASE")) c->two_phase = atoi(e) != 0;
   if (const char* e = getenv("AMSM_TAIL_QUAD")) c->tail_quad = atoi(e) != 0;
   if (const char* e = getenv("AMSM_K1")) c->K1 = std::max(1, atoi(e));
   if (const char* e = getenv("AMSM_RED_S")) c->red_s = std::max(1, atoi(e));
@@ -1149,6 +1479,21 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
 
 void amsm_ctx_destroy(amsm_ctx* c) {
   if (!c) return;
+  if (c->parent) return;  // a shard context is borrowed: it goes with its parent
+  for (ShardWorker* w : c->workers) delete w;  // joins the threads
+  c->workers.clear();
+  if (c->rccl_comms) {
+    const RcclApi& api = RcclApi::get();
+    for (size_t g = 0; g < c->shard_ctx.size(); g++)
+      if (c->rccl_comms[g] && api.comm_destroy) (void)api.comm_destroy(c->rccl_comms[g]);
+    delete[] c->rccl_comms;
+    c->rccl_comms = nullptr;
+  }
+  for (size_t g = 1; g < c->shard_ctx.size(); g++) {
+    c->shard_ctx[g]->parent = nullptr;
+    amsm_ctx_destroy(c->shard_ctx[g]);
+  }
+  c->shard_ctx.clear();
   (void)hipSetDevice(c->device);
   if (c->s_prep) (void)hipStreamSynchronize(c->s_prep);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1173,7 +1518,88 @@ void amsm_ctx_destroy(amsm_ctx* c) {
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   if (c->scalars.p) (void)hipFree(c->scalars.p);
   if (c->xyzz_scratch.p) (void)hipFree(c->xyzz_scratch.p);
+  for (DevBuf* b : {&c->rec_send, &c->rec_recv, &c->stage})
+    if (b->p) (void)hipFree(b->p);
+  if (c->multi_fork) (void)hipEventDestroy(c->multi_fork);
   delete c;
+}
+
+int amsm_ctx_create_multi(amsm_ctx** out, int curve, const int* device_ids, int n_dev) {
+  if (!out) return AMSM_E_INVALID_ARG;
+  *out = nullptr;
+  if (!device_ids || n_dev < 1 || n_dev > 64) return AMSM_E_INVALID_ARG;
+  amsm_ctx* c = nullptr;
+  TRY(amsm_ctx_create(&c, curve, device_ids[0], nullptr));
+  c->shard_ctx.push_back(c);
+  bool ok = hipEventCreateWithFlags(&c->multi_fork, hipEventDisableTiming) == hipSuccess;
+  for (int g = 1; g < n_dev && ok; g++) {
+    amsm_ctx* cg = nullptr;
+    int rc = amsm_ctx_create(&cg, curve, device_ids[g], nullptr);
+    if (rc != AMSM_OK) {
+      amsm_ctx_destroy(c);
+      return rc;
+    }
+    cg->parent = c;
+    c->shard_ctx.push_back(cg);
+    c->workers.push_back(new ShardWorker());
+  }
+  if (!ok) {
+    amsm_ctx_destroy(c);
+    return AMSM_E_HIP;
+  }
+  (void)hipSetDevice(c->device);
+  if (n_dev > 1) {
+    bool distinct = true;
+    for (int a = 0; a < n_dev; a++)
+      for (int b = a + 1; b < n_dev; b++) distinct = distinct && device_ids[a] != device_ids[b];
+    const char* want = getenv("AMSM_COLLECTIVE");  // "rccl" (fail if unavailable) | "peer" | unset (RCCL when possible)
+    const bool force_rccl = want && strcmp(want, "rccl") == 0, force_peer = want && strcmp(want, "peer") == 0;
+    c->collective = 2;
+    if (!force_peer && distinct) {
+      const RcclApi& api = RcclApi::get();
+      int e = -1;
+      if (api.ok) {
+        c->rccl_comms = new void*[n_dev]();
+        e = api.comm_init_all(c->rccl_comms, n_dev, device_ids);
+        (void)hipSetDevice(c->device);
+        if (e != 0) {
+          fprintf(stderr, "[amsm] ncclCommInitAll failed (%s)%s\n", api.error_string ? api.error_string(e) : "?",
+                  force_rccl ? "" : ": falling back to peer copies");
+          delete[] c->rccl_comms;
+          c->rccl_comms = nullptr;
+        }
+      }
+      if (e == 0) c->collective = 1;
+    }
+    if (c->collective != 1 && force_rccl) {
+      amsm_ctx_destroy(c);
+      return AMSM_E_RCCL;
+    }
+    if (c->collective == 2 && distinct) {  // direct peer copies where the fabric allows (xGMI); else HIP stages them
+      for (int a = 0; a < n_dev; a++)
+        for (int b = 0; b < n_dev; b++) {
+          int can = 0;
+          if (a != b && hipDeviceCanAccessPeer(&can, device_ids[a], device_ids[b]) == hipSuccess && can) {
+            (void)hipSetDevice(device_ids[a]);
+            (void)hipDeviceEnablePeerAccess(device_ids[b], 0);
+            (void)hipGetLastError();
+          }
+        }
+      (void)hipSetDevice(c->device);
+    }
+  }
+  *out = c;
+  return AMSM_OK;
+}
+
+int amsm_ctx_num_devices(const amsm_ctx* c) { return c ? (int)n_shards(c) : AMSM_E_INVALID_ARG; }
+amsm_ctx* amsm_ctx_shard(amsm_ctx* c, int g) {
+  if (!c || g < 0 || (size_t)g >= n_shards(c)) return nullptr;
+  return c->shard_ctx.empty() ? c : c->shard_ctx[g];
+}
+const char* amsm_ctx_collective(const amsm_ctx* c) {
+  if (!c) return "none";
+  return c->collective == 1 ? "rccl" : (c->collective == 2 ? "peer-copy" : "none");
 }
 
 int amsm_ctx_curve(const amsm_ctx* c) { return c ? c->curve : AMSM_E_INVALID_ARG; }
@@ -1185,6 +1611,7 @@ int amsm_ctx_set_window(amsm_ctx* c, int bits) {
 }
 int amsm_ctx_synchronize(amsm_ctx* c) {
   if (!c) return AMSM_E_INVALID_ARG;
+  for (size_t g = 1; g < c->shard_ctx.size(); g++) TRY(amsm_ctx_synchronize(c->shard_ctx[g]));
   TRY(bind_device(c));
   HIP_TRY(hipStreamSynchronize(c->s_prep));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1208,6 +1635,12 @@ int amsm_bases_load(amsm_ctx* c, const uint64_t* xy, const uint8_t* is_inf, size
   if (!c || !out || (n && !xy)) return AMSM_E_INVALID_ARG;
   if (n >= (1ull << 31)) return AMSM_E_UNSUPPORTED;
   TRY(bind_device(c));
+  if (n_shards(c) > 1) {  // shard g copies its own range of the caller's arrays
+    const size_t L2 = 2 * (size_t)amsm_ctx_fq_limbs(c);
+    return bases_create_sharded(c, n, out, [&](size_t, amsm_ctx* cg, size_t lo, size_t cnt, amsm_bases** o) {
+      return amsm_bases_load(cg, xy + lo * L2, is_inf ? is_inf + lo : nullptr, cnt, flags, o);
+    });
+  }
   return DISPATCH(c, (bases_load_impl<PallasFq, PallasFr>(c, xy, is_inf, n, flags, out)),
                   (bases_load_impl<Bls12381Fq, Bls12381Fr>(c, xy, is_inf, n, flags, out)));
 }
@@ -1215,28 +1648,77 @@ int amsm_bases_generate(amsm_ctx* c, uint64_t seed, size_t n, unsigned flags, am
   if (!c || !out) return AMSM_E_INVALID_ARG;
   if (n >= (1ull << 31)) return AMSM_E_UNSUPPORTED;
   TRY(bind_device(c));
+  if (n_shards(c) > 1)  // shard g generates its own range of the synthetic stream
+    return bases_create_sharded(c, n, out, [&](size_t, amsm_ctx* cg, size_t lo, size_t cnt, amsm_bases** o) {
+      return DISPATCH(cg, (bases_generate_impl<PallasFq, PallasFr>(cg, seed, cnt, flags, o, lo)),
+                      (bases_generate_impl<Bls12381Fq, Bls12381Fr>(cg, seed, cnt, flags, o, lo)));
+    });
   return DISPATCH(c, (bases_generate_impl<PallasFq, PallasFr>(c, seed, n, flags, out)),
                   (bases_generate_impl<Bls12381Fq, Bls12381Fr>(c, seed, n, flags, out)));
 }
 int amsm_bases_read(amsm_ctx* c, const amsm_bases* b, size_t off, size_t n, uint64_t* xy, uint8_t* is_inf) {
   if (!c || !b || (n && !xy) || b->curve != c->curve) return AMSM_E_INVALID_ARG;
+  if (key_sharded(b)) {
+    if (!key_matches(c, b) || off > b->n || n > b->n - off) return AMSM_E_INVALID_ARG;
+    const size_t L2 = 2 * (size_t)amsm_ctx_fq_limbs(c);
+    for (size_t g = 0; g < b->shards.size(); g++) {
+      const size_t lo = std::max(b->bound[g], off), hi = std::min(b->bound[g + 1], off + n);
+      if (hi > lo)
+        TRY(amsm_bases_read(c->shard_ctx[g], b->shards[g], lo - b->bound[g], hi - lo, xy + (lo - off) * L2,
+                            is_inf ? is_inf + (lo - off) : nullptr));
+    }
+    return bind_device(c);
+  }
   TRY(bind_device(c));
   return DISPATCH(c, (bases_read_impl<PallasFq>(c, b, off, n, xy, is_inf)),
                   (bases_read_impl<Bls12381Fq>(c, b, off, n, xy, is_inf)));
 }
 size_t amsm_bases_len(const amsm_bases* b) { return b ? b->n : 0; }
 int amsm_bases_precomputed(const amsm_bases* b) { return b ? b->precomp : 0; }
+int amsm_bases_num_shards(const amsm_bases* b) { return !b ? 0 : (key_sharded(b) ? (int)b->shards.size() : 1); }
+int amsm_bases_shard_range(const amsm_bases* b, int g, size_t* lo, size_t* hi) {
+  if (!b || !lo || !hi || g < 0 || g >= amsm_bases_num_shards(b)) return AMSM_E_INVALID_ARG;
+  *lo = key_sharded(b) ? b->bound[g] : 0;
+  *hi = key_sharded(b) ? b->bound[g + 1] : b->n;
+  return AMSM_OK;
+}
 void amsm_bases_free(amsm_bases* b) {
   if (!b) return;
+  for (amsm_bases* s : b->shards) amsm_bases_free(s);
+  b->shards.clear();
   (void)hipSetDevice(b->device);
+  if (b->ready) {
+    (void)hipEventSynchronize(b->ready);
+    (void)hipEventDestroy(b->ready);
+  }
   if (b->d_table) (void)hipFree(b->d_table);
   if (b->d_abi) (void)hipFree(b->d_abi);
   delete b;
 }
 
+// n_vecs MSMs over a sharded key -> n_vecs affine points (shared by every entry point that accepts one)
+static int msm_sharded_affine(amsm_ctx* c, const amsm_bases* b, size_t off, size_t n, size_t n_vecs, int mont, SliceKind kind,
+                              const void* const* srcs, uint64_t* out_xy, uint8_t* out_inf) {
+  TRY(bind_device(c));
+  if (c->curve == AMSM_PALLAS) {
+    std::vector<host::HXYZZ<PallasFq>> r;
+    TRY((msm_sharded<PallasFq, PallasFr>(c, b, off, n, n_vecs, mont, kind, srcs, &r)));
+    write_affine_batch<PallasFq>(r, out_xy, out_inf);
+  } else {
+    std::vector<host::HXYZZ<Bls12381Fq>> r;
+    TRY((msm_sharded<Bls12381Fq, Bls12381Fr>(c, b, off, n, n_vecs, mont, kind, srcs, &r)));
+    write_affine_batch<Bls12381Fq>(r, out_xy, out_inf);
+  }
+  return AMSM_OK;
+}
+
 int amsm_msm(amsm_ctx* c, const amsm_bases* b, size_t off, const uint64_t* scalars, size_t n, int mont, uint64_t* out_xy,
              uint8_t* out_inf) {
-  if (!c || !b || !out_xy || (n && !scalars) || b->curve != c->curve || b->device != c->device) return AMSM_E_INVALID_ARG;
+  if (!c || !b || !out_xy || (n && !scalars) || !key_matches(c, b)) return AMSM_E_INVALID_ARG;
+  if (key_sharded(b)) {
+    const void* src = scalars;
+    return msm_sharded_affine(c, b, off, n, 1, mont, SLICE_HOST, &src, out_xy, out_inf);
+  }
   TRY(bind_device(c));
   if (c->curve == AMSM_PALLAS) {
     host::HXYZZ<PallasFq> r;
@@ -1252,8 +1734,8 @@ int amsm_msm(amsm_ctx* c, const amsm_bases* b, size_t off, const uint64_t* scala
 
 int amsm_msm_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* d_scalars, size_t n, int mont,
                     uint64_t* out_xy, uint8_t* out_inf) {
-  if (!c || !b || !out_xy || (n && !d_scalars) || b->curve != c->curve || b->device != c->device)
-    return AMSM_E_INVALID_ARG;
+  if (!c || !b || !out_xy || (n && !d_scalars) || !key_matches(c, b)) return AMSM_E_INVALID_ARG;
+  if (key_sharded(b)) return msm_sharded_affine(c, b, off, n, 1, mont, SLICE_PRIMARY, &d_scalars, out_xy, out_inf);
   TRY(bind_device(c));
   if (c->curve == AMSM_PALLAS) {
     host::HXYZZ<PallasFq> r;
@@ -1269,10 +1751,10 @@ int amsm_msm_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* d_
 
 int amsm_msm_batch_device(amsm_ctx* c, const amsm_bases* b, size_t off, const void* const* d_scalars, size_t n_vecs,
                           size_t n, int mont, uint64_t* out_xy, uint8_t* out_inf) {
-  if (!c || !b || (n_vecs && (!d_scalars || !out_xy)) || b->curve != c->curve || b->device != c->device)
-    return AMSM_E_INVALID_ARG;
+  if (!c || !b || (n_vecs && (!d_scalars || !out_xy)) || !key_matches(c, b)) return AMSM_E_INVALID_ARG;
   for (size_t v = 0; v < n_vecs; v++)
     if (n && !d_scalars[v]) return AMSM_E_INVALID_ARG;
+  if (key_sharded(b)) return msm_sharded_affine(c, b, off, n, n_vecs, mont, SLICE_PRIMARY, d_scalars, out_xy, out_inf);
   TRY(bind_device(c));
   if (c->curve == AMSM_PALLAS) {
     std::vector<host::HXYZZ<PallasFq>> r;
@@ -1289,8 +1771,9 @@ int amsm_msm_batch_device(amsm_ctx* c, const amsm_bases* b, size_t off, const vo
 int amsm_msm_multi_device(amsm_ctx* c, const amsm_bases* b, size_t n_msms, const size_t* base_offs,
                           const void* const* d_scalars, const size_t* ns, int mont, uint64_t* out_xy, uint8_t* out_inf) {
   if (!c || !b || (n_msms && (!base_offs || !d_scalars || !ns || !out_xy)) || b->curve != c->curve ||
-      b->device != c->device)
+      (!key_sharded(b) && b->device != c->device))
     return AMSM_E_INVALID_ARG;
+  if (key_sharded(b)) return AMSM_E_UNSUPPORTED;
   for (size_t v = 0; v < n_msms; v++)
     if (ns[v] && !d_scalars[v]) return AMSM_E_INVALID_ARG;
   TRY(bind_device(c));
@@ -1310,6 +1793,7 @@ int amsm_msm_grouped_device(amsm_ctx* c, const amsm_bases* b, size_t off, const 
                             unsigned group_shift, uint64_t* out_xy, uint8_t* out_inf) {
   if (!c || !b || !out_xy || (n && !d_scalars) || group_shift > 31 || b->curve != c->curve || b->device != c->device)
     return AMSM_E_INVALID_ARG;
+  if (key_sharded(b)) return AMSM_E_UNSUPPORTED;  // does not shard (include/amsm.h: amsm_ctx_create_multi)
   TRY(bind_device(c));
   return DISPATCH(c, (msm_grouped_impl<PallasFq, PallasFr>(c, b, off, d_scalars, n, mont, group_shift, out_xy, out_inf)),
                   (msm_grouped_impl<Bls12381Fq, Bls12381Fr>(c, b, off, d_scalars, n, mont, group_shift, out_xy, out_inf)));
@@ -1324,6 +1808,7 @@ int amsm_msm_partial_device(amsm_ctx* c, const amsm_bases* b, size_t off, const 
                             void* d_out) {
   if (!c || !b || !d_out || (n && !d_scalars) || b->curve != c->curve || b->device != c->device)
     return AMSM_E_INVALID_ARG;
+  if (key_sharded(b)) return AMSM_E_UNSUPPORTED;  // does not shard (include/amsm.h: amsm_ctx_create_multi)
   TRY(bind_device(c));
   return DISPATCH(c, (msm_partial_impl<PallasFq, PallasFr>(c, b, off, d_scalars, n, mont, d_out)),
                   (msm_partial_impl<Bls12381Fq, Bls12381Fr>(c, b, off, d_scalars, n, mont, d_out)));
@@ -1335,6 +1820,7 @@ int amsm_msm_partial_batch_device(amsm_ctx* c, const amsm_bases* b, size_t off, 
     return AMSM_E_INVALID_ARG;
   for (size_t v = 0; v < n_vecs; v++)
     if (n && !d_scalars[v]) return AMSM_E_INVALID_ARG;
+  if (key_sharded(b)) return AMSM_E_UNSUPPORTED;  // does not shard (include/amsm.h: amsm_ctx_create_multi)
   TRY(bind_device(c));
   return DISPATCH(c, (msm_partial_batch_impl<PallasFq, PallasFr>(c, b, off, d_scalars, n_vecs, n, mont, d_out)),
                   (msm_partial_batch_impl<Bls12381Fq, Bls12381Fr>(c, b, off, d_scalars, n_vecs, n, mont, d_out)));
@@ -1355,11 +1841,32 @@ int amsm_partials_combine(amsm_ctx* c, const void* d_partials, size_t count, uin
                   (partials_combine_impl<Bls12381Fq>(c, d_partials, count, out_xy, out_inf)));
 }
 
+static int pedersen_sharded(amsm_ctx* c, const amsm_bases* ck, size_t n, SliceKind kind, const void* const* src,
+                            const uint64_t* rand_mont, const uint64_t* hiding_xy, uint64_t* out_xy, uint8_t* out_inf) {
+  TRY(bind_device(c));
+  return DISPATCH(c, (pedersen_sharded_impl<PallasFq, PallasFr>(c, ck, n, kind, src, rand_mont, hiding_xy, out_xy, out_inf)),
+                  (pedersen_sharded_impl<Bls12381Fq, Bls12381Fr>(c, ck, n, kind, src, rand_mont, hiding_xy, out_xy, out_inf)));
+}
+
+int amsm_msm_batch_sharded_device(amsm_ctx* c, const amsm_bases* b, const void* const* d_slices, size_t n_vecs, int mont,
+                                  uint64_t* out_xy, uint8_t* out_inf) {
+  if (!c || !b || (n_vecs && (!d_slices || !out_xy)) || !key_matches(c, b)) return AMSM_E_INVALID_ARG;
+  if (!key_sharded(b)) return amsm_msm_batch_device(c, b, 0, d_slices, n_vecs, b->n, mont, out_xy, out_inf);
+  const size_t N = b->shards.size();
+  for (size_t v = 0; v < n_vecs; v++)
+    for (size_t g = 0; g < N; g++)
+      if (b->bound[g + 1] > b->bound[g] && !d_slices[v * N + g]) return AMSM_E_INVALID_ARG;
+  return msm_sharded_affine(c, b, 0, b->n, n_vecs, mont, SLICE_SHARDED, d_slices, out_xy, out_inf);
+}
+
 int amsm_pedersen_commit(amsm_ctx* c, const amsm_bases* ck, const uint64_t* elems, size_t n, const uint64_t* rand_mont,
                          const uint64_t* hiding_xy, uint64_t* out_xy, uint8_t* out_inf) {
-  if (!c || !ck || !out_xy || (n && !elems) || ck->curve != c->curve || ck->device != c->device)
-    return AMSM_E_INVALID_ARG;
+  if (!c || !ck || !out_xy || (n && !elems) || !key_matches(c, ck)) return AMSM_E_INVALID_ARG;
   if ((rand_mont == nullptr) != (hiding_xy == nullptr)) return AMSM_E_INVALID_ARG;
+  if (key_sharded(ck)) {
+    const void* src = elems;
+    return pedersen_sharded(c, ck, n, SLICE_HOST, &src, rand_mont, hiding_xy, out_xy, out_inf);
+  }
   TRY(bind_device(c));
   return DISPATCH(c, (pedersen_impl<PallasFq, PallasFr>(c, ck, elems, n, rand_mont, hiding_xy, out_xy, out_inf)),
                   (pedersen_impl<Bls12381Fq, Bls12381Fr>(c, ck, elems, n, rand_mont, hiding_xy, out_xy, out_inf)));
@@ -1367,9 +1874,9 @@ int amsm_pedersen_commit(amsm_ctx* c, const amsm_bases* ck, const uint64_t* elem
 
 int amsm_pedersen_commit_device(amsm_ctx* c, const amsm_bases* ck, const void* d_elems, size_t n,
                                 const uint64_t* rand_mont, const uint64_t* hiding_xy, uint64_t* out_xy, uint8_t* out_inf) {
-  if (!c || !ck || !out_xy || (n && !d_elems) || ck->curve != c->curve || ck->device != c->device)
-    return AMSM_E_INVALID_ARG;
+  if (!c || !ck || !out_xy || (n && !d_elems) || !key_matches(c, ck)) return AMSM_E_INVALID_ARG;
   if ((rand_mont == nullptr) != (hiding_xy == nullptr)) return AMSM_E_INVALID_ARG;
+  if (key_sharded(ck)) return pedersen_sharded(c, ck, n, SLICE_PRIMARY, &d_elems, rand_mont, hiding_xy, out_xy, out_inf);
   TRY(bind_device(c));
   return DISPATCH(c, (pedersen_device_impl<PallasFq, PallasFr>(c, ck, d_elems, n, rand_mont, hiding_xy, out_xy, out_inf)),
                   (pedersen_device_impl<Bls12381Fq, Bls12381Fr>(c, ck, d_elems, n, rand_mont, hiding_xy, out_xy,
@@ -1520,9 +2027,13 @@ int amsm_bases_from_device(amsm_ctx* c, const void* d_xy, size_t n, unsigned fla
   return AMSM_OK;
 }
 const void* amsm_bases_device_ptr(const amsm_bases* b) {
-  if (!b) return nullptr;
+  if (!b || key_sharded(b)) return nullptr;
   bool internal = b->curve == AMSM_PALLAS ? device_internal_radix<PallasFq>() : device_internal_radix<Bls12381Fq>();
+  // the table may still be written by the fold that created the key (queued on that context's non-blocking stream,
+  // which the NULL stream below does not order behind)
+  if (b->ready && hipEventSynchronize(b->ready) != hipSuccess) return nullptr;
   if (!internal) return b->d_table;
+  std::lock_guard<std::mutex> lock(b->abi_mu);
   if (!b->d_abi && b->n) {  // the table is in the device radix: hand out a C-ABI-radix copy of level 0
     size_t pb = (b->curve == AMSM_PALLAS) ? affine_bytes<PallasFq>() : affine_bytes<Bls12381Fq>();
     int prev = 0;
@@ -1588,6 +2099,7 @@ int amsm_bases_fold(amsm_ctx* c, const amsm_bases* key, size_t n_half, const uin
   if (!c || !key || !out || !x_mont || key->curve != c->curve || key->device != c->device || nbits > 256 ||
       n_half == 0 || 2 * n_half > key->n)
     return AMSM_E_INVALID_ARG;
+  if (key_sharded(key)) return AMSM_E_UNSUPPORTED;
   TRY(bind_device(c));
   size_t pb = (c->curve == AMSM_PALLAS) ? affine_bytes<PallasFq>() : affine_bytes<Bls12381Fq>();
   amsm_bases* b = new (std::nothrow) amsm_bases();
@@ -1609,12 +2121,15 @@ int amsm_bases_fold(amsm_ctx* c, const amsm_bases* key, size_t n_half, const uin
     launch_points_fold<PallasFq>(c->stream, l, r, (u32)n_half, canon, nbits, b->d_table, false, scratch);
   else
     launch_points_fold<Bls12381Fq>(c->stream, l, r, (u32)n_half, canon, nbits, b->d_table, false, scratch);
-  if (hipGetLastError() != hipSuccess) {
+  if (hipGetLastError() != hipSuccess || hipEventCreateWithFlags(&b->ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventRecord(b->ready, c->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    if (b->ready) (void)hipEventDestroy(b->ready);
     (void)hipFree(b->d_table);
     delete b;
     return AMSM_E_HIP;
   }
-  *out = b;  // stream-ordered: every consumer (MSM prep, another fold) is ordered behind the context's stream
+  *out = b;  // stream-ordered: MSM prep and further folds are ordered behind the context's stream; others wait for `ready`
   return AMSM_OK;
 }
 
@@ -1695,6 +2210,7 @@ int amsm_ipa_round(amsm_ctx* c, const amsm_bases* key, const uint64_t* xi_mont, 
   if (!c || !key || !d_coeffs || !d_z || !d_u || !out_lr_xy || !out_ip_mont || (j && !xi_mont) || log_key == 0 || log_key > 30 ||
       j >= log_key || key->curve != c->curve || key->device != c->device)
     return AMSM_E_INVALID_ARG;
+  if (key_sharded(key)) return AMSM_E_UNSUPPORTED;
   TRY(bind_device(c));
   const size_t half = (size_t)1 << (log_key - j - 1);
   return DISPATCH(c, (ipa_round_impl<PallasFq, PallasFr>(c, key, xi_mont, j, log_key, d_coeffs, d_z, half, d_u, out_lr_xy, out_lr_inf,

@@ -4,6 +4,7 @@
 #include "vec_kernels.h"
 #include "prep_kernels.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -51,18 +52,29 @@ static PrepGeom prep_geom(const MsmGeom& g) {
 static size_t prep_heavy_words(const MsmGeom& g) { return (size_t)g.B + 4096 + 64; }
 size_t prep_small_words(const MsmGeom& g) { return 4 * (PREP_MAX_P + 1) + 1 + 3 * prep_heavy_words(g) + PREP_MAX_HEAVY; }
 static size_t prep_local_lds(const PrepGeom& pg) { return (2 * (size_t)(1u << pg.SH) + 1024 + pg.CAP) * sizeof(u32); }
-// more than 64 KiB of dynamic LDS needs the attribute once per process
-static bool prep_local_attr_done = false;
+// more than 64 KiB of dynamic LDS needs the attribute, once per DEVICE (the attribute is per device: a second context on
+// another GPU of the same process needs its own opt-in)
+constexpr size_t PREP_LDS_LIMIT = 160 * 1024;  // gfx950: 160 KiB per workgroup
+static std::atomic<unsigned long long> prep_local_attr_devices{0};
 static void prep_local_attr() {
-  if (prep_local_attr_done) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  const unsigned long long bit = 1ull << dev;
+  if (dev != 63 && (prep_local_attr_devices.load(std::memory_order_acquire) & bit)) return;
   (void)hipFuncSetAttribute((const void*)k_prep_local, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-  prep_local_attr_done = true;
+  prep_local_attr_devices.fetch_or(bit, std::memory_order_release);
+}
+static size_t prep_scatter_lds(const MsmGeom& g, const PrepGeom& pg) {
+  const size_t cap = (size_t)pg.SPB * g.S;
+  return (3 * (size_t)pg.P + cap) * sizeof(u32) + cap * sizeof(uint16_t);
 }
 bool prep_supported(const MsmGeom& g) {
   if (g.n == 0 || g.S > 32u) return false;  // S > 32 <=> c < 8: tiny problems, the rocPRIM chain is fine there
   PrepGeom pg = prep_geom(g);
-  // entry word = negate | bucket-id low bits << IB | index; k_prep_local keeps 2 * 2^SH + 256 words in LDS
-  return pg.SH <= 12u && pg.IB + pg.SH <= 31u;
+  // entry word = negate | bucket-id low bits << IB | index; k_prep_local keeps 2 * 2^SH + 256 words in LDS; the dynamic
+  // LDS of every kernel of the chain must fit a workgroup (wide windows / many bucket sets: fall back to rocPRIM)
+  return pg.SH <= 12u && pg.IB + pg.SH <= 31u && prep_scatter_lds(g, pg) <= PREP_LDS_LIMIT &&
+         prep_local_lds(pg) <= PREP_LDS_LIMIT && (pg.P + 256) * sizeof(u32) <= 64 * 1024;
 }
 
 void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
@@ -88,8 +100,15 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
     if (hipMemsetAsync(b.d_small, 0, (4 * (PREP_MAX_P + 1) + 1 + prep_heavy_words(g)) * sizeof(u32), st) != hipSuccess) \
       return -1;                                                                                                     \
     u32 blocks = cdiv_(g.n, pg.SPB);                                                                                 \
-    u32 cap = pg.SPB * g.S;                                                                                          \
-    size_t lds_scatter = (3 * pg.P + cap) * sizeof(u32) + cap * sizeof(uint16_t);                                    \
+    size_t lds_scatter = prep_scatter_lds(g, pg);                                                                    \
+    if (lds_scatter > 64 * 1024) { /* rare (P above ~1300): opt in for this launch's instantiation */                \
+      if (g.S <= 16u)                                                                                                \
+        (void)hipFuncSetAttribute((const void*)k_prep_scatter<FR, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)PREP_LDS_LIMIT);                                                              \
+      else                                                                                                           \
+        (void)hipFuncSetAttribute((const void*)k_prep_scatter<FR, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)PREP_LDS_LIMIT);                                                              \
+    }                                                                                                                \
     {  /* the histogram's blocking is independent of the scatter's: 1024 scalars, one per lane */                    \
       PrepGeom ph = pg;                                                                                              \
       ph.SPB = 1024;                                                                                                 \

@@ -11,9 +11,11 @@ namespace amsm {
 // ---- per-curve (Fq) launchers ------------------------------------------------------------------
 template <class Fq>
 void launch_accum_l0(hipStream_t st, const u32* table, const u32* vals_sorted, const u32* start,
-                     const u32* item_off, MsmGeom g, u32* partials);
+                     const u32* item_off, MsmGeom g, u32* partials, u32 lds_pad = 0);
+// resident 256-lane workgroups of accumulate L0 per CU (occupancy query); lds_pad = unused dynamic LDS per workgroup,
+// which caps the residency (AMSM_L0_LDS_PAD: leaves wave slots / registers to the kernels of the other MSMs in flight)
 template <class Fq>
-int accum_l0_blocks_per_cu();  // resident 256-lane workgroups of accumulate L0 per CU (occupancy query)
+int accum_l0_blocks_per_cu(u32 lds_pad = 0);
 template <class Fq>
 void launch_accum_l1(hipStream_t st, u32 lanes_per_bucket, const u32* partials, const u32* items, const u32* item_off, MsmGeom g,
                      u32* buckets, u32* heavy_count, u32* heavy_list);
@@ -36,7 +38,7 @@ void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, 
 template <class Fq>
 void launch_apply_inf(hipStream_t st, u32* table, const uint8_t* is_inf, u32 n);
 template <class Fq>
-void launch_generate_bases(hipStream_t st, u32* table, u64 seed, u32 n, const u32* gen_xy_mont);
+void launch_generate_bases(hipStream_t st, u32* table, u64 seed, u32 first, u32 n, const u32* gen_xy_mont);
 
 // The device may keep points in an internal Montgomery radix (fpu.h): key tables, partials and buckets are in it,
 // everything the C ABI exposes is not.  import/export convert a point array (src may equal dst); they do

@@ -29,8 +29,8 @@
 namespace amsm {
 
 // ---------------------------------------------------------------------------------------------
-// accumulate L0: lane c owns the fixed-size chunk [c*K0, (c+1)*K0) of the SORTED entry list, whatever
-// buckets it spans: every lane does exactly K0 gathered mixed additions, so all SIMDs stay at full
+// accumulate L0: lane c owns the fixed-size chunk [chunk_start(c), chunk_start(c+1)) of the SORTED entry list, whatever
+// buckets it spans: every lane of a workgroup does exactly K0 (K0b) gathered mixed additions, so all SIMDs stay at full
 // occupancy until the end of the kernel and wave64 lanes stay converged for ANY digit distribution
 // (uniform, or the all-equal vectors of SURVEY.md F8).  When the bucket id changes inside a chunk the
 // lane flushes its running sum as one partial of the finished bucket.  The partials of bucket b are the
@@ -78,8 +78,11 @@ AMSM_DEV Affine<Fq> gather_read(const u32* lds_wave, u32 lane) {
 // after the sort), bits 0..29 = index into the generator table.
 constexpr u32 ENTRY_NEG = 0x80000000u, ENTRY_LAST = 0x40000000u, ENTRY_IDX = 0x3fffffffu;
 
+#ifndef AMSM_L0_VGPR_ATTR
+#define AMSM_L0_VGPR_ATTR
+#endif
 template <class Fq>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) AMSM_L0_VGPR_ATTR
     k_accum_l0(const u32* __restrict__ table, const u32* __restrict__ vals_sorted, const u32* __restrict__ start,
                const u32* __restrict__ item_off, MsmGeom g, u32* __restrict__ partials) {
   // two gather regions per wave: the points of mixed addition i+2 are fetched while i and i+1 are computed
@@ -87,11 +90,18 @@ __global__ void __launch_bounds__(256)
   const u32 lane = threadIdx.x & 63u;
   u32* lds_wave0 = lds + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (2 * GatherLds<Fq>::WAVE_BYTES / 4);
   u32* lds_wave1 = lds_wave0 + GatherLds<Fq>::WAVE_BYTES / 4;
-  u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 e_valid = start[g.B];  // entries with a non-zero digit
-  if (blockIdx.x * blockDim.x * g.K0 >= e_valid) return;  // the grid is sized for n*W entries; zero digits emit none
-  u32 s = c * g.K0;          // K0 is a multiple of 4: every lane's chunk is a 16-byte aligned run of entries
-  u32 e = min(s + g.K0, e_valid);
+  // (A persistent grid drawing 64-chunk units from a global counter -- a fixed share of the wave slots for accumulate L0, the
+  // rest left to the other MSMs' prep / tail kernels -- was built and measured in round 2: 2 resident workgroups per CU run
+  // a lone launch as fast as 3 (the VALU saturates with two waves per SIMD), but a batch gets no faster: the concurrent
+  // kernels cost their stand-alone time whichever slots they run in.  profiles/r02_pipeline_experiments.md.)
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 e_valid = start[g.B];  // entries with a non-zero digit
+  // chunk size of this workgroup (msm_types.h: two phases, nA is a multiple of the workgroup size)
+  const bool ph_a = blockIdx.x * blockDim.x < g.nA;
+  const u32 K = ph_a ? g.K0 : g.K0b;
+  if (chunk_start(g, blockIdx.x * blockDim.x) >= e_valid) return;  // the grid is sized for n*W entries; zero digits emit none
+  u32 s = ph_a ? c * g.K0 : g.T0 + (c - g.nA) * g.K0b;  // K0, K0b multiples of 4: a chunk is a 16-byte aligned run of entries
+  u32 e = min(s + K, e_valid);
   // every lane runs all K0 iterations (the gather is cooperative); lanes past their range replay a valid
   // group of entries and skip the arithmetic.  Entries are read 4 at a time (one dwordx4 per 4 mixed
   // additions): 8x fewer requests than word-by-word reads of a stride-128-byte access pattern.
@@ -112,7 +122,7 @@ __global__ void __launch_bounds__(256)
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   gather_issue<Fq>(table, cur.x & ENTRY_IDX, lds_wave0, lane);
   gather_issue<Fq>(table, cur.y & ENTRY_IDX, lds_wave1, lane);
-  for (u32 grp = 0; grp < g.K0; grp += 4) {
+  for (u32 grp = 0; grp < K; grp += 4) {
     uint4 nn = v4[min(s + grp + 8, last_grp) / 4];
     u32 w[6] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y};
 #pragma unroll
@@ -131,7 +141,7 @@ __global__ void __launch_bounds__(256)
         u32 v = w[i];
         xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (v & ENTRY_NEG) != 0));
         if ((v & ENTRY_LAST) || k + 1 == e) {  // bucket (or chunk) finished: flush one partial
-          u32 slot = item_off[b_cur] + (c - start[b_cur] / g.K0);
+          u32 slot = item_off[b_cur] + (c - chunk_of(g, start[b_cur]));
           xyzz_store<Fq>(partials, slot, acc);
           acc = xyzz_inf<Fq>();
           if (k + 1 < e) {  // next entry opens the next NON-EMPTY bucket: largest b with start[b] <= k+1
@@ -551,17 +561,18 @@ struct AffineWords {  // an affine point as kernel-argument words (C-ABI Montgom
   u32 w[2 * Fq::W];
 };
 
-// G_i = k_i * G, k_i = rng_scalar(seed, i); generator (gx, gy) passed in (C-ABI) Montgomery form.
+// table[i] = G_{first + i} = k * G, k = rng_scalar(seed, first + i); generator (gx, gy) passed in (C-ABI) Montgomery form.
+// `first`: a shard of a multi-device key generates its own range of the stream.
 template <class Fq>
 __global__ void __launch_bounds__(256)
-    k_generate_bases(u32* __restrict__ table, u64 seed, u32 n, AffineWords<Fq> gw) {
+    k_generate_bases(u32* __restrict__ table, u64 seed, u32 first, u32 n, AffineWords<Fq> gw) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<Fq> gen;
   gen.x = fe_import<Fq>(fe_from_words<Fq>(gw.w));
   gen.y = fe_import<Fq>(fe_from_words<Fq>(gw.w + Fq::W));
   u32 k[8];
-  rng_scalar(seed, i, k);
+  rng_scalar(seed, first + i, k);
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   for (int bit = 253; bit >= 0; bit--) {
     acc = xyzz_dbl<Fq>(acc);

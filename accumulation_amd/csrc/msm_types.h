@@ -24,11 +24,26 @@ struct MsmGeom {
   u32 base_off;      // first generator used
   u32 table_stride;  // generators per table level (key length)
   u32 precomp;       // table has W levels
-  u32 K0;            // entries per L0 work item
+  u32 K0;            // entries per accumulate-L0 work item (chunk) of phase A: chunks [0, nA)
+  u32 K0b;           // ... of phase B: chunks [nA, n_chunks).  Two sizes (K0 > K0b, both multiples of 4) let the grid be a
+                     // WHOLE number of rounds of the resident wave slots: with one size the last round of a 2^20-pair
+                     // launch was 56 % full (3.56 rounds of 24 entries: 11 % of the kernel's time on half-empty SIMDs)
+  u32 nA;            // chunks of phase A (a multiple of 256: a workgroup never straddles the phases)
+  u32 T0;            // entries covered by phase A = nA * K0
+  u32 n_chunks;      // work items of accumulate L0 (upper bound: sized for E entries)
   u32 K1;            // max partials folded by one L1 lane
   u32 red_s;         // buckets per reduce lane
   u32 red_threads;   // reduce lanes per set
 };
+
+// chunk <-> entry position of the two-phase chunking (host and device)
+#if defined(__HIPCC__)
+#define AMSM_GEOM_FN __host__ __device__ inline
+#else
+#define AMSM_GEOM_FN inline
+#endif
+AMSM_GEOM_FN u32 chunk_of(const MsmGeom& g, u32 pos) { return pos < g.T0 ? pos / g.K0 : g.nA + (pos - g.T0) / g.K0b; }
+AMSM_GEOM_FN u32 chunk_start(const MsmGeom& g, u32 c) { return c < g.nA ? c * g.K0 : g.T0 + (c - g.nA) * g.K0b; }
 
 struct CombineArgs {
   const u32* vec[VEC_MAX];

@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(1024)
     u32 c = cnt[k];
     off[k] = run;
     u32 lo = ps + run, hi = lo + c;
-    u32 it = c ? (hi - 1) / g.K0 - lo / g.K0 + 1 : 0u;
+    u32 it = c ? chunk_of(g, hi - 1) - chunk_of(g, lo) + 1 : 0u;
     if (b0 + k < g.B) {
       start[b0 + k] = lo;  // also for empty buckets: where the bucket would start
       items[b0 + k] = it;
@@ -521,10 +521,10 @@ __global__ void __launch_bounds__(256)
       item_off[g.B] = sl[T - 1];  // total number of partials
     }
     // accumulate L0 reads entries in groups of 4 and prefetches the point of every entry it reads; its last active
-    // workgroup covers entries up to the next multiple of 256 * K0 past e_valid (plus two groups of look-ahead), clamped
+    // workgroup starts at or before e_valid and covers 256 chunks (plus two groups of look-ahead), clamped
     // to the group holding entry E - 1: everything in that range past the real entries must be a valid table index
-    const u32 span = 256u * g.K0;
-    unsigned long long reach = ((unsigned long long)(e_valid / span) + 1ull) * span + 16ull;
+    const u32 span = 256u * max(g.K0, g.K0b);
+    unsigned long long reach = (unsigned long long)e_valid + span + 16ull;
     const u32 pad_end = (u32)min(reach, (unsigned long long)((g.E + 3u) & ~3u));
     for (u32 k = e_valid + t; k < pad_end; k += T) vals_sorted[k] = 0;
   }

@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256)
   u32 hi = lower_bound_u32(keys_sorted, g.E, b + 1);
   start[b] = lo;
   if (hi > lo) vals_sorted[hi - 1] |= 0x40000000u;  // ENTRY_LAST: accumulate L0 no longer needs the keys
-  items[b] = hi > lo ? (hi - 1) / g.K0 - lo / g.K0 + 1 : 0u;
+  items[b] = hi > lo ? chunk_of(g, hi - 1) - chunk_of(g, lo) + 1 : 0u;
   if (b == g.B - 1) {
     start[g.B] = hi;
     items[g.B] = 0;

@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libamsm.so")
+# AMSM_LIB_PATH: load another build of the same library (A/B of compile-time variants, tools/build_variant.sh)
+LIB_PATH = os.environ.get("AMSM_LIB_PATH") or os.path.join(_HERE, "libamsm.so")
 
 AMSM_PALLAS = 0
 AMSM_BLS12_381_G1 = 1
@@ -23,6 +24,7 @@ AMSM_E_HIP = -3
 AMSM_E_UNSUPPORTED = -4
 AMSM_E_NO_DEVICE = -5
 AMSM_E_SCALAR_RANGE = -6
+AMSM_E_RCCL = -7
 
 AMSM_BASES_DEFAULT = 0
 AMSM_BASES_PRECOMPUTE = 1
@@ -38,6 +40,10 @@ SIGNATURES = {
     "amsm_strerror": (C.c_char_p, [C.c_int]),
     "amsm_device_count": (C.c_int, []),
     "amsm_ctx_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),
+    "amsm_ctx_create_multi": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "amsm_ctx_num_devices": (C.c_int, [_vp]),
+    "amsm_ctx_shard": (_vp, [_vp, C.c_int]),
+    "amsm_ctx_collective": (C.c_char_p, [_vp]),
     "amsm_ctx_destroy": (None, [_vp]),
     "amsm_ctx_curve": (C.c_int, [_vp]),
     "amsm_ctx_fq_limbs": (C.c_int, [_vp]),
@@ -51,11 +57,14 @@ SIGNATURES = {
     "amsm_bases_generate": (C.c_int, [_vp, C.c_uint64, _sz, C.c_uint, C.POINTER(_vp)]),
     "amsm_bases_read": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "amsm_bases_len": (_sz, [_vp]),
+    "amsm_bases_num_shards": (C.c_int, [_vp]),
+    "amsm_bases_shard_range": (C.c_int, [_vp, C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
     "amsm_bases_precomputed": (C.c_int, [_vp]),
     "amsm_bases_free": (None, [_vp]),
     "amsm_msm": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_msm_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_msm_batch_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_vp), _sz, _sz, C.c_int, _vp, _vp]),
+    "amsm_msm_batch_sharded_device": (C.c_int, [_vp, _vp, C.POINTER(_vp), _sz, C.c_int, _vp, _vp]),
     "amsm_msm_multi_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), C.c_int, _vp, _vp]),
     "amsm_msm_grouped_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, C.c_uint, _vp, _vp]),
     "amsm_partial_bytes": (_sz, [_vp]),

@@ -156,9 +156,10 @@ class AtomicASForInnerProductArgPC:
         fr = Fr(ctx.curve)
         ins = list(inputs)
         olds = list(old_accumulators)
-        for x in ins + olds:  # check_input_instance_structure :112-128
-            if x.ipa_commitment.shifted_comm is not None:
-                raise (MalformedAccumulator if x in olds else MalformedInput)("Explicit degree bounds not supported.")
+        for group, err in ((ins, MalformedInput), (olds, MalformedAccumulator)):  # check_input_instance_structure :112-128
+            for x in group:
+                if x.ipa_commitment.shifted_comm is not None:
+                    raise err("Explicit degree bounds not supported.")
         make_zk = rng is not None
         if not make_zk:
             for x in ins + olds:

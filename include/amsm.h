@@ -22,6 +22,11 @@
  * opaque handles.  A ctx is NOT thread-safe; an amsm_bases is immutable after creation.
  * Errors: 0 = OK, negative = AMSM_E_*; nothing throws across the boundary.
  * There is NO CPU fallback: every entry point fails with AMSM_E_NO_DEVICE when no gfx950 GPU is usable.
+ *
+ * Multi-GPU: ONE process drives the GPUs of a node through a multi-device context (amsm_ctx_create_multi, below): the
+ * committer key is sharded over the devices by contiguous index ranges, every MSM entry point that takes a key accepts a
+ * sharded one, and the devices' partial sums are exchanged inside the library (RCCL all-gather over xGMI, peer copies as
+ * the fallback).  The one-process-per-GPU form (amsm_msm_partial*_device + the caller's own collective) remains.
  */
 #ifndef AMSM_H
 #define AMSM_H
@@ -49,6 +54,7 @@ enum amsm_status {
   AMSM_E_UNSUPPORTED = -4,
   AMSM_E_NO_DEVICE = -5,
   AMSM_E_SCALAR_RANGE = -6, /* a scalar was >= 2^255 (not a canonical `into_repr()` value) */
+  AMSM_E_RCCL = -7,         /* the RCCL collective of a multi-device context failed */
 };
 
 /* flags for amsm_bases_load / amsm_bases_generate */
@@ -67,6 +73,27 @@ int amsm_device_count(void);
  * `stream` is a hipStream_t owned by the caller (e.g. torch.cuda.current_stream().cuda_stream) or
  * NULL to let the context create its own non-blocking stream. */
 int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream);
+/* Multi-device context (reference: `prove` is ONE synchronous call in ONE process,
+ * src/lib.rs:163-249): n_dev >= 1 devices driven by the calling process.  Device device_ids[0] is the PRIMARY: scalar
+ * vectors handed to the `_device` entry points, the scalar-field vector kernels and every result live there.  Keys created
+ * through this context are SHARDED: device g holds generators [lo_g, hi_g) = [g*n/n_dev, (g+1)*n/n_dev) (its own
+ * precomputed table), and amsm_msm / amsm_msm_device / amsm_msm_batch_device / amsm_pedersen_commit[_device] split the
+ * scalars the same way (host slices are uploaded straight to their device, primary-device vectors are peer-copied), run the
+ * shards concurrently (one host worker thread per device), gather the per-device 128/192-byte partial sums on the primary
+ * with ONE RCCL all-gather per call (communicators created from the device list; hipMemcpyPeerAsync when RCCL is
+ * unavailable, AMSM_COLLECTIVE=peer, or a device is listed twice) and fold + normalise once.  Results are bit-identical to
+ * the single-device ones.  Entry points that do not shard (grouped / multi-offset MSMs, key folds, the IPA round,
+ * amsm_bases_device_ptr) return AMSM_E_UNSUPPORTED / NULL for a sharded key.
+ * A device id may appear more than once (two shards on one GPU: how a 1-GPU box exercises this path). */
+int amsm_ctx_create_multi(amsm_ctx** out, int curve, const int* device_ids, int n_dev);
+/* 1 for amsm_ctx_create contexts. */
+int amsm_ctx_num_devices(const amsm_ctx* ctx);
+/* The single-device context of shard g (borrowed: destroyed with its parent; g = 0 is the primary, i.e. usable exactly
+ * like `ctx` itself): lets the caller allocate / fill / transform scalar vectors ON device g with the ordinary entry
+ * points, e.g. the slices amsm_msm_batch_sharded_device takes.  NULL when g is out of range. */
+amsm_ctx* amsm_ctx_shard(amsm_ctx* ctx, int g);
+/* "rccl", "peer-copy" (multi-device contexts) or "none". */
+const char* amsm_ctx_collective(const amsm_ctx* ctx);
 void amsm_ctx_destroy(amsm_ctx* ctx);
 int amsm_ctx_curve(const amsm_ctx* ctx);
 /* limbs (u64) of a base-field element: 4 (Pallas) or 6 (BLS12-381). */
@@ -97,6 +124,9 @@ int amsm_bases_generate(amsm_ctx* ctx, uint64_t seed, size_t n, unsigned flags, 
 /* Copy generators [off, off+n) back to the host (affine, Montgomery). */
 int amsm_bases_read(amsm_ctx* ctx, const amsm_bases* bases, size_t off, size_t n, uint64_t* xy_mont, uint8_t* is_inf);
 size_t amsm_bases_len(const amsm_bases* bases);
+/* Shards of a key (1 for a single-device key) and the generator range [*lo, *hi) shard g holds. */
+int amsm_bases_num_shards(const amsm_bases* bases);
+int amsm_bases_shard_range(const amsm_bases* bases, int g, size_t* lo, size_t* hi);
 int amsm_bases_precomputed(const amsm_bases* bases);
 void amsm_bases_free(amsm_bases* bases);
 
@@ -121,6 +151,13 @@ int amsm_msm_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, con
  * outputs are n_vecs consecutive points. */
 int amsm_msm_batch_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* const* d_scalars,
                           size_t n_vecs, size_t n, int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+
+/* amsm_msm_batch_device over a WHOLE sharded key with the scalars already sharded: d_slices[v * n_dev + g] is the slice of
+ * vector v for shard g -- (hi_g - lo_g) scalars resident on device g (allocated / produced through amsm_ctx_shard(ctx, g)).
+ * No scalar crosses a device boundary: only the partial sums do (weak scaling: what bench.py --gpus N times in its
+ * single-process mode).  A single-device context accepts n_dev = 1. */
+int amsm_msm_batch_sharded_device(amsm_ctx* ctx, const amsm_bases* bases, const void* const* d_slices, size_t n_vecs,
+                                  int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
 
 /* n_msms independent MSMs over windows of ONE key, pipelined like amsm_msm_batch_device: MSM v uses generators
  * [base_offs[v], base_offs[v] + ns[v]) and the device scalars d_scalars[v].  The two cross commitments of an IPA
