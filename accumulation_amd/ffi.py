@@ -81,6 +81,12 @@ SIGNATURES = {
     "amsm_fr_inv": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_fr_to_mont": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_fr_from_mont": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "amsm_fr_serialized_size": (_sz, [C.c_int]),
+    "amsm_point_serialized_size": (_sz, [C.c_int, C.c_int]),
+    "amsm_fr_serialize": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "amsm_fr_deserialize": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "amsm_points_serialize": (C.c_int, [C.c_int, _vp, _vp, _sz, C.c_int, _vp]),
+    "amsm_points_deserialize": (C.c_int, [C.c_int, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_vec_fill": (C.c_int, [_vp, _vp, _sz, _vp]),
     "amsm_dev_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "amsm_dev_free": (C.c_int, [_vp, _vp]),

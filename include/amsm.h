@@ -250,6 +250,23 @@ int amsm_fr_inv(int curve, const uint64_t* a_mont, size_t n, uint64_t* out_mont)
 int amsm_fr_to_mont(int curve, const uint64_t* canonical, size_t n, uint64_t* out_mont);
 int amsm_fr_from_mont(int curve, const uint64_t* a_mont, size_t n, uint64_t* out_canonical);
 
+/* ---- wire format: ark-serialize 0.2 `CanonicalSerialize` / `CanonicalDeserialize` (ext) ---
+ * The reference derives it for every instance / witness / proof type (src/hp_as/data_structures.rs:13,53,76,94,
+ * src/r1cs_nark_as/data_structures.rs:105,155,217,249, src/ipa_pc_as/data_structures.rs:55,76) and prints
+ * `serialized_size()` at examples/scaling-as.rs:123-131.  Host only (no context, no device).  The composite types are
+ * assembled from these in include/amsm_serialize.hpp.  PARITY UNPINNED (accumulation_amd/csrc/host_serialize.h).
+ *   field element : canonical integer, little-endian, 32 bytes (Fr of both curves)
+ *   point         : compressed = x with 2 flag bits in the top of the last byte (bit 7: y is the larger root, bit 6:
+ *                   infinity) -- 33 bytes (Pallas) / 48 (BLS12-381 G1); uncompressed = x | y+flags -- 65 / 96 bytes.
+ * Deserialisation returns AMSM_E_INVALID_ARG for a non-canonical integer, an x without a point, a point off the curve or
+ * outside the prime-order subgroup, or both flag bits set. */
+size_t amsm_fr_serialized_size(int curve);
+size_t amsm_point_serialized_size(int curve, int compressed);
+int amsm_fr_serialize(int curve, const uint64_t* a_mont, size_t n, uint8_t* out);
+int amsm_fr_deserialize(int curve, const uint8_t* in, size_t n, uint64_t* out_mont);
+int amsm_points_serialize(int curve, const uint64_t* xy_mont, const uint8_t* is_inf, size_t n, int compressed, uint8_t* out);
+int amsm_points_deserialize(int curve, const uint8_t* in, size_t n, int compressed, uint64_t* xy_mont, uint8_t* is_inf);
+
 /* ---- inner-product-argument opening (ark_poly_commit::ipa_pc, ext) ------------ */
 /* Committer key living in device memory (the folded keys of the IPA rounds change every round, so they are
  * never precomputed): wraps a COPY of n affine points (Montgomery x|y, (0,0) = identity) at d_xy. */
