@@ -21,6 +21,7 @@
 
 #include "fp.h"
 #include "host_field.h"
+#include "host_poseidon.h"
 #include "host_serialize.h"
 #include "launch.h"
 
@@ -165,6 +166,12 @@ struct amsm_bases {
   std::vector<amsm_bases*> shards;
   std::vector<size_t> bound;
   const amsm_ctx* owner = nullptr;
+};
+
+struct amsm_sponge {  // host-side Poseidon sponge over the curve's base field (host_poseidon.h)
+  int curve = 0;
+  host::PoseidonSponge<PallasFq> pallas;
+  host::PoseidonSponge<Bls12381Fq> bls;
 };
 
 struct amsm_matrix {
@@ -1981,6 +1988,121 @@ int amsm_points_deserialize(int curve, const uint8_t* in, size_t n, int compress
       ok = host::point_deserialize<Bls12381Fq>(in + i * sz, compressed != 0, 4, true, r, xy_mont + i * 12, is_inf + i);
     }
     if (!ok) return AMSM_E_INVALID_ARG;
+  }
+  return AMSM_OK;
+}
+
+// ---- Poseidon sponge (host_poseidon.h) ---------------------------------------------------------------------------------
+#define SPONGE_DO(s, EXPR_P, EXPR_B) \
+  do {                               \
+    if ((s)->curve == AMSM_PALLAS) { \
+      auto& sp = (s)->pallas;        \
+      using FQ = PallasFq;           \
+      (void)sizeof(FQ);              \
+      EXPR_P;                        \
+    } else {                         \
+      auto& sp = (s)->bls;           \
+      using FQ = Bls12381Fq;         \
+      (void)sizeof(FQ);              \
+      EXPR_B;                        \
+    }                                \
+  } while (0)
+int amsm_poseidon_new(int curve, amsm_sponge** out) {
+  if (!out || (curve != AMSM_PALLAS && curve != AMSM_BLS12_381_G1)) return AMSM_E_INVALID_ARG;
+  amsm_sponge* s = new (std::nothrow) amsm_sponge();
+  if (!s) return AMSM_E_OOM;
+  s->curve = curve;
+  *out = s;
+  return AMSM_OK;
+}
+int amsm_poseidon_clone(const amsm_sponge* s, amsm_sponge** out) {
+  if (!s || !out) return AMSM_E_INVALID_ARG;
+  amsm_sponge* c = new (std::nothrow) amsm_sponge(*s);
+  if (!c) return AMSM_E_OOM;
+  *out = c;
+  return AMSM_OK;
+}
+void amsm_poseidon_free(amsm_sponge* s) { delete s; }
+int amsm_poseidon_absorb_native(amsm_sponge* s, const uint64_t* fq_mont, size_t n) {
+  if (!s || (n && !fq_mont)) return AMSM_E_INVALID_ARG;
+  SPONGE_DO(s, sp.absorb_words(fq_mont, n), sp.absorb_words(fq_mont, n));
+  return AMSM_OK;
+}
+int amsm_poseidon_absorb_u64(amsm_sponge* s, uint64_t v) {
+  if (!s) return AMSM_E_INVALID_ARG;
+  SPONGE_DO(s, sp.absorb_u64(v), sp.absorb_u64(v));
+  return AMSM_OK;
+}
+int amsm_poseidon_absorb_bytes(amsm_sponge* s, const uint8_t* b, size_t n) {
+  if (!s || (n && !b)) return AMSM_E_INVALID_ARG;
+  SPONGE_DO(s, sp.absorb_bytes(b, n), sp.absorb_bytes(b, n));
+  return AMSM_OK;
+}
+int amsm_poseidon_absorb_points(amsm_sponge* s, const uint64_t* xy_mont, const uint8_t* is_inf, size_t n) {
+  if (!s || (n && !xy_mont)) return AMSM_E_INVALID_ARG;
+  SPONGE_DO(s, sp.absorb_points(xy_mont, is_inf, n), sp.absorb_points(xy_mont, is_inf, n));
+  return AMSM_OK;
+}
+int amsm_poseidon_fork(const amsm_sponge* s, const uint8_t* domain, size_t n, amsm_sponge** out) {
+  if (!s || !out || (n && !domain)) return AMSM_E_INVALID_ARG;
+  TRY(amsm_poseidon_clone(s, out));
+  std::vector<uint8_t> input(8 + n);  // `domain.len()` as u64 little-endian, then the domain
+  for (int i = 0; i < 8; i++) input[i] = (uint8_t)((uint64_t)n >> (8 * i));
+  if (n) memcpy(input.data() + 8, domain, n);
+  return amsm_poseidon_absorb_bytes(*out, input.data(), input.size());
+}
+int amsm_poseidon_squeeze_native(amsm_sponge* s, size_t n, uint64_t* out_fq_mont) {
+  if (!s || (n && !out_fq_mont)) return AMSM_E_INVALID_ARG;
+  SPONGE_DO(s, sp.squeeze_words(n, out_fq_mont), sp.squeeze_words(n, out_fq_mont));
+  return AMSM_OK;
+}
+int amsm_poseidon_squeeze_bits(amsm_sponge* s, size_t n_bits, uint8_t* out_bytes) {
+  if (!s || (n_bits && !out_bytes)) return AMSM_E_INVALID_ARG;
+  std::vector<uint8_t> b;
+  SPONGE_DO(s, b = sp.squeeze_bits(n_bits), b = sp.squeeze_bits(n_bits));
+  if (!b.empty()) memcpy(out_bytes, b.data(), b.size());
+  return AMSM_OK;
+}
+int amsm_poseidon_squeeze_nonnative(amsm_sponge* s, unsigned n_bits, size_t count, uint64_t* out_canonical) {
+  if (!s || (count && !out_canonical) || n_bits == 0 || n_bits > 254) return AMSM_E_INVALID_ARG;
+  std::vector<uint8_t> b;
+  const size_t total = (size_t)n_bits * count;
+  SPONGE_DO(s, b = sp.squeeze_bits(total), b = sp.squeeze_bits(total));
+  memset(out_canonical, 0, count * 32);
+  for (size_t k = 0; k < count; k++)
+    for (unsigned i = 0; i < n_bits; i++) {
+      const size_t bit = k * n_bits + i;
+      if ((b[bit >> 3] >> (bit & 7)) & 1) out_canonical[4 * k + (i >> 6)] |= 1ull << (i & 63);
+    }
+  return AMSM_OK;
+}
+int amsm_poseidon_permute(int curve, uint64_t* state_mont) {
+  if (!state_mont || (curve != AMSM_PALLAS && curve != AMSM_BLS12_381_G1)) return AMSM_E_INVALID_ARG;
+  amsm_sponge s;
+  s.curve = curve;
+  SPONGE_DO(&s, {
+    constexpr int N = host::HFe<FQ>::N;
+    for (int i = 0; i < 3; i++) memcpy(sp.state[i].v, state_mont + i * N, 8 * N);
+    sp.permute();
+    for (int i = 0; i < 3; i++) memcpy(state_mont + i * N, sp.state[i].v, 8 * N);
+  }, {
+    constexpr int N = host::HFe<FQ>::N;
+    for (int i = 0; i < 3; i++) memcpy(sp.state[i].v, state_mont + i * N, 8 * N);
+    sp.permute();
+    for (int i = 0; i < 3; i++) memcpy(state_mont + i * N, sp.state[i].v, 8 * N);
+  });
+  return AMSM_OK;
+}
+int amsm_poseidon_round_constants(int curve, uint64_t* out_mont) {  // (8 + 31) * 3 elements, round-major
+  if (!out_mont || (curve != AMSM_PALLAS && curve != AMSM_BLS12_381_G1)) return AMSM_E_INVALID_ARG;
+  if (curve == AMSM_PALLAS) {
+    const auto& p = host::PoseidonParams<PallasFq>::get();
+    for (int r = 0; r < 39; r++)
+      for (int i = 0; i < 3; i++) memcpy(out_mont + (r * 3 + i) * 4, p.ark[r][i].v, 32);
+  } else {
+    const auto& p = host::PoseidonParams<Bls12381Fq>::get();
+    for (int r = 0; r < 39; r++)
+      for (int i = 0; i < 3; i++) memcpy(out_mont + (r * 3 + i) * 6, p.ark[r][i].v, 48);
   }
   return AMSM_OK;
 }

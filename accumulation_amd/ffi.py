@@ -87,6 +87,19 @@ SIGNATURES = {
     "amsm_fr_deserialize": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_points_serialize": (C.c_int, [C.c_int, _vp, _vp, _sz, C.c_int, _vp]),
     "amsm_points_deserialize": (C.c_int, [C.c_int, _vp, _sz, C.c_int, _vp, _vp]),
+    "amsm_poseidon_new": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "amsm_poseidon_clone": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "amsm_poseidon_free": (None, [_vp]),
+    "amsm_poseidon_fork": (C.c_int, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "amsm_poseidon_absorb_native": (C.c_int, [_vp, _vp, _sz]),
+    "amsm_poseidon_absorb_u64": (C.c_int, [_vp, C.c_uint64]),
+    "amsm_poseidon_absorb_bytes": (C.c_int, [_vp, _vp, _sz]),
+    "amsm_poseidon_absorb_points": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "amsm_poseidon_squeeze_native": (C.c_int, [_vp, _sz, _vp]),
+    "amsm_poseidon_squeeze_bits": (C.c_int, [_vp, _sz, _vp]),
+    "amsm_poseidon_squeeze_nonnative": (C.c_int, [_vp, C.c_uint, _sz, _vp]),
+    "amsm_poseidon_permute": (C.c_int, [C.c_int, _vp]),
+    "amsm_poseidon_round_constants": (C.c_int, [C.c_int, _vp]),
     "amsm_vec_fill": (C.c_int, [_vp, _vp, _sz, _vp]),
     "amsm_dev_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "amsm_dev_free": (C.c_int, [_vp, _vp]),

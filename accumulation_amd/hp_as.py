@@ -235,7 +235,7 @@ class ASForHadamardProducts:
     @staticmethod
     def _absorb_statement(sponge, num_elems: int, instances, hiding_comms):  # absorb!(...) :753-758, :863-868
         sponge.absorb_u64(num_elems)
-        sponge.absorb_u64(len(instances))
+        sponge.absorb_len(len(instances))
         for inst in instances:
             inst.absorb_into(sponge)
         if hiding_comms is None:

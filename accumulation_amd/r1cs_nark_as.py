@@ -175,10 +175,10 @@ class ASForR1CSNark:
         """:423-448"""
         s = as_sponge
         s.absorb_bytes(as_matrices_hash)
-        s.absorb_u64(len(acc_instances))
+        s.absorb_len(len(acc_instances))
         for a in acc_instances:
             a.absorb_into(s, fr)
-        s.absorb_u64(len(input_instances))
+        s.absorb_len(len(input_instances))
         for i in input_instances:
             i.absorb_into(s, fr)
         if proof_randomness is None:

@@ -267,6 +267,35 @@ int amsm_fr_deserialize(int curve, const uint8_t* in, size_t n, uint64_t* out_mo
 int amsm_points_serialize(int curve, const uint64_t* xy_mont, const uint8_t* is_inf, size_t n, int compressed, uint8_t* out);
 int amsm_points_deserialize(int curve, const uint8_t* in, size_t n, int compressed, uint64_t* xy_mont, uint8_t* is_inf);
 
+/* ---- Poseidon sponge over the curve's base field (ark-sponge `PoseidonSponge<ConstraintF<G>>`, ext) ------------------------
+ * The `S` every scheme test of the reference instantiates (src/hp_as/mod.rs:1047-1055, src/r1cs_nark_as/mod.rs:1279-1287,
+ * examples/scaling-as.rs:27,36); call sites of absorb / squeeze: src/hp_as/mod.rs:233-275,753-780, src/r1cs_nark_as/mod.rs:
+ * 423-448, src/r1cs_nark_as/r1cs_nark/mod.rs:49-72, src/ipa_pc_as/mod.rs:254-388.  Host only: O(#inputs) hashing, SURVEY.md
+ * section 8(f) rank 2.  Parameters and encodings are stated in accumulation_amd/csrc/host_poseidon.h (PARITY UNPINNED: ark-sponge
+ * @ branch `accumulation-experimental` is not in /root/reference).  include/amsm_poseidon.hpp wraps this as the `Sponge`
+ * template argument of the scheme drivers. */
+typedef struct amsm_sponge amsm_sponge;
+int amsm_poseidon_new(int curve, amsm_sponge** out);                       /* PoseidonSponge::new() */
+int amsm_poseidon_clone(const amsm_sponge* s, amsm_sponge** out);
+void amsm_poseidon_free(amsm_sponge* s);
+/* `fork(domain)`: a clone that absorbed (domain.len() as u64 LE || domain) as a byte string. */
+int amsm_poseidon_fork(const amsm_sponge* s, const uint8_t* domain, size_t n, amsm_sponge** out);
+/* absorb: native elements (base field, Montgomery); one usize / bool / Option tag; a byte string (31-byte LE chunks for
+ * Pallas, 47 for BLS12-381, one element each); affine points (x, y, infinity each). */
+int amsm_poseidon_absorb_native(amsm_sponge* s, const uint64_t* fq_mont, size_t n);
+int amsm_poseidon_absorb_u64(amsm_sponge* s, uint64_t v);
+int amsm_poseidon_absorb_bytes(amsm_sponge* s, const uint8_t* bytes, size_t n);
+int amsm_poseidon_absorb_points(amsm_sponge* s, const uint64_t* xy_mont, const uint8_t* is_inf, size_t n);
+int amsm_poseidon_squeeze_native(amsm_sponge* s, size_t n, uint64_t* out_fq_mont);
+/* n_bits bits, little-endian, packed into ceil(n_bits / 8) bytes. */
+int amsm_poseidon_squeeze_bits(amsm_sponge* s, size_t n_bits, uint8_t* out_bytes);
+/* `squeeze_nonnative_field_elements_with_sizes(&[Truncated(n_bits); count])` -> count canonical integers < 2^n_bits
+ * (4 u64 each); n_bits <= 254.  ONE squeeze for the whole batch (the windows are consecutive bits of it). */
+int amsm_poseidon_squeeze_nonnative(amsm_sponge* s, unsigned n_bits, size_t count, uint64_t* out_canonical);
+/* The bare permutation on 3 elements (Montgomery), and the 39 * 3 round constants, for known-answer tests. */
+int amsm_poseidon_permute(int curve, uint64_t* state_mont);
+int amsm_poseidon_round_constants(int curve, uint64_t* out_mont);
+
 /* ---- inner-product-argument opening (ark_poly_commit::ipa_pc, ext) ------------ */
 /* Committer key living in device memory (the folded keys of the IPA rounds change every round, so they are
  * never precomputed): wraps a COPY of n affine points (Montgomery x|y, (0,0) = identity) at d_xy. */

@@ -73,7 +73,20 @@ class Sha256 {
   }
 };
 
-// Same construction as accumulation_amd/sponge.py:Sha256Sponge (byte-identical challenges).
+// The `Sponge` template argument of every scheme driver (the reference's `S: CryptographicSponge<ConstraintF<G>>`,
+// src/hp_as/mod.rs:98-103) is any type with these members; the absorb calls of the drivers follow the reference's `absorb!`
+// item lists one to one:
+//   void absorb_bytes(const std::vector<uint8_t>&)   a byte string item (hashes, `to_bytes!(..)` of scalars, Option tags)
+//   void absorb_u64(uint64_t)                        a usize item
+//   void absorb_len(uint64_t)                        the length of a Vec that is about to be absorbed item by item: FRAMING for
+//                                                    hash-based sponges only -- the reference's field-element encoding of a
+//                                                    Vec has no length (include/amsm_poseidon.hpp ignores it)
+//   void absorb_point(const Affine&), absorb_points(const std::vector<Affine>&)
+//   Fr squeeze_bits(unsigned n_bits)                 `squeeze_nonnative_field_elements_with_sizes(&[Truncated(n_bits)])`
+//   std::vector<Fr> squeeze_field_elements(size_t count, unsigned n_bits)    the same for `[Truncated(n_bits); count]`: ONE
+//                                                    squeeze (a Poseidon sponge cuts the windows out of one bit stream)
+//   S fork(const char* domain)
+// Sha256Sponge: same construction as accumulation_amd/sponge.py:Sha256Sponge (byte-identical challenges).
 class Sha256Sponge {
  public:
   Sha256Sponge() {
@@ -99,9 +112,15 @@ class Sha256Sponge {
     b.push_back(p.infinity ? 1 : 0);
     absorb_bytes(b);
   }
+  void absorb_len(uint64_t n) { absorb_u64(n); }
   void absorb_points(const std::vector<Affine>& pts) {
-    absorb_u64(pts.size());
+    absorb_len(pts.size());
     for (auto& p : pts) absorb_point(p);
+  }
+  std::vector<Fr> squeeze_field_elements(size_t count, unsigned n_bits) {
+    std::vector<Fr> out;
+    for (size_t i = 0; i < count; i++) out.push_back(squeeze_bits(n_bits));
+    return out;
   }
   // `squeeze_nonnative_field_elements_with_sizes(Truncated(n_bits))`, n_bits <= 256: canonical limbs
   Fr squeeze_bits(unsigned n_bits) {
@@ -428,7 +447,8 @@ class ASForHadamardProducts {
   }
   static std::vector<Fr> squeeze_mu(Sponge& sponge, const FrOps& fr, size_t num_inputs, bool make_zk) {  // :233-253
     std::vector<Fr> mu{fr.one()};
-    for (size_t i = 1; i < num_inputs; i++) mu.push_back(fr.to_mont(sponge.squeeze_bits(CHALLENGE_SIZE)));
+    if (num_inputs > 1)
+      for (const Fr& c : sponge.squeeze_field_elements(num_inputs - 1, CHALLENGE_SIZE)) mu.push_back(fr.to_mont(c));
     if (make_zk) mu.push_back(fr.mul(mu[1], mu[num_inputs - 1]));
     return mu;
   }
@@ -445,7 +465,7 @@ class ASForHadamardProducts {
   static void absorb_statement(Sponge& sponge, size_t num_elems, const std::vector<const InputInstance*>& instances,
                                const std::optional<ProofHidingCommitments>& hiding) {  // absorb!(...) :753-758, :863-868
     sponge.absorb_u64(num_elems);
-    sponge.absorb_u64(instances.size());
+    sponge.absorb_len(instances.size());
     for (auto* i : instances) i->absorb_into(sponge);
     if (!hiding) {
       sponge.absorb_bytes({0});

@@ -572,8 +572,10 @@ class AtomicASForInnerProductArgPC {
     Combined out;
     std::vector<const Affine*> pts;
     std::vector<Fr> scs;
+    std::vector<Fr> squeezed = sp.squeeze_field_elements(checks.size(), LINEAR_COMBINATION_CHALLENGE_SIZE);
+    size_t k_chal = 0;
     for (auto& c : checks) {
-      Fr a = sp.squeeze_bits(LINEAR_COMBINATION_CHALLENGE_SIZE);
+      Fr a = squeezed[k_chal++];
       out.alphas_canon.push_back(a);
       out.alphas.push_back(fr.to_mont(a));
       pts.push_back(&c.final_comm_key);

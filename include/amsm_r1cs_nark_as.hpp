@@ -334,9 +334,9 @@ class ASForR1CSNark {
                                          const std::vector<const AccumulatorInstance*>& accs, const std::vector<const InputInstance*>& ins,
                                          const std::optional<ProofRandomness>& pr, Sponge& s) {
     s.absorb_bytes(std::vector<uint8_t>(as_hash.begin(), as_hash.end()));
-    s.absorb_u64(accs.size());
+    s.absorb_len(accs.size());
     for (auto* a : accs) a->absorb_into(s);
-    s.absorb_u64(ins.size());
+    s.absorb_len(ins.size());
     for (auto* i : ins) i->absorb_into(s);
     if (!pr) {
       s.absorb_bytes({0});
@@ -350,7 +350,8 @@ class ASForR1CSNark {
       s.absorb_point(pr->comm_r_c);
     }
     std::vector<Fr> beta{fr.one()};
-    for (size_t k = 1; k < num; k++) beta.push_back(fr.to_mont(s.squeeze_bits(CHALLENGE_SIZE)));
+    if (num > 1)
+      for (const Fr& c : s.squeeze_field_elements(num - 1, CHALLENGE_SIZE)) beta.push_back(fr.to_mont(c));
     return beta;
   }
   struct Components {

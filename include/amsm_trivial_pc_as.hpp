@@ -243,7 +243,7 @@ class ASForTrivialPC {
       sp.absorb_bytes(canonical_bytes(fr, p.witness_eval));
     }
     std::vector<Fr> out;
-    for (size_t k = 0; k < 2 * proof.size(); k++) out.push_back(fr.to_mont(sp.squeeze_bits(LINEAR_COMBINATION_CHALLENGE_SIZE)));
+    for (const Fr& c : sp.squeeze_field_elements(2 * proof.size(), LINEAR_COMBINATION_CHALLENGE_SIZE)) out.push_back(fr.to_mont(c));
     return out;
   }
   static Affine lincomb(Context& ctx, const std::vector<const Affine*>& points, const std::vector<Fr>& scalars) {

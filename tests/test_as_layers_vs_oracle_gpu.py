@@ -30,6 +30,9 @@ class RecordingSponge:
     def absorb_u64(self, x):
         self.inner.absorb_u64(x)
 
+    def absorb_len(self, n):
+        self.inner.absorb_len(n)
+
     def absorb_point(self, p):
         self.inner.absorb_point(p)
 
