@@ -4,5 +4,5 @@ The product is libamsm.so (hand-written HIP for gfx950 behind the C ABI in inclu
 is the thin host-side mirror of the reference interfaces used by tests, bench.py and examples.
 """
 from . import ffi  # noqa: F401
-from .engine import (CommitterKey, Context, FrVector, PedersenCommitment,  # noqa: F401
+from .engine import (CommitterKey, Context, FrVector, MultiContext, PedersenCommitment,  # noqa: F401
                      PointVector, VariableBaseMSM)

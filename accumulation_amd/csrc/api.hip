@@ -30,7 +30,12 @@ using namespace amsm;
 namespace {
 
 enum Stage { ST_DIGITS = 0, ST_SORT, ST_BOUNDS, ST_ACCUM_L0, ST_ACCUM_L12, ST_REDUCE, ST_COUNT };
-const char* kStageNames[ST_COUNT] = {"digits", "sort", "bounds_scan", "accum_l0", "accum_l1_l2", "bucket_reduce_fold"};
+// Elapsed device time between the stage's first and last kernel on the stream the stage runs on (hipEvent pairs).  The first
+// three are the prep stream: with the short prep chain everything is in "prep_chain" (the other two only have work in the
+// rocPRIM fallback).  Inside a batch these are the times the kernels take WHILE SHARING the GPU with the other MSMs in flight
+// (prep_chain stretches to about one accumulate-L0 duration); a blocking call gives the stand-alone times.
+const char* kStageNames[ST_COUNT] = {"prep_chain", "prep_sort_rocprim", "prep_bounds_rocprim", "accum_l0", "accum_l1_l2",
+                                     "bucket_reduce_fold"};
 
 struct DevBuf {
   void* p = nullptr;
@@ -46,7 +51,8 @@ constexpr int N_SLOTS = 3;  // MSMs of one batch in flight
 
 struct Slot {  // buffers and events of one MSM in flight (the streams belong to the context: one per pipeline stage)
   hipEvent_t l0_done = nullptr, prep_done = nullptr;
-  hipEvent_t ev[ST_COUNT + 1] = {};
+  hipEvent_t ev[ST_COUNT + 1] = {};  // stage begins (each on the stream its stage runs on)
+  hipEvent_t ev_prep_end = nullptr, ev_l0_end = nullptr;  // ends of the stages whose successor starts on ANOTHER stream
   hipEvent_t done = nullptr;
   DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
       sort_tmp, scan_tmp, prep_small, heavy_scratch;
@@ -119,6 +125,10 @@ struct amsm_ctx {
   int window_override = 0;
   int K0 = 0;          // 0 = automatic (see make_geom)
   int cu_count = 256;
+  // AMSM_L0_SPREAD=1: small launches as ONE round at 1-2 workgroups per CU (residency capped with unused LDS).  Built on the
+  // theory that the dispatcher packs a CU to the kernel's occupancy before moving on; measured in round 2 it changes nothing
+  // (2^16: 0.460 vs 0.447 ms per blocking call) -- the small-launch time was the per-flush bucket search.  Off.
+  bool small_spread = false;
   u32 l0_lds_pad = 0;  // AMSM_L0_LDS_PAD: dynamic LDS bytes per accumulate-L0 workgroup that only cap its residency
   int K0_max = 32;     // automatic choice: largest chunk (AMSM_K0_MAX); round 2, batches of 2^20-pair MSMs: 32 -> 811-816, 24 -> 805 Mpairs/s
   bool two_phase = true;  // automatic choice: two chunk sizes so that the grid is a whole number of rounds (AMSM_K0_2PHASE=0: A/B)
@@ -328,10 +338,23 @@ int make_geom(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, size_t n,
   if ((unsigned long long)bases->n * (bases->precomp ? W : 1) >= (1ull << 30)) return AMSM_E_UNSUPPORTED;
   // chunk length of accumulate L0: the grid should be a whole number of rounds of the resident wave
   // slots (queried from the kernel's occupancy), so that no SIMD idles while a partial last round drains
+  const unsigned long long lanes_per_cu_block = 256ull * (unsigned long long)std::max(1, ctx->cu_count);
   if (ctx->K0 > 0) {
     g.K0 = ((u32)ctx->K0 + 3u) & ~3u;  // accumulate L0 reads entries in groups of 4
     g.K0b = g.K0;
     g.nA = 0xffffff00u;
+  } else if (ctx->small_spread && (unsigned long long)g.E <= lanes_per_cu_block * 2ull * 24ull) {
+    // Small MSMs (an IPA round at d + 1 = 2^16: 1.1 M entries): fewer workgroups than the GPU holds.  The dispatcher fills a
+    // CU to the kernel's occupancy (3 workgroups) before it moves on, so 384 workgroups ran on 128 of the 256 CUs, three
+    // waves per SIMD sharing one multiplier: 144 us for 47 us of dependent work per lane (rocprofv3 timeline, round 2).
+    // ONE round at 1 (or 2) workgroups per CU instead: the residency is capped with unused dynamic LDS, and the chunk is
+    // the lane's whole share.
+    const unsigned long long cap = (unsigned long long)g.E <= lanes_per_cu_block * 24ull ? 1ull : 2ull;
+    const unsigned long long share = (g.E + lanes_per_cu_block * cap - 1) / (lanes_per_cu_block * cap);
+    g.K0 = (u32)std::max<unsigned long long>(4ull, (share + 3ull) & ~3ull);
+    g.K0b = g.K0;
+    g.nA = 0xffffff00u;
+    g.l0_per_cu = (u32)cap;
   } else {
     // <= K0_max entries per lane per round of resident waves (24 measured best on MI355X for batches of MSMs,
     // tools/ab_pipeline.py: shorter chunks let the other MSMs' prep / tail kernels in sooner, longer ones save partials),
@@ -509,12 +532,16 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   }
   AMSM_DBG("pre-l0");
   }
+  if (ctx->profiling) (void)hipEventRecord(sl->ev_prep_end, st);
   HIP_TRY(hipEventRecord(sl->prep_done, st));
   HIP_TRY(hipStreamWaitEvent(sm, sl->prep_done, 0));
   stage_mark(ctx, sl, ST_ACCUM_L0, sm);
   launch_accum_l0<Fq>(sm, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)sl->start.p,
-                      (const u32*)sl->item_off.p, g, (u32*)sl->partials.p, ctx->l0_lds_pad);
+                      (const u32*)sl->item_off.p, g, (u32*)sl->partials.p,
+                      // 160 KiB of LDS per CU, 32 KiB static per workgroup: 64 KiB of padding lets one workgroup in, 24 KiB two
+                      g.l0_per_cu == 1 ? 65536u : (g.l0_per_cu == 2 ? 24576u : ctx->l0_lds_pad));
   AMSM_DBG("l0");
+  if (ctx->profiling) (void)hipEventRecord(sl->ev_l0_end, sm);
   HIP_TRY(hipEventRecord(sl->l0_done, sm));
   hipStream_t tl = ctx->s_tail;
   HIP_TRY(hipStreamWaitEvent(tl, sl->l0_done, 0));
@@ -558,7 +585,10 @@ int msm_collect(amsm_ctx* ctx, Slot* sl, host::HXYZZ<Fq>* out) {
   if (ctx->profiling) {
     for (int s = 0; s < ST_COUNT; s++) {
       float ms = 0;
-      (void)hipEventElapsedTime(&ms, sl->ev[s], sl->ev[s + 1]);
+      // a stage ends on its own stream: the next stage's begin mark sits on another stream for prep -> L0 -> tail, and
+      // would add that stream's queueing (the tail stream is still busy with the previous MSM inside a batch)
+      hipEvent_t end = s == ST_BOUNDS ? sl->ev_prep_end : (s == ST_ACCUM_L0 ? sl->ev_l0_end : sl->ev[s + 1]);
+      (void)hipEventElapsedTime(&ms, sl->ev[s], end);
       ctx->stage_acc[s] += ms;
     }
     ctx->stage_n++;
@@ -696,14 +726,18 @@ int bases_finish(amsm_ctx* ctx, amsm_bases* b, unsigned flags) {
   else if (flags & AMSM_BASES_NO_PRECOMPUTE) pre = false;
   else pre = b->n >= 256;
   if (!pre) return AMSM_OK;
+  // An EXPLICIT request (AMSM_BASES_PRECOMPUTE) that cannot be honoured is an error, not a silent 10x slower key; the
+  // library's own choice (AMSM_BASES_DEFAULT) degrades to the plain key.
+  const bool requested = (flags & AMSM_BASES_PRECOMPUTE) != 0;
   int c = ctx->window_override ? ctx->window_override : choose_window(b->n, true);
   int W = windows_for(c);
-  if ((unsigned long long)b->n * W >= (1ull << 30)) return AMSM_OK;  // stay un-precomputed
+  if ((unsigned long long)b->n * W >= (1ull << 30))  // entry words carry a 30-bit table index
+    return requested ? AMSM_E_UNSUPPORTED : AMSM_OK;
   u32* table = nullptr;
   hipError_t e = hipMalloc((void**)&table, (size_t)b->n * W * affine_bytes<Fq>());
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    return AMSM_OK;  // not enough HBM for W copies: keep the plain key
+    return requested ? AMSM_E_OOM : AMSM_OK;  // not enough HBM for W copies
   }
   HIP_TRY(hipMemcpyAsync(table, b->d_table, b->n * affine_bytes<Fq>(), hipMemcpyDeviceToDevice, ctx->stream));
   u32* scratch = nullptr;
@@ -1103,21 +1137,27 @@ int msm_partial_impl(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, co
 template <class Fr>
 int vec_combine_impl(amsm_ctx* ctx, const void* const* d_vecs, const size_t* lens, size_t n_vecs,
                      const uint64_t* coeffs, const void* d_hiding, size_t hiding_len, void* d_out, size_t n) {
-  if (n_vecs > (size_t)VEC_MAX) return AMSM_E_UNSUPPORTED;
   if (!n) return AMSM_OK;
-  CombineArgs a;
-  memset(&a, 0, sizeof(a));
-  for (size_t j = 0; j < n_vecs; j++) {
-    a.vec[j] = (const u32*)d_vecs[j];
-    a.len[j] = (u32)(lens ? std::min(lens[j], n) : n);
-    memcpy(a.coeff[j], coeffs + 4 * j, 32);
-  }
-  a.hiding = (const u32*)d_hiding;
-  a.hiding_len = (u32)hiding_len;
-  a.n_vecs = (u32)n_vecs;
-  a.n = (u32)n;
-  launch_vec_combine<Fr>(ctx->stream, a, (u32*)d_out);
-  HIP_TRY(hipGetLastError());
+  // more than VEC_MAX vectors (the reference has no limit): groups of VEC_MAX, the running sum carried as the "hiding"
+  // addend of the next launch (in place: a lane reads its own element of d_out before it writes it)
+  size_t done = 0;
+  do {
+    const size_t k = std::min(n_vecs - done, (size_t)VEC_MAX);
+    CombineArgs a;
+    memset(&a, 0, sizeof(a));
+    for (size_t j = 0; j < k; j++) {
+      a.vec[j] = (const u32*)d_vecs[done + j];
+      a.len[j] = (u32)(lens ? std::min(lens[done + j], n) : n);
+      memcpy(a.coeff[j], coeffs + 4 * (done + j), 32);
+    }
+    a.hiding = done ? (const u32*)d_out : (const u32*)d_hiding;
+    a.hiding_len = done ? (u32)n : (u32)hiding_len;
+    a.n_vecs = (u32)k;
+    a.n = (u32)n;
+    launch_vec_combine<Fr>(ctx->stream, a, (u32*)d_out);
+    HIP_TRY(hipGetLastError());
+    done += k;
+  } while (done < n_vecs);
   return AMSM_OK;
 }
 
@@ -1452,6 +1492,7 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   }
   for (int k = 0; k < N_SLOTS && ok; k++) {
     for (int i = 0; i <= ST_COUNT && ok; i++) ok = hipEventCreate(&c->slot[k].ev[i]) == hipSuccess;
+    ok = ok && hipEventCreate(&c->slot[k].ev_prep_end) == hipSuccess && hipEventCreate(&c->slot[k].ev_l0_end) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->slot[k].l0_done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->slot[k].prep_done, hipEventDisableTiming) == hipSuccess;
@@ -1476,6 +1517,7 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   if (const char* e = getenv("AMSM_PREP")) c->custom_prep = strcmp(e, "rocprim") != 0;
   if (const char* e = getenv("AMSM_K0")) c->K0 = std::max(0, atoi(e));
   if (const char* e = getenv("AMSM_K0_MAX")) c->K0_max = std::max(4, atoi(e));
+  if (const char* e = getenv("AMSM_L0_SPREAD")) c->small_spread = atoi(e) != 0;
   if (const char* e = getenv("AMSM_K0_2PHASE")) c->two_phase = atoi(e) != 0;
   if (const char* e = getenv("AMSM_TAIL_QUAD")) c->tail_quad = atoi(e) != 0;
   if (const char* e = getenv("AMSM_K1")) c->K1 = std::max(1, atoi(e));
@@ -1516,6 +1558,8 @@ void amsm_ctx_destroy(amsm_ctx* c) {
     if (sl->h_pinned) (void)hipHostFree(sl->h_pinned);
     for (int i = 0; i <= ST_COUNT; i++)
       if (sl->ev[i]) (void)hipEventDestroy(sl->ev[i]);
+    if (sl->ev_prep_end) (void)hipEventDestroy(sl->ev_prep_end);
+    if (sl->ev_l0_end) (void)hipEventDestroy(sl->ev_l0_end);
     if (sl->done) (void)hipEventDestroy(sl->done);
     if (sl->l0_done) (void)hipEventDestroy(sl->l0_done);
     if (sl->prep_done) (void)hipEventDestroy(sl->prep_done);

@@ -4,6 +4,7 @@
 #include "vec_kernels.h"
 #include "prep_kernels.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -11,6 +12,21 @@
 namespace amsm {
 
 static inline u32 cdiv_(u32 a, u32 b) { return (a + b - 1) / b; }
+// grid of a streaming (grid-stride) kernel: enough 256-lane workgroups to fill the wave slots a few times over, not one
+// per 256 elements beyond that (AMSM_VEC_BLOCKS_PER_CU overrides the 64 per CU: one element per lane up to 2^22 elements)
+static u32 stream_grid(u32 n) {
+  static const u32 per_cu = [] {
+    const char* e = getenv("AMSM_VEC_BLOCKS_PER_CU");
+    return (u32)std::max(1, e ? atoi(e) : 64);  // round 2, 2^22 elements: 64 -> 0.57-0.79 of 8 TB/s, 8 -> 0.52-0.75
+  }();
+  static const u32 cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256u;
+    return (u32)std::max(1, prop.multiProcessorCount);
+  }();
+  return std::max(1u, std::min(cdiv_(n, 256), cus * per_cu));
+}
 
 void launch_bounds(hipStream_t st, const void* keys_sorted, bool keys16, u32* vals_sorted, MsmGeom g, u32* start,
                    u32* items) {
@@ -150,11 +166,22 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
   }                                                                                                                  \
   template <>                                                                                                        \
   void launch_vec_hadamard<FR>(hipStream_t st, const u32* a, const u32* b, u32* out, u32 n) {                        \
-    hipLaunchKernelGGL((k_vec_hadamard<FR>), dim3(cdiv_(n, 256)), dim3(256), 0, st, a, b, out, n);                   \
+    hipLaunchKernelGGL((k_vec_hadamard<FR>), dim3(stream_grid(n)), dim3(256), 0, st, a, b, out, n);                  \
   }                                                                                                                  \
   template <>                                                                                                        \
   void launch_vec_combine<FR>(hipStream_t st, const CombineArgs& a, u32* out) {                                      \
-    hipLaunchKernelGGL((k_vec_combine<FR>), dim3(cdiv_(a.n, 256)), dim3(256), 0, st, a, out);                        \
+    dim3 grid(stream_grid(a.n)), block(256);                                                                         \
+    switch (a.n_vecs) {                                                                                              \
+      case 0: /* only the hiding addend */                                                                          \
+      case 1: hipLaunchKernelGGL((k_vec_combine<FR, 1>), grid, block, 0, st, a, out); break;                         \
+      case 2: hipLaunchKernelGGL((k_vec_combine<FR, 2>), grid, block, 0, st, a, out); break;                         \
+      case 3: hipLaunchKernelGGL((k_vec_combine<FR, 3>), grid, block, 0, st, a, out); break;                         \
+      case 4: hipLaunchKernelGGL((k_vec_combine<FR, 4>), grid, block, 0, st, a, out); break;                         \
+      case 5: hipLaunchKernelGGL((k_vec_combine<FR, 5>), grid, block, 0, st, a, out); break;                         \
+      case 6: hipLaunchKernelGGL((k_vec_combine<FR, 6>), grid, block, 0, st, a, out); break;                         \
+      case 7: hipLaunchKernelGGL((k_vec_combine<FR, 7>), grid, block, 0, st, a, out); break;                         \
+      default: hipLaunchKernelGGL((k_vec_combine<FR, 8>), grid, block, 0, st, a, out); break;                        \
+    }                                                                                                                \
   }                                                                                                                  \
   template <>                                                                                                        \
   void launch_vec_powers<FR>(hipStream_t st, const u32 point[8], u32 n, u32* out) {                                  \
@@ -194,7 +221,7 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
   }                                                                                                                  \
   template <>                                                                                                        \
   void launch_hp_t_vecs<FR>(hipStream_t st, const TVecArgs& a, int n_inputs) {                                       \
-    dim3 grid(cdiv_(a.len, 256)), block(256);                                                                        \
+    dim3 grid(stream_grid(a.len)), block(256);                                                                       \
     switch (n_inputs) {                                                                                              \
       case 1: hipLaunchKernelGGL((k_hp_t_vecs<FR, 1>), grid, block, 0, st, a); break;                                \
       case 2: hipLaunchKernelGGL((k_hp_t_vecs<FR, 2>), grid, block, 0, st, a); break;                                \

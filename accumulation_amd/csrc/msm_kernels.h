@@ -145,12 +145,25 @@ __global__ void __launch_bounds__(256) AMSM_L0_VGPR_ATTR
           xyzz_store<Fq>(partials, slot, acc);
           acc = xyzz_inf<Fq>();
           if (k + 1 < e) {  // next entry opens the next NON-EMPTY bucket: largest b with start[b] <= k+1
-            u32 lo = b_cur + 1, hi = g.B;
-            while (lo < hi) {
-              u32 mid = (lo + hi + 1) >> 1;
-              if (start[mid] <= k + 1) lo = mid; else hi = mid - 1;
+            // Almost always the very next bucket (an empty bucket needs a digit value nobody drew): probe a few buckets
+            // linearly -- ONE dependent load in the common case -- before falling back to the binary search, whose ~15
+            // dependent loads per flush were most of accumulate L0's time on small MSMs (a wave pays them whenever ANY of
+            // its lanes closes a bucket: every iteration at 34 entries per bucket; rocprofv3 timeline of an IPA round, round 2).
+            u32 b = b_cur + 1;  // start[B] = e_valid > k + 1 ends the probe at the last bucket
+            u32 probes = 0;
+            while (probes < 4u && start[b + 1] <= k + 1) {
+              b++;
+              probes++;
             }
-            b_cur = lo;
+            if (start[b + 1] <= k + 1) {
+              u32 lo = b + 1, hi = g.B;
+              while (lo < hi) {
+                u32 mid = (lo + hi + 1) >> 1;
+                if (start[mid] <= k + 1) lo = mid; else hi = mid - 1;
+              }
+              b = lo;
+            }
+            b_cur = b;
           }
         }
       }

@@ -31,6 +31,7 @@ struct MsmGeom {
   u32 nA;            // chunks of phase A (a multiple of 256: a workgroup never straddles the phases)
   u32 T0;            // entries covered by phase A = nA * K0
   u32 n_chunks;      // work items of accumulate L0 (upper bound: sized for E entries)
+  u32 l0_per_cu;     // host only: resident accumulate-L0 workgroups per CU to enforce for this launch (0 = natural occupancy)
   u32 K1;            // max partials folded by one L1 lane
   u32 red_s;         // buckets per reduce lane
   u32 red_threads;   // reduce lanes per set

@@ -15,73 +15,170 @@
 namespace amsm {
 
 
+// The three streaming kernels below run as a grid-stride loop over a grid sized to the resident wave slots, with the NEXT
+// element's operands loaded before the current element's multiplications (register double buffering): with one element per
+// lane and one launch-sized grid the waves of a CU move in lock step -- all loading, then all multiplying, then all storing --
+// and memory time and multiplier time ADD (round 2: two-vector combination 102 us = 46 us of multiplications + 56 us of
+// memory where the Hadamard kernel, one multiplication per 96 bytes, hid its arithmetic completely).
+// Outputs are written once and read next by another kernel's first pass over 128 MiB: non-temporal stores.
+template <class P>
+AMSM_DEV void fe_store_nt(u32* __restrict__ p, const Fe<P>& a) {
+  typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t* q = reinterpret_cast<u32x4_t*>(p);
+#pragma unroll
+  for (int i = 0; i < P::W / 4; i++) {
+    u32x4_t v = {a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]};
+    __builtin_nontemporal_store(v, q + i);  // global_store_dwordx4 ... nt
+  }
+}
+
 template <class Fr>
 __global__ void __launch_bounds__(256)
     k_vec_hadamard(const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, u32 n) {
+  const u32 stride = gridDim.x * blockDim.x;
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fe<Fr> x = fe_load<Fr>(a + (size_t)i * 8);
-  Fe<Fr> y = fe_load<Fr>(b + (size_t)i * 8);
-  fe_store<Fr>(out + (size_t)i * 8, fe_mul<Fr>(x, y));
+  Fe<Fr> x = fe_load<Fr>(a + (size_t)i * 8), y = fe_load<Fr>(b + (size_t)i * 8);
+  for (;;) {
+    const u32 nx = i + stride;
+    const bool more = nx < n;
+    Fe<Fr> x2 = x, y2 = y;
+    if (more) {
+      x2 = fe_load<Fr>(a + (size_t)nx * 8);
+      y2 = fe_load<Fr>(b + (size_t)nx * 8);
+    }
+    fe_store_nt<Fr>(out + (size_t)i * 8, fe_mul<Fr>(x, y));
+    if (!more) break;
+    x = x2;
+    y = y2;
+    i = nx;
+  }
 }
 
 
+// is the kernel-argument coefficient the field's one (Montgomery form)?  Uniform over the grid: the first challenge of every
+// linear combination of the schemes is 1 (mu_0, nu^0, beta_0: src/hp_as/mod.rs:241,266, src/r1cs_nark_as/mod.rs:444), and
+// skipping its multiplication takes a third off the arithmetic of the common two-vector combination.
 template <class Fr>
+AMSM_DEV bool coeff_is_one(const u32 c[8]) {
+  const Fe<Fr> one = fe_one<Fr>();
+  u32 d = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) d |= c[k] ^ one.v[k];
+  return d == 0;
+}
+
+// NV = number of vectors, compile time: the loads of all operands are issued before the first multiplication (with a
+// run-time vector count the loop serialised load -> multiply -> load: 4.2 TB/s for two vectors where the Hadamard kernel,
+// with the same 96 bytes per element, reached 5.9).
+template <class Fr, int NV>
 __global__ void __launch_bounds__(256) k_vec_combine(CombineArgs a, u32* __restrict__ out) {
+  const u32 stride = gridDim.x * blockDim.x;
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  Fe<Fr> acc = fe_zero<Fr>();
-  if (a.hiding && i < a.hiding_len) acc = fe_load<Fr>(a.hiding + (size_t)i * 8);
-  for (u32 j = 0; j < a.n_vecs; j++) {
-    if (i < a.len[j]) {
-      Fe<Fr> cf;
+  auto load = [&](u32 e, Fe<Fr>* x, Fe<Fr>& h) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) cf.v[k] = a.coeff[j][k];
-      Fe<Fr> x = fe_load<Fr>(a.vec[j] + (size_t)i * 8);
-      acc = fe_add<Fr>(acc, fe_mul<Fr>(cf, x));
+    for (int j = 0; j < NV; j++) x[j] = e < a.len[j] ? fe_load<Fr>(a.vec[j] + (size_t)e * 8) : fe_zero<Fr>();
+    h = (a.hiding && e < a.hiding_len) ? fe_load<Fr>(a.hiding + (size_t)e * 8) : fe_zero<Fr>();
+  };
+  Fe<Fr> x[NV], acc;
+  load(i, x, acc);
+  for (;;) {
+    const u32 nx = i + stride;
+    const bool more = nx < a.n;
+    Fe<Fr> x2[NV], h2;
+    if (more) load(nx, x2, h2);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      if (coeff_is_one<Fr>(a.coeff[j])) {
+        acc = fe_add<Fr>(acc, x[j]);
+      } else {
+        Fe<Fr> cf;
+#pragma unroll
+        for (int k = 0; k < 8; k++) cf.v[k] = a.coeff[j][k];
+        acc = fe_add<Fr>(acc, fe_mul<Fr>(cf, x[j]));
+      }
     }
+    // in-place chunked combination (more than VEC_MAX vectors) re-reads `out` as the hiding addend: plain store there
+    if (a.hiding == out) fe_store<Fr>(out + (size_t)i * 8, acc);
+    else fe_store_nt<Fr>(out + (size_t)i * 8, acc);
+    if (!more) break;
+#pragma unroll
+    for (int j = 0; j < NV; j++) x[j] = x2[j];
+    acc = h2;
+    i = nx;
   }
-  fe_store<Fr>(out + (size_t)i * 8, acc);
 }
 
 
 // N = number of inputs (compile time so the N x N product stays in registers)
 template <class Fr, int N>
 __global__ void __launch_bounds__(256) k_hp_t_vecs(TVecArgs a) {
+  const u32 stride = gridDim.x * blockDim.x;
   u32 li = blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= a.len) return;
-  Fe<Fr> ac[N], bc[N];
+  // raw operands of element e: a_j, b_j and the two hiding vectors (zero where a vector is shorter: `.get(li)`, :306-318)
+  auto load = [&](u32 e, Fe<Fr>* ra, Fe<Fr>* rb, Fe<Fr>& ha, Fe<Fr>& hb) {
 #pragma unroll
-  for (int j = 0; j < N; j++) {
-    Fe<Fr> mu;
-#pragma unroll
-    for (int k = 0; k < 8; k++) mu.v[k] = a.mu[j][k];
-    ac[j] = li < a.a_len[j] ? fe_mul<Fr>(mu, fe_load<Fr>(a.a[j] + (size_t)li * 8)) : fe_zero<Fr>();
-    // b coefficients are reversed: B(X) = sum_j b_{N-1-j} X^j   (src/hp_as/mod.rs:320)
-    bc[N - 1 - j] = li < a.b_len[j] ? fe_load<Fr>(a.b[j] + (size_t)li * 8) : fe_zero<Fr>();
-  }
-  if (a.hiding_a && li < a.hiding_a_len) {  // a_coeffs[0] += hiding_a[li] * mu[N]   (:322-325)
-    Fe<Fr> mu;
-#pragma unroll
-    for (int k = 0; k < 8; k++) mu.v[k] = a.mu[N][k];
-    ac[0] = fe_add<Fr>(ac[0], fe_mul<Fr>(fe_load<Fr>(a.hiding_a + (size_t)li * 8), mu));
-  }
-  if (a.hiding_b && li < a.hiding_b_len) {  // b_coeffs[0] += hiding_b[li] * mu[1]   (:327-329)
-    Fe<Fr> mu;
-#pragma unroll
-    for (int k = 0; k < 8; k++) mu.v[k] = a.mu[1][k];
-    bc[0] = fe_add<Fr>(bc[0], fe_mul<Fr>(fe_load<Fr>(a.hiding_b + (size_t)li * 8), mu));
-  }
-#pragma unroll
-  for (int k = 0; k < 2 * N - 1; k++) {
-    if (a.t[k] == nullptr) continue;  // uniform branch: coefficient N-1 is never committed
-    Fe<Fr> s = fe_zero<Fr>();
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      int j = k - i;
-      if (j >= 0 && j < N) s = fe_add<Fr>(s, fe_mul<Fr>(ac[i], bc[j]));
+    for (int j = 0; j < N; j++) {
+      ra[j] = e < a.a_len[j] ? fe_load<Fr>(a.a[j] + (size_t)e * 8) : fe_zero<Fr>();
+      rb[j] = e < a.b_len[j] ? fe_load<Fr>(a.b[j] + (size_t)e * 8) : fe_zero<Fr>();
     }
-    fe_store<Fr>(a.t[k] + (size_t)li * 8, s);
+    ha = (a.hiding_a && e < a.hiding_a_len) ? fe_load<Fr>(a.hiding_a + (size_t)e * 8) : fe_zero<Fr>();
+    hb = (a.hiding_b && e < a.hiding_b_len) ? fe_load<Fr>(a.hiding_b + (size_t)e * 8) : fe_zero<Fr>();
+  };
+  Fe<Fr> ra[N], rb[N], ha, hb;
+  load(li, ra, rb, ha, hb);
+  for (;;) {
+    const u32 nx = li + stride;
+    const bool more = nx < a.len;
+    Fe<Fr> ra2[N], rb2[N], ha2, hb2;
+    if (more) load(nx, ra2, rb2, ha2, hb2);
+    Fe<Fr> ac[N], bc[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      ac[j] = ra[j];
+      if (!coeff_is_one<Fr>(a.mu[j])) {  // mu_0 = 1 (src/hp_as/mod.rs:241): uniform branch
+        Fe<Fr> mu;
+#pragma unroll
+        for (int k = 0; k < 8; k++) mu.v[k] = a.mu[j][k];
+        ac[j] = fe_mul<Fr>(mu, ac[j]);
+      }
+      // b coefficients are reversed: B(X) = sum_j b_{N-1-j} X^j   (src/hp_as/mod.rs:320)
+      bc[N - 1 - j] = rb[j];
+    }
+    if (a.hiding_a) {  // a_coeffs[0] += hiding_a[li] * mu[N]   (:322-325)
+      Fe<Fr> mu;
+#pragma unroll
+      for (int k = 0; k < 8; k++) mu.v[k] = a.mu[N][k];
+      ac[0] = fe_add<Fr>(ac[0], fe_mul<Fr>(ha, mu));
+    }
+    if (a.hiding_b) {  // b_coeffs[0] += hiding_b[li] * mu[1]   (:327-329)
+      Fe<Fr> mu;
+#pragma unroll
+      for (int k = 0; k < 8; k++) mu.v[k] = a.mu[1][k];
+      bc[0] = fe_add<Fr>(bc[0], fe_mul<Fr>(hb, mu));
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+      if (a.t[k] == nullptr) continue;  // uniform branch: coefficient N-1 is never committed
+      Fe<Fr> s = fe_zero<Fr>();
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        int j = k - i;
+        if (j >= 0 && j < N) s = fe_add<Fr>(s, fe_mul<Fr>(ac[i], bc[j]));
+      }
+      fe_store_nt<Fr>(a.t[k] + (size_t)li * 8, s);
+    }
+    if (!more) break;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      ra[j] = ra2[j];
+      rb[j] = rb2[j];
+    }
+    ha = ha2;
+    hb = hb2;
+    li = nx;
   }
 }
 

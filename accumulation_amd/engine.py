@@ -125,6 +125,77 @@ class Context:
         return v
 
 
+class _ShardContext(Context):
+    """Borrowed single-device context of one shard of a MultiContext (amsm_ctx_shard): allocate / fill vectors ON that
+    device; destroyed with its parent."""
+
+    def __init__(self, parent: "MultiContext", g: int, handle):
+        self._lib = parent._lib
+        self._h = handle
+        self.curve = parent.curve
+        self.device = parent.devices[g]
+        self.fq_limbs = parent.fq_limbs
+        self._pool = {}
+        self._parent = parent
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.empty_cache()
+            self._h = None  # owned by the parent
+
+
+class MultiContext(Context):
+    """ONE process driving several GPUs (amsm_ctx_create_multi): keys created through it are sharded over the devices,
+    the MSM entry points accept them, the partial sums are gathered inside the library (RCCL / peer copies).  The context
+    itself is the primary device's; shard(g) gives the per-device contexts."""
+
+    def __init__(self, curve: int = ffi.AMSM_PALLAS, devices=(0,)):
+        self._lib = ffi.load()
+        self.devices = [int(d) for d in devices]
+        ids = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        ffi.check(self._lib.amsm_ctx_create_multi(C.byref(h), curve, ids, len(self.devices)), "amsm_ctx_create_multi")
+        self._h = h
+        self.curve = curve
+        self.device = self.devices[0]
+        self.fq_limbs = self._lib.amsm_ctx_fq_limbs(h)
+        self._pool = {}
+        self._shards = [self] + [_ShardContext(self, g, C.c_void_p(self._lib.amsm_ctx_shard(h, g)))
+                                 for g in range(1, len(self.devices))]
+
+    @property
+    def num_devices(self) -> int:
+        return len(self.devices)
+
+    @property
+    def collective(self) -> str:
+        return self._lib.amsm_ctx_collective(self._h).decode()
+
+    def shard(self, g: int) -> Context:
+        return self._shards[g]
+
+    def shard_range(self, key: "CommitterKey", g: int):
+        lo, hi = C.c_size_t(), C.c_size_t()
+        ffi.check(self._lib.amsm_bases_shard_range(key._h, g, C.byref(lo), C.byref(hi)), "amsm_bases_shard_range")
+        return lo.value, hi.value
+
+    def msm_batch_sharded(self, key: "CommitterKey", slices, mont: bool):
+        """slices[v][g]: FrVector on device g holding shard g's part of vector v -> (points (k, 2L), infinity flags)."""
+        k, N = len(slices), self.num_devices
+        ptrs = (C.c_void_p * (k * N))(*[slices[v][g].ptr for v in range(k) for g in range(N)])
+        out = np.zeros((k, 2 * self.fq_limbs), dtype=np.uint64)
+        inf = np.zeros(k, dtype=np.uint8)
+        ffi.check(self._lib.amsm_msm_batch_sharded_device(self._h, key._h, ptrs, k, 1 if mont else 0, _ptr(out), _ptr(inf)),
+                  "amsm_msm_batch_sharded_device")
+        return out, inf
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for s in self._shards[1:]:
+                s.close()
+            super().close()
+
+
 class FrVector:
     """n scalar-field elements (32 B each) in device memory."""
 

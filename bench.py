@@ -17,8 +17,17 @@ Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/un
   "cpu_baseline": the plain-C ark-ec-style restatement (oracle/ark_msm.c, kind "port") timed on this
                   box's host cores on the same inputs (rank 0, N = 1 only), and used to check the GPU
                   result bit-for-bit;
-  "accumulations": accumulations/sec (the metric's second half) of hp_as at 2^22, r1cs_nark_as at 2^18 constraints and
-                  ipa_pc_as at d + 1 = 2^16, measured after and outside the timed region (N = 1 only; --no-schemes skips).
+  "accumulations": accumulations/sec (the metric's second half) of trivial_pc_as at 2^10, ipa_pc_as at d + 1 = 2^16,
+                  r1cs_nark_as at 2^18 constraints and hp_as at 2^22 through the C++ scheme drivers (tools/profile_as.cpp =
+                  the reference's harness examples/scaling-as.rs:38-138): the harness's own shape (1 input + the same
+                  accumulator twice, MakeZK::Enabled) and the lighter n_all = 2 no-zk shape, each verified, decided and
+                  serialised; measured after and outside the timed region (N = 1 only; --no-schemes skips).
+
+    python bench.py --gpus N --single-process [--devices 0,1,...]
+runs the N-GPU job from ONE process through the multi-device context of the C ABI (amsm_ctx_create_multi: key sharded over
+the devices, scalars resident per shard, partial sums gathered inside the library over RCCL / peer copies) -- the form a
+single-process host (the reference's `prove` is one call in one process) would use; the torchrun form above stays the
+driver's contract.
 """
 from __future__ import annotations
 
@@ -53,7 +62,13 @@ def main() -> int:
     ap.add_argument("--one-gpu", action="store_true")
     ap.add_argument("--sync", action="store_true", help="one synchronous MSM call per step (no MSMs overlapped)")
     ap.add_argument("--cpu-log2n", type=int, default=None, help="sample size of the CPU baseline (default: log2n)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive all --gpus devices from this process through amsm_ctx_create_multi (no torchrun)")
+    ap.add_argument("--devices", default=None, help="--single-process: comma-separated device ids (default 0..gpus-1; an id "
+                                                    "may repeat: several shards on one GPU, numbers meaningless)")
     args = ap.parse_args()
+    if args.single_process:
+        return main_single_process(args)
 
     import torch
     import torch.distributed as dist
@@ -112,6 +127,7 @@ def main() -> int:
                 pts, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [vecs[i % n_distinct] for i in range(k)],
                                                                    mont=False)
                 last["xy"], last["inf"] = pts[0], bool(infs[0])
+                last["all"] = (np.array(pts), np.array(infs))
             else:
                 outs, infs = sharded.msm_batch([vecs[i % n_distinct] for i in range(k)], mont=False)
                 last["xy"], last["inf"] = outs[0], bool(infs[0])
@@ -142,6 +158,13 @@ def main() -> int:
         ms_sync = (time.perf_counter() - t1) / 5 * 1e3
         stage_ms_alone = ctx.stage_ms()  # stages of the last blocking call: nothing else on the GPU
         ctx.set_profiling(False)
+        # the PCIe-inclusive form (`amsm_msm`: the scalars start in pageable host memory like a Rust `&[BigInt]`); never `value`
+        h_scalars = scalars.download()
+        ffi.check(ctx._lib.amsm_msm(ctx._h, ck._h, 0, _ptr(h_scalars), n, 0, _ptr(out), C.byref(inf)), "amsm_msm")
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ffi.check(ctx._lib.amsm_msm(ctx._h, ck._h, 0, _ptr(h_scalars), n, 0, _ptr(out), C.byref(inf)), "amsm_msm")
+        ms_host = (time.perf_counter() - t1) / 5 * 1e3
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -179,6 +202,8 @@ def main() -> int:
                 "parallelism": f"point-sharded x{world}" + (" + one RCCL all-gather of the steps' partial records" if world > 1 else ""),
                 "key_setup_s": round(t_key, 3),
                 "ms_per_msm_synchronous_call": round(ms_sync, 4),
+                "ms_per_msm_host_scalars": round(ms_host, 4),
+                "pairs_per_s_host_scalars": round(n / (ms_host * 1e-3), 1),
                 "msms_in_flight": 1 if args.sync else 3,
                 "seeds": {"scalars": SEED_SCALARS, "points": SEED_POINTS},
             },
@@ -189,7 +214,8 @@ def main() -> int:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args),
+                "traffic": pmc_traffic(args)[0],
+                "traffic_source": pmc_traffic(args)[1],
                 "kernel_ms": dom_ms,
                 "algorithmic_bytes_per_launch": n * bytes_per_pair,
                 # the kernel is integer-VALU bound, not HBM bound: the ceiling that binds is
@@ -199,11 +225,14 @@ def main() -> int:
                 "kernel_ms_unshared": stage_ms_alone.get(dom, 0.0),
                 "alu_unshared": alu_roofline(args, ck, n, stage_ms_alone.get(dom, 0.0)),
             },
-            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            # elapsed device time per pipeline stage (hipEvent pairs on the stage's stream): inside the timed batch, where
+            # the prep chain of MSM k+1 and the tail of MSM k-1 share the GPU with accumulate L0 of MSM k (so the prep chain
+            # STRETCHES to about one L0: it is not queue wait), and for one blocking call with the GPU to itself
+            "stage_ms": {"in_batch": {k: round(v, 4) for k, v in stage_ms.items()},
+                         "blocking_call": {k: round(v, 4) for k, v in stage_ms_alone.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(ctx, ck, scalars, curve_id, args, out.copy(), bool(inf.value),
-                                                  last["xy"], last["inf"])
+            result["cpu_baseline"] = cpu_baseline(ctx, ck, vecs, curve_id, args, out.copy(), bool(inf.value), last.get("all"))
         if world == 1 and not args.no_schemes and args.log2n == 20 and args.curve == "pallas":
             result["accumulations"] = scheme_rates()
         print(json.dumps(result), flush=True)
@@ -214,29 +243,97 @@ def main() -> int:
 
 
 def scheme_rates():
-    """accumulations/sec (one `prove` = one accumulation; BASELINE.json's second metric) of the three schemes at the
-    sizes of configs 1, 3 and 4, after the timed region and outside it: tools/bench_configs.py's workloads (1 input + 1 old
-    accumulator, no zk), each verified and decided.  Never fails the bench line: an error is reported in place."""
-    import importlib.util
-    out = {}
+    """accumulations/sec (one `prove` = one accumulation; BASELINE.json's second metric) through the C++ scheme drivers:
+    tools/profile_as.cpp, the reference's harness (examples/scaling-as.rs:38-138), at the sizes of BASELINE.json's configs --
+    the harness's shape (1 input + the same accumulator twice, zk) and the n_all = 2 no-zk shape -- after the timed region
+    and outside it.  Never fails the bench line: an error is reported in place."""
+    import subprocess
+    out = {"driver": "C++ (include/amsm_*.hpp) via tools/profile_as.cpp; sponge: SHA-256 stand-in (Poseidon: --sponge poseidon)"}
     try:
-        spec = importlib.util.spec_from_file_location("amsm_bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
-        bc = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(bc)
-        got = []
-        bc.emit = lambda **kw: got.append(kw)
-        for name, fn in (("hp_as_2^22", lambda: bc.bench_hp_as(22)), ("r1cs_nark_as_2^18", lambda: bc.bench_r1cs_nark_as(18)),
-                         ("ipa_pc_as_2^16", lambda: bc.bench_ipa(16))):
+        exe = os.path.join(ROOT, "build", "profile_as")
+        src = os.path.join(ROOT, "tools", "profile_as.cpp")
+        libdir = os.path.join(ROOT, "accumulation_amd")
+        lib = os.path.join(libdir, "libamsm.so")
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", libdir,
+                                   "-l:libamsm.so", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+        for scheme, lg, extra in (("trivial_pc_as", 10, ["--reps", "5"]), ("ipa_pc_as", 16, ["--reps", "3"]),
+                                  ("r1cs_nark_as", 18, ["--reps", "3"]), ("hp_as", 22, ["--reps", "3", "--no-roundtrip"])):
             try:
-                fn()
-                r = got[-1]
-                out[name] = {"accumulations_per_s": round(r["accumulations_per_s"], 2), "prove_ms": round(r["prove_ms"], 3),
-                             "decide_ms": round(r["decide_ms"], 3), "verified": bool(r["verify_ok"] and r["decide_ok"])}
+                p = subprocess.run([exe, scheme, str(lg), str(lg), *extra], capture_output=True, text=True, timeout=600)
+                if p.returncode != 0:
+                    raise RuntimeError(p.stderr[-300:])
+                for line in p.stdout.splitlines():
+                    if not line.startswith("JSON "):
+                        continue
+                    r = json.loads(line[5:])
+                    shape = "harness_1in_2acc_zk" if r["shape"].startswith("harness") else "n2_1in_1acc_nozk"
+                    out[f"{scheme}_2^{lg}_{shape}"] = {
+                        "accumulations_per_s": round(r["accumulations_per_s"], 2), "prove_ms": round(r["prove_ms"], 3),
+                        "verify_ms": round(r["verify_ms"], 3), "decide_ms": round(r["decide_ms"], 3),
+                        "index_ms": round(r["index_ms"], 1), "zk": r["zk"],
+                        "accumulator_bytes": r["accumulator_bytes"],
+                        "verified": bool(r["verified"] and r["decided"] and r["serialize_roundtrip_decides"])}
             except Exception as e:  # noqa: BLE001
-                out[name] = {"error": f"{type(e).__name__}: {e}"}
+                out[f"{scheme}_2^{lg}"] = {"error": f"{type(e).__name__}: {e}"}
     except Exception as e:  # noqa: BLE001
         out["error"] = f"{type(e).__name__}: {e}"
     return out
+
+
+def main_single_process(args) -> int:
+    """--gpus N --single-process: ONE process, N devices, through amsm_ctx_create_multi.  Weak scaling like the torchrun
+    form: 2^log2n pairs per device, the job is one N * 2^log2n-pair MSM per step; every shard's scalars are resident on its
+    device; per step the devices' 128-byte partial sums are gathered inside the library."""
+    import torch  # noqa: F401  (same HIP runtime initialisation as the torchrun form)
+
+    from accumulation_amd import CommitterKey, MultiContext, ffi
+
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    N = len(devices)
+    curve_id = ffi.AMSM_PALLAS if args.curve == "pallas" else ffi.AMSM_BLS12_381_G1
+    n = 1 << args.log2n
+    ctx = MultiContext(curve_id, devices)
+    flags = ffi.AMSM_BASES_NO_PRECOMPUTE if args.no_precompute else ffi.AMSM_BASES_PRECOMPUTE
+    t0 = time.time()
+    ck = CommitterKey.generate(ctx, SEED_POINTS, n * N, flags)
+    t_key = time.time() - t0
+    n_distinct = 4
+    # vector j, shard g: its own slice of the seed's stream would need an offset; independent streams per (j, g) do as well
+    slices = [[ctx.shard(g).random_vector(SEED_SCALARS + 1000 * j + g, ctx.shard_range(ck, g)[1] - ctx.shard_range(ck, g)[0],
+                                          mont=False) for g in range(N)] for j in range(n_distinct)]
+    ctx.synchronize()
+
+    def run_steps(k):
+        return ctx.msm_batch_sharded(ck, [slices[i % n_distinct] for i in range(k)], mont=False)
+
+    run_steps(args.warmup)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    pts, infs = run_steps(args.steps)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    result = {
+        "metric": "MSM throughput (point-scalar pairs/sec) at 2^20 Pallas", "value": n * N * args.steps / elapsed,
+        "unit": "pairs/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"one {N} x 2^{args.log2n}-pair {args.curve} MSM per step, key sharded over {N} devices of ONE "
+                               f"process (amsm_ctx_create_multi), scalars resident per shard",
+                   "pairs_per_gpu": n, "curve": args.curve, "devices": devices, "collective": ctx.collective,
+                   "parallelism": f"point-sharded x{N}, single process, one host thread per device",
+                   "key_setup_s": round(t_key, 3), "seeds": {"scalars": SEED_SCALARS, "points": SEED_POINTS}},
+    }
+    if not args.no_cpu_baseline and n * N <= (1 << 21):  # bit-exact check of the first step against the CPU restatement
+        from oracle import cref
+        xy, _ = ck.read(0, n * N)
+        sc = np.concatenate([slices[0][g].download() for g in range(N)])
+        ref, ref_inf = cref.msm(curve_id, xy, sc, threads=min(os.cpu_count() or 1, 16))
+        result["cpu_baseline"] = {"gpu_result_bit_exact_vs_cpu": bool(np.array_equal(ref, pts[0]) and bool(ref_inf) == bool(infs[0])),
+                                  "kind": "port", "sample": "step 0 of the timed batch, not timed"}
+    print(json.dumps(result), flush=True)
+    ctx.close()
+    return 0
 
 
 ALU_PEAK_GMADD = {"pallas": 18.7, "bls12_381_g1": 6.95}  # isolated xyzz_madd, all SIMDs busy (tools/fp_bench.hip)
@@ -257,29 +354,32 @@ def alu_roofline(args, ck, n, kernel_ms):
 
 
 def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    """(HBM bytes per launch, provenance) of the dominant kernel from the committed rocprofv3 PMC passes
     (tools/profile_round.sh -> profiles/*_pmc_accum_l0.json; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for 16-B-per-lane loads).  Only valid for the default workload; null otherwise."""
     if args.log2n != 20 or args.curve != "pallas" or args.no_precompute:
-        return None
+        return None, None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_accum_l0.json")))
     if not files:
-        return None
+        return None, None
     try:
-        return json.load(open(files[-1]))["hbm_traffic_bytes_per_launch"]
+        return json.load(open(files[-1]))["hbm_traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT) + \
+            " (committed rocprofv3 --pmc passes of this workload; not re-measured in this run)"
     except Exception:
-        return None
+        return None, None
 
 
-def cpu_baseline(ctx, ck, scalars, curve_id, args, gpu_out, gpu_inf, batch_out, batch_inf):
-    """Time the plain-C ark-ec-style restatement on the host cores, on the same inputs, and check the
-    GPU result against it bit-for-bit.  (Only this leg of bench.py touches oracle/.)"""
+def cpu_baseline(ctx, ck, vecs, curve_id, args, gpu_out, gpu_inf, batch):
+    """Time the plain-C ark-ec-style restatement on the host cores, on the same inputs, and check the GPU results against
+    it bit-for-bit: the blocking call, the host-scalar call and EVERY MSM of the timed batch (step k used vector k % 4: four
+    CPU MSMs cover them all).  (Only this leg of bench.py touches oracle/.)"""
     from oracle import cref
 
     cpu_log2n = args.cpu_log2n if args.cpu_log2n is not None else args.log2n
     m = min(1 << cpu_log2n, len(ck))
     xy, _ = ck.read(0, m)
+    scalars = vecs[0]
     sc = scalars.download()[:m]
     cores = os.cpu_count() or 1
     n_windows = -(-255 // cref.load().ark_msm_window_bits(m))
@@ -293,9 +393,16 @@ def cpu_baseline(ctx, ck, scalars, curve_id, args, gpu_out, gpu_inf, batch_out, 
     cref.msm(curve_id, xy[:ms], sc[:ms], threads=1)
     t_one = time.perf_counter() - t0
     match = None
+    checked = 0
     if m == len(ck):
-        match = bool(np.array_equal(cpu_out, gpu_out) and cpu_inf == gpu_inf
-                     and np.array_equal(cpu_out, batch_out) and cpu_inf == batch_inf)
+        match = bool(np.array_equal(cpu_out, gpu_out) and cpu_inf == gpu_inf)
+        if batch is not None:
+            refs = [(cpu_out, cpu_inf)] + [cref.msm(curve_id, xy, v.download()[:m], threads=threads) for v in vecs[1:]]
+            pts, infs = batch
+            for k in range(len(pts)):
+                r_out, r_inf = refs[k % len(vecs)]
+                match = match and bool(np.array_equal(pts[k], r_out) and bool(infs[k]) == bool(r_inf))
+                checked += 1
     return {
         "value": m / t_par,
         "unit": "pairs/s",
@@ -306,6 +413,7 @@ def cpu_baseline(ctx, ck, scalars, curve_id, args, gpu_out, gpu_inf, batch_out, 
         "single_thread_value": ms / t_one,
         "single_thread_sample": f"one 2^{ms.bit_length() - 1}-pair MSM, 1 thread (reference default features); {t_one:.2f} s",
         "gpu_result_bit_exact_vs_cpu": match,
+        "timed_batch_msms_checked": checked,
     }
 
 

@@ -60,7 +60,9 @@ enum amsm_status {
 /* flags for amsm_bases_load / amsm_bases_generate */
 enum amsm_bases_flags {
   AMSM_BASES_DEFAULT = 0,      /* library picks (precompute when the key is large enough to benefit) */
-  AMSM_BASES_PRECOMPUTE = 1,   /* keep 2^(c*w)*G_i for every window w resident in HBM (W x memory) */
+  AMSM_BASES_PRECOMPUTE = 1,   /* keep 2^(c*w)*G_i for every window w resident in HBM (W x memory); creation fails with
+                                  AMSM_E_OOM / AMSM_E_UNSUPPORTED (n * W >= 2^30) when the table cannot be built --
+                                  only AMSM_BASES_DEFAULT falls back to a plain key (amsm_bases_precomputed() tells) */
   AMSM_BASES_NO_PRECOMPUTE = 2 /* one copy of the key; windows are combined on the host */
 };
 

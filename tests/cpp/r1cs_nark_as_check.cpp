@@ -5,11 +5,20 @@
 #include <cstdio>
 
 #include "amsm_r1cs_nark_as.hpp"
+#include "amsm_poseidon.hpp"
+
+// -DAMSM_TEST_POSEIDON: the same template runs with the reference's sponge (ark-sponge Poseidon, include/amsm_poseidon.hpp)
+// as the Sponge argument instead of the SHA-256 stand-in
+#ifdef AMSM_TEST_POSEIDON
+using TestSponge = amsm::poseidon::PoseidonSponge;
+#else
+using TestSponge = amsm::hp_as::Sha256Sponge;
+#endif
 
 using namespace amsm;
 using namespace amsm::r1cs_nark_as;
-using AS = ASForR1CSNark<hp_as::Sha256Sponge>;
-using Nark = r1cs_nark::R1CSNark<hp_as::Sha256Sponge>;
+using AS = ASForR1CSNark<TestSponge>;
+using Nark = r1cs_nark::R1CSNark<TestSponge>;
 
 static const size_t NUM_INPUTS = 5, NUM_CONSTRAINTS = 10;
 
@@ -43,7 +52,7 @@ static std::vector<Input> generate_inputs(Context& ctx, const r1cs_nark::IndexPr
     std::vector<Fr> inst{one, ab};
     for (size_t k = 1; k < NUM_INPUTS; k++) inst.push_back(a);
     auto wit = std::make_shared<FrVector>(ctx, std::vector<Fr>{am, bm});
-    auto sp = AS::sponges(hp_as::Sha256Sponge());
+    auto sp = AS::sponges(TestSponge());
     r1cs_nark::Proof proof = Nark::prove(ipk, inst, wit, prng, sp.nark);
     out.push_back(Input{InputInstance{inst, proof.first_msg}, proof.second_msg});
   }

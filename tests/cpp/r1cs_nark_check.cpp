@@ -4,10 +4,19 @@
 #include <cstdio>
 
 #include "amsm_r1cs_nark.hpp"
+#include "amsm_poseidon.hpp"
+
+// -DAMSM_TEST_POSEIDON: the same template runs with the reference's sponge (ark-sponge Poseidon, include/amsm_poseidon.hpp)
+// as the Sponge argument instead of the SHA-256 stand-in
+#ifdef AMSM_TEST_POSEIDON
+using TestSponge = amsm::poseidon::PoseidonSponge;
+#else
+using TestSponge = amsm::hp_as::Sha256Sponge;
+#endif
 
 using namespace amsm;
 using namespace amsm::r1cs_nark;
-using Nark = R1CSNark<hp_as::Sha256Sponge>;
+using Nark = R1CSNark<TestSponge>;
 
 struct SchemeRng {  // tests/test_hp_as_scheme_gpu.py:SchemeRng
   uint64_t seed, i = 0;

@@ -4,10 +4,19 @@
 #include <cstdio>
 
 #include "amsm_trivial_pc_as.hpp"
+#include "amsm_poseidon.hpp"
+
+// -DAMSM_TEST_POSEIDON: the same template runs with the reference's sponge (ark-sponge Poseidon, include/amsm_poseidon.hpp)
+// as the Sponge argument instead of the SHA-256 stand-in
+#ifdef AMSM_TEST_POSEIDON
+using TestSponge = amsm::poseidon::PoseidonSponge;
+#else
+using TestSponge = amsm::hp_as::Sha256Sponge;
+#endif
 
 using namespace amsm;
 using namespace amsm::trivial_pc_as;
-using AS = ASForTrivialPC<Sha256Sponge>;
+using AS = ASForTrivialPC<TestSponge>;
 
 static const size_t DEGREE = 11;
 

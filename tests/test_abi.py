@@ -42,7 +42,7 @@ def test_strerror_and_stage_names(built_lib):
     assert b"no CPU fallback" in built_lib.amsm_strerror(ffi.AMSM_E_NO_DEVICE)
     n = built_lib.amsm_stage_count()
     names = [built_lib.amsm_stage_name(i).decode() for i in range(n)]
-    assert "accum_l0" in names and "sort" in names
+    assert "accum_l0" in names and "prep_chain" in names
 
 
 def test_no_gpu_fails_loudly(built_lib, have_gpu):

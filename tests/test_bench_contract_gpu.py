@@ -32,8 +32,25 @@ def test_default_line_n1(built_lib):
     assert d["metric"].startswith("MSM throughput") and d["unit"] == "pairs/s" and d["value"] > 1e8
     assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(d["roofline"])
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_result_bit_exact_vs_cpu"] is True
-    assert all(v.get("verified") for v in d["accumulations"].values()), d["accumulations"]
-    assert "workload" in d["config"]
+    assert d["cpu_baseline"]["timed_batch_msms_checked"] == 12  # every MSM of the timed batch against the CPU result
+    acc = {k: v for k, v in d["accumulations"].items() if isinstance(v, dict)}
+    assert len(acc) == 8 and all(v.get("verified") for v in acc.values()), d["accumulations"]  # 4 schemes x 2 shapes
+    assert any(k.endswith("harness_1in_2acc_zk") for k in acc)
+    assert "workload" in d["config"] and d["config"]["ms_per_msm_host_scalars"] > d["config"]["ms_per_msm_synchronous_call"] * 0.9
+    assert d["roofline"]["traffic_source"] and set(d["stage_ms"]) == {"in_batch", "blocking_call"}
+    assert "prep_chain" in d["stage_ms"]["in_batch"]
+
+
+def test_single_process_two_shards_on_one_gpu(built_lib):
+    """--single-process: the N-device job from one process through amsm_ctx_create_multi (both shards on GPU 0 here)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--devices", "0,0",
+                        "--log2n", "16", "--steps", "4", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in KEYS[:-1]:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["config"]["collective"] == "peer-copy" and d["value"] > 1e6
+    assert d["cpu_baseline"]["gpu_result_bit_exact_vs_cpu"] is True
 
 
 def test_two_rank_branch_on_one_gpu(built_lib):

@@ -107,6 +107,12 @@ class TestASForHP:
         assert run_template(env, [0], make_zk, num_iterations=1)
 
 
+@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
+def test_simple_accumulation_reference_iteration_count(env, make_zk):
+    """the reference runs every scenario NUM_ITERATIONS = 50 times (src/lib.rs:273); one scenario at that count"""
+    assert run_template(env, [1, 1], make_zk, num_iterations=50)
+
+
 def test_error_behaviour(env):
     """prove() error variants of src/hp_as/mod.rs:110-157, 664-673."""
     from accumulation_amd.hp_as import (ASForHadamardProducts as AS, Accumulator, InputInstance, InputWitness,

@@ -277,6 +277,12 @@ class TestASForIpaPC:
         assert run_template(env, [0], make_zk, num_iterations=1)
 
 
+@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
+def test_simple_accumulation_reference_iteration_count(env, make_zk):
+    """the reference runs every scenario NUM_ITERATIONS = 50 times (src/lib.rs:273); one scenario at that count"""
+    assert run_template(env, [1, 1], make_zk, num_iterations=50)
+
+
 def test_sponge_argument_is_refused(env):
     from accumulation_amd.ipa_pc_as import AtomicASForInnerProductArgPC as AS
     from accumulation_amd.sponge import Sha256Sponge

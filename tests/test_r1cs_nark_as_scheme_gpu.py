@@ -86,6 +86,12 @@ class TestASForR1CSNark:
         assert run_template(env, [0], make_zk, num_iterations=1)
 
 
+@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
+def test_simple_accumulation_reference_iteration_count(env, make_zk):
+    """the reference runs every scenario NUM_ITERATIONS = 50 times (src/lib.rs:273); one scenario at that count"""
+    assert run_template(env, [1, 1], make_zk, num_iterations=50)
+
+
 def test_tampered_accumulator_rejected(env):
     from accumulation_amd.r1cs_nark_as import ASForR1CSNark as AS, Accumulator, AccumulatorInstance
     ctx, ipk, r = env

@@ -81,6 +81,11 @@ class TestASForTrivialPC:
         assert run_template(env, [0], num_iterations=1)
 
 
+def test_simple_accumulation_reference_iteration_count(env):
+    """the reference runs every scenario NUM_ITERATIONS = 50 times (src/lib.rs:273); one scenario at that count"""
+    assert run_template(env, [1, 1], num_iterations=50)
+
+
 def test_pieces_vs_oracle(env):
     from accumulation_amd.scalar_field import Fr
     from accumulation_amd.trivial_pc_as import ASForTrivialPC as AS, LabeledPolynomial, TrivialPC, _poly_div_linear

@@ -53,6 +53,27 @@ def test_combine_vectors_ragged_and_hiding(ctxs, cref, c):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("k", [1, 2, 5, 8, 9, 13, 17])
+def test_combine_vectors_any_count_and_unit_coefficients(ctxs, cref, c, k):
+    """the reference has no limit on the number of addends (src/hp_as/mod.rs:492-512): more than the 8 of one launch are
+    combined in groups; coefficients equal to one (mu_0, beta_0, nu^0) take the no-multiplication branch"""
+    from accumulation_amd.hp_as import combine_vectors
+    ctx = ctxs[c.name]
+    lens = [300 - 7 * j for j in range(k)]
+    vecs = [cref.fr_to_mont(c.curve_id, cref.rng_scalars(50 + j, ln)) for j, ln in enumerate(lens)]
+    ch = cref.fr_to_mont(c.curve_id, cref.rng_scalars(70, k))
+    one = cref.fr_to_mont(c.curve_id, h.scalars_to_np([1]))[0]
+    ch[0] = one
+    if k > 9:
+        ch[9] = one
+    hid = cref.fr_to_mont(c.curve_id, cref.rng_scalars(71, 310))
+    dv = [ctx.upload(v) for v in vecs]
+    assert np.array_equal(combine_vectors(ctx, dv, ch).download(), cref.fr_combine(c.curve_id, vecs, ch))
+    assert np.array_equal(combine_vectors(ctx, dv, ch, ctx.upload(hid)).download(),
+                          cref.fr_combine(c.curve_id, vecs, ch, hiding=hid))
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("n_in", [1, 2, 3, 4])
 @pytest.mark.parametrize("zk", [False, True])
 def test_compute_t_vecs(ctxs, c, n_in, zk):

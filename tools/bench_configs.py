@@ -167,10 +167,20 @@ def bench_vec(log2n):
     t = timed(ctx, lambda: compute_hp(ctx, a[0], b[0]))
     emit(kind="vec", op="compute_hp", log2n=log2n, ms=t * 1e3, GBps=96 * n / t / 1e9, frac_hbm=96 * n / t / 1e9 / HBM)
     t = timed(ctx, lambda: combine_vectors(ctx, a, ch))
-    emit(kind="vec", op="combine_vectors(n=2)", log2n=log2n, ms=t * 1e3, GBps=96 * n / t / 1e9, frac_hbm=96 * n / t / 1e9 / HBM)
+    emit(kind="vec", op="combine_vectors(n=2)", log2n=log2n, ms=t * 1e3, GBps=96 * n / t / 1e9, frac_hbm=96 * n / t / 1e9 / HBM,
+         multiplications_per_element=2)
     t = timed(ctx, lambda: compute_t_vecs(ctx, a, b, ch, n, None, skip_uncommitted=True))
     emit(kind="vec", op="compute_t_vecs(n=2, 4 in / 2 out)", log2n=log2n, ms=t * 1e3, GBps=192 * n / t / 1e9,
-         frac_hbm=192 * n / t / 1e9 / HBM)
+         frac_hbm=192 * n / t / 1e9 / HBM, multiplications_per_element=4)
+    # the coefficients the PROVER passes: the first challenge of every combination is 1 (mu_0, nu^0, beta_0:
+    # src/hp_as/mod.rs:241,266, src/r1cs_nark_as/mod.rs:444), and the kernels skip that multiplication
+    ch1 = fr.to_limbs_many([1, 5])
+    t = timed(ctx, lambda: combine_vectors(ctx, a, ch1))
+    emit(kind="vec", op="combine_vectors(n=2, coefficients 1, x as in prove)", log2n=log2n, ms=t * 1e3, GBps=96 * n / t / 1e9,
+         frac_hbm=96 * n / t / 1e9 / HBM, multiplications_per_element=1)
+    t = timed(ctx, lambda: compute_t_vecs(ctx, a, b, ch1, n, None, skip_uncommitted=True))
+    emit(kind="vec", op="compute_t_vecs(n=2, mu = 1, x as in prove)", log2n=log2n, ms=t * 1e3, GBps=192 * n / t / 1e9,
+         frac_hbm=192 * n / t / 1e9 / HBM, multiplications_per_element=3)
     ctx.close()
 
 
