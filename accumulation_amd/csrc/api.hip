@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <unordered_map>
 #include <rocprim/rocprim.hpp>
 #include <vector>
 
@@ -154,6 +155,15 @@ struct amsm_ctx {
   void** rccl_comms = nullptr;   // ncclComm_t per shard
   DevBuf rec_send, rec_recv, stage;  // per device: this shard's partial records / the gathered ones / scalar slices
   hipEvent_t multi_fork = nullptr;
+  // ---- caching allocator behind amsm_dev_alloc / amsm_dev_free ----
+  // hipMalloc / hipFree synchronise the device: a scheme driver that allocates its vectors per call (every `Vec<F>` the
+  // reference builds) would serialise the GPU on each one.  Freed buffers go to size-keyed free lists and are handed out
+  // again; reuse is safe in stream order because every kernel that touches them runs on this context's streams and the MSM
+  // calls that read them from the prep stream are blocking.  amsm_ctx_trim releases everything.
+  std::unordered_map<size_t, std::vector<void*>> pool;    // rounded size -> free buffers
+  std::unordered_map<void*, size_t> pool_size;            // every live or pooled buffer -> its rounded size
+  size_t pool_free_bytes = 0, pool_live_bytes = 0;
+  size_t pool_cap_bytes = (size_t)16 << 30;               // free-list budget (AMSM_POOL_MAX_MB); beyond it frees are real
 };
 
 struct amsm_bases {
@@ -1517,6 +1527,7 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   if (const char* e = getenv("AMSM_PREP")) c->custom_prep = strcmp(e, "rocprim") != 0;
   if (const char* e = getenv("AMSM_K0")) c->K0 = std::max(0, atoi(e));
   if (const char* e = getenv("AMSM_K0_MAX")) c->K0_max = std::max(4, atoi(e));
+  if (const char* e = getenv("AMSM_POOL_MAX_MB")) c->pool_cap_bytes = (size_t)std::max(0, atoi(e)) << 20;
   if (const char* e = getenv("AMSM_L0_SPREAD")) c->small_spread = atoi(e) != 0;
   if (const char* e = getenv("AMSM_K0_2PHASE")) c->two_phase = atoi(e) != 0;
   if (const char* e = getenv("AMSM_TAIL_QUAD")) c->tail_quad = atoi(e) != 0;
@@ -1527,6 +1538,7 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   return AMSM_OK;
 }
 
+static void pool_release_all(amsm_ctx* c);
 void amsm_ctx_destroy(amsm_ctx* c) {
   if (!c) return;
   if (c->parent) return;  // a shard context is borrowed: it goes with its parent
@@ -1570,6 +1582,7 @@ void amsm_ctx_destroy(amsm_ctx* c) {
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   if (c->scalars.p) (void)hipFree(c->scalars.p);
   if (c->xyzz_scratch.p) (void)hipFree(c->xyzz_scratch.p);
+  pool_release_all(c);
   for (DevBuf* b : {&c->rec_send, &c->rec_recv, &c->stage})
     if (b->p) (void)hipFree(b->p);
   if (c->multi_fork) (void)hipEventDestroy(c->multi_fork);
@@ -1690,7 +1703,9 @@ int amsm_bases_load(amsm_ctx* c, const uint64_t* xy, const uint8_t* is_inf, size
   if (n_shards(c) > 1) {  // shard g copies its own range of the caller's arrays
     const size_t L2 = 2 * (size_t)amsm_ctx_fq_limbs(c);
     return bases_create_sharded(c, n, out, [&](size_t, amsm_ctx* cg, size_t lo, size_t cnt, amsm_bases** o) {
-      return amsm_bases_load(cg, xy + lo * L2, is_inf ? is_inf + lo : nullptr, cnt, flags, o);
+      // the impl, not the entry point: shard 0's context IS this (multi-device) context
+      return DISPATCH(cg, (bases_load_impl<PallasFq, PallasFr>(cg, xy + lo * L2, is_inf ? is_inf + lo : nullptr, cnt, flags, o)),
+                      (bases_load_impl<Bls12381Fq, Bls12381Fr>(cg, xy + lo * L2, is_inf ? is_inf + lo : nullptr, cnt, flags, o)));
     });
   }
   return DISPATCH(c, (bases_load_impl<PallasFq, PallasFr>(c, xy, is_inf, n, flags, out)),
@@ -2162,20 +2177,104 @@ int amsm_vec_fill(amsm_ctx* c, const uint64_t* value_mont, size_t n, void* d_out
   return AMSM_OK;
 }
 
+static size_t pool_round(size_t bytes) {  // 256-byte granules up to 1 MiB, 64-KiB granules above
+  bytes = std::max<size_t>(bytes, 16);
+  const size_t g = bytes <= ((size_t)1 << 20) ? 256 : 65536;
+  return (bytes + g - 1) / g * g;
+}
+static void pool_release_all(amsm_ctx* c) {
+  for (auto& kv : c->pool)
+    for (void* p : kv.second) {
+      (void)hipFree(p);
+      c->pool_size.erase(p);
+    }
+  c->pool.clear();
+  c->pool_free_bytes = 0;
+}
 int amsm_dev_alloc(amsm_ctx* c, size_t bytes, void** d_ptr) {
   if (!c || !d_ptr) return AMSM_E_INVALID_ARG;
   TRY(bind_device(c));
-  hipError_t e = hipMalloc(d_ptr, std::max<size_t>(bytes, 16));
+  const size_t sz = pool_round(bytes);
+  auto it = c->pool.find(sz);
+  if (it != c->pool.end() && !it->second.empty()) {
+    *d_ptr = it->second.back();
+    it->second.pop_back();
+    c->pool_free_bytes -= sz;
+    c->pool_live_bytes += sz;
+    return AMSM_OK;
+  }
+  hipError_t e = hipMalloc(d_ptr, sz);
+  if (e != hipSuccess) {  // give the free lists back to the driver and try once more
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(c->stream);
+    pool_release_all(c);
+    e = hipMalloc(d_ptr, sz);
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return AMSM_E_OOM;
   }
+  c->pool_size[*d_ptr] = sz;
+  c->pool_live_bytes += sz;
   return AMSM_OK;
 }
 int amsm_dev_free(amsm_ctx* c, void* d_ptr) {
   if (!c) return AMSM_E_INVALID_ARG;
   TRY(bind_device(c));
-  if (d_ptr) HIP_TRY(hipFree(d_ptr));
+  if (!d_ptr) return AMSM_OK;
+  auto it = c->pool_size.find(d_ptr);
+  if (it == c->pool_size.end()) {  // not one of ours (allocated before a trim raced, or foreign): plain free
+    HIP_TRY(hipFree(d_ptr));
+    return AMSM_OK;
+  }
+  const size_t sz = it->second;
+  c->pool_live_bytes -= sz;
+  if (c->pool_free_bytes + sz > c->pool_cap_bytes) {
+    c->pool_size.erase(it);
+    HIP_TRY(hipFree(d_ptr));
+    return AMSM_OK;
+  }
+  c->pool[sz].push_back(d_ptr);
+  c->pool_free_bytes += sz;
+  return AMSM_OK;
+}
+int amsm_ctx_memory(const amsm_ctx* c, size_t* workspace_bytes, size_t* vectors_live_bytes, size_t* vectors_pooled_bytes) {
+  if (!c) return AMSM_E_INVALID_ARG;
+  size_t ws = c->scalars.bytes + c->xyzz_scratch.bytes + c->rec_send.bytes + c->rec_recv.bytes + c->stage.bytes;
+  for (int k = 0; k < N_SLOTS; k++) {
+    const Slot* sl = &c->slot[k];
+    const DevBuf* bufs[] = {&sl->keys_a, &sl->keys_b, &sl->vals_a, &sl->vals_b, &sl->start, &sl->items, &sl->item_off,
+                            &sl->partials, &sl->buckets, &sl->red_out, &sl->fold_out, &sl->heavy, &sl->misc, &sl->sort_tmp,
+                            &sl->scan_tmp, &sl->prep_small, &sl->heavy_scratch};
+    for (const DevBuf* b : bufs) ws += b->bytes;
+  }
+  if (workspace_bytes) *workspace_bytes = ws;
+  if (vectors_live_bytes) *vectors_live_bytes = c->pool_live_bytes;
+  if (vectors_pooled_bytes) *vectors_pooled_bytes = c->pool_free_bytes;
+  return AMSM_OK;
+}
+int amsm_ctx_trim(amsm_ctx* c) {
+  if (!c) return AMSM_E_INVALID_ARG;
+  for (size_t g = 1; g < c->shard_ctx.size(); g++) TRY(amsm_ctx_trim(c->shard_ctx[g]));
+  TRY(amsm_ctx_synchronize(c));
+  pool_release_all(c);
+  DevBuf* own[] = {&c->scalars, &c->xyzz_scratch, &c->rec_send, &c->rec_recv, &c->stage};
+  for (DevBuf* b : own)
+    if (b->p) {
+      (void)hipFree(b->p);
+      *b = DevBuf();
+    }
+  for (int k = 0; k < N_SLOTS; k++) {
+    Slot* sl = &c->slot[k];
+    DevBuf* bufs[] = {&sl->keys_a, &sl->keys_b, &sl->vals_a, &sl->vals_b, &sl->start, &sl->items, &sl->item_off,
+                      &sl->partials, &sl->buckets, &sl->red_out, &sl->fold_out, &sl->heavy, &sl->misc, &sl->sort_tmp,
+                      &sl->scan_tmp, &sl->prep_small, &sl->heavy_scratch};
+    for (DevBuf* b : bufs)
+      if (b->p) {
+        (void)hipFree(b->p);
+        *b = DevBuf();
+      }
+  }
   return AMSM_OK;
 }
 int amsm_dev_upload(amsm_ctx* c, void* d_dst, const void* h_src, size_t bytes) {

@@ -84,6 +84,17 @@ class Context:
         except Exception:
             pass
 
+    def memory(self) -> dict:
+        """Device memory the context holds (amsm_ctx_memory): MSM workspace, live vectors, the allocator's free lists."""
+        ws, live, pooled = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        ffi.check(self._lib.amsm_ctx_memory(self._h, C.byref(ws), C.byref(live), C.byref(pooled)), "amsm_ctx_memory")
+        return {"workspace_bytes": ws.value, "vectors_live_bytes": live.value, "vectors_pooled_bytes": pooled.value}
+
+    def trim(self):
+        """Release the MSM workspace and every cached buffer (amsm_ctx_trim); live vectors and keys stay."""
+        self.empty_cache()
+        ffi.check(self._lib.amsm_ctx_trim(self._h), "amsm_ctx_trim")
+
     def set_window(self, c_bits: int):
         ffi.check(self._lib.amsm_ctx_set_window(self._h, c_bits), "amsm_ctx_set_window")
 

@@ -49,6 +49,8 @@ SIGNATURES = {
     "amsm_ctx_fq_limbs": (C.c_int, [_vp]),
     "amsm_ctx_set_window": (C.c_int, [_vp, C.c_int]),
     "amsm_ctx_synchronize": (C.c_int, [_vp]),
+    "amsm_ctx_memory": (C.c_int, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
+    "amsm_ctx_trim": (C.c_int, [_vp]),
     "amsm_ctx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "amsm_stage_count": (C.c_int, []),
     "amsm_stage_name": (C.c_char_p, [C.c_int]),

@@ -104,6 +104,13 @@ int amsm_ctx_fq_limbs(const amsm_ctx* ctx);
 int amsm_ctx_set_window(amsm_ctx* ctx, int c_bits);
 int amsm_ctx_synchronize(amsm_ctx* ctx);
 
+/* Device memory the context holds: the MSM workspace (grow-only: sized by the largest MSM so far, three pipeline slots), the
+ * bytes of live amsm_dev_alloc buffers and the bytes parked on the allocator's free lists (amsm_dev_free keeps buffers for
+ * reuse because hipMalloc / hipFree synchronise the device; AMSM_POOL_MAX_MB caps the free lists, default 16384).
+ * amsm_ctx_trim synchronises and releases the workspace and the free lists (live buffers and keys stay). */
+int amsm_ctx_memory(const amsm_ctx* ctx, size_t* workspace_bytes, size_t* vectors_live_bytes, size_t* vectors_pooled_bytes);
+int amsm_ctx_trim(amsm_ctx* ctx);
+
 /* Per-stage device timings of the LAST msm call (hipEvent pairs on the context's stream).
  * Enable with on != 0; stage names: amsm_stage_name(i), i in [0, amsm_stage_count()). */
 int amsm_ctx_set_profiling(amsm_ctx* ctx, int on);

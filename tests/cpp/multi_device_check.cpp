@@ -193,7 +193,18 @@ int main(int argc, char** argv) {
     // a sharded key does not work with a foreign context
     EXPECT(amsm_msm_device(one, keyN, 0, d_v[0], n, 1, got.xy.data(), &got.inf) == AMSM_E_INVALID_ARG);
   }
-  // (8) empty ranges
+  // (8) a sharded key loaded from the caller's arrays (amsm_bases_load), not generated
+  {
+    amsm_bases* keyL = nullptr;
+    CHECK(amsm_bases_load(multi, key_xy.data(), key_inf.data(), n, AMSM_BASES_DEFAULT, &keyL));
+    EXPECT(amsm_bases_num_shards(keyL) == n_shards && amsm_bases_len(keyL) == n);
+    CHECK(amsm_msm_device(multi, keyL, 0, d_p[1], n, 1, got.xy.data(), &got.inf));
+    EXPECT(got == ref[1]);
+    CHECK(amsm_msm_device(multi, keyL, w_off, d_p[0], w_n, 1, got.xy.data(), &got.inf));
+    EXPECT(got == ref_win);
+    amsm_bases_free(keyL);
+  }
+  // (9) empty ranges
   CHECK(amsm_msm_device(multi, keyN, n, d_p[0], 10, 1, got.xy.data(), &got.inf));
   EXPECT(got.inf == 1);
   CHECK(amsm_ctx_synchronize(multi));
