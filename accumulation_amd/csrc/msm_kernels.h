@@ -109,8 +109,10 @@ __global__ void __launch_bounds__(256) AMSM_L0_VGPR_ATTR
   const uint4* v4 = reinterpret_cast<const uint4*>(vals_sorted);
   uint4 cur = v4[min(s, last_grp) / 4];
   uint4 nxt = v4[min(s + 4, last_grp) / 4];
-  // bucket of the first entry: largest b with start[b] <= s
-  u32 b_cur = 0;
+  // bucket of the first entry: largest b with start[b] <= s.  Everything a flush needs is loaded when a bucket is ENTERED
+  // (its end = start[b + 1], its first partial slot) so that closing a bucket costs ONE dependent load (the next bucket's end,
+  // for the empty-bucket test): a wave pays a flush whenever any of its lanes closes a bucket -- every iteration on small MSMs.
+  u32 b_cur = 0, s_next = 0, slot0 = 0;  // slot0 + c = the partial slot of (bucket, this chunk)
   if (s < e) {
     u32 lo = 0, hi = g.B;
     while (lo < hi) {
@@ -118,6 +120,8 @@ __global__ void __launch_bounds__(256) AMSM_L0_VGPR_ATTR
       if (start[mid] <= s) lo = mid; else hi = mid - 1;
     }
     b_cur = lo;
+    s_next = start[b_cur + 1];
+    slot0 = item_off[b_cur] - chunk_of(g, start[b_cur]);  // first partial of the bucket, minus the chunk holding its first entry
   }
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   gather_issue<Fq>(table, cur.x & ENTRY_IDX, lds_wave0, lane);
@@ -138,32 +142,33 @@ __global__ void __launch_bounds__(256) AMSM_L0_VGPR_ATTR
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       gather_issue<Fq>(table, w[i + 2] & ENTRY_IDX, region, lane);
       if (k < e) {
-        u32 v = w[i];
-        xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (v & ENTRY_NEG) != 0));
-        if ((v & ENTRY_LAST) || k + 1 == e) {  // bucket (or chunk) finished: flush one partial
-          u32 slot = item_off[b_cur] + (c - chunk_of(g, start[b_cur]));
-          xyzz_store<Fq>(partials, slot, acc);
+        xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (w[i] & ENTRY_NEG) != 0));
+        if (k + 1 == s_next || k + 1 == e) {  // bucket (or chunk) finished: flush one partial
+          xyzz_store<Fq>(partials, slot0 + c, acc);
           acc = xyzz_inf<Fq>();
-          if (k + 1 < e) {  // next entry opens the next NON-EMPTY bucket: largest b with start[b] <= k+1
-            // Almost always the very next bucket (an empty bucket needs a digit value nobody drew): probe a few buckets
-            // linearly -- ONE dependent load in the common case -- before falling back to the binary search, whose ~15
-            // dependent loads per flush were most of accumulate L0's time on small MSMs (a wave pays them whenever ANY of
-            // its lanes closes a bucket: every iteration at 34 entries per bucket; rocprofv3 timeline of an IPA round, round 2).
-            u32 b = b_cur + 1;  // start[B] = e_valid > k + 1 ends the probe at the last bucket
-            u32 probes = 0;
-            while (probes < 4u && start[b + 1] <= k + 1) {
-              b++;
-              probes++;
-            }
-            if (start[b + 1] <= k + 1) {
-              u32 lo = b + 1, hi = g.B;
-              while (lo < hi) {
-                u32 mid = (lo + hi + 1) >> 1;
-                if (start[mid] <= k + 1) lo = mid; else hi = mid - 1;
+          if (k + 1 < e) {  // entry k + 1 opens the next NON-EMPTY bucket: the largest b with start[b] <= k + 1
+            u32 b = b_cur + 1;  // almost always the very next one (an empty bucket needs a digit value nobody drew)
+            u32 sn = start[b + 1];  // (prefetching this one too costs the two registers that drop the occupancy to 2 waves)
+            if (sn <= k + 1) {  // bucket b is empty: probe a few more, then binary search (skewed inputs leave long gaps)
+              u32 probes = 0;
+              do {
+                b++;
+                sn = start[b + 1];  // start[B] = e_valid > k + 1 ends the probe at the last bucket
+                probes++;
+              } while (probes < 4u && sn <= k + 1);
+              if (sn <= k + 1) {
+                u32 lo = b + 1, hi = g.B;
+                while (lo < hi) {
+                  u32 mid = (lo + hi + 1) >> 1;
+                  if (start[mid] <= k + 1) lo = mid; else hi = mid - 1;
+                }
+                b = lo;
+                sn = start[b + 1];
               }
-              b = lo;
             }
             b_cur = b;
+            s_next = sn;
+            slot0 = item_off[b] - chunk_of(g, k + 1);  // start[b] == k + 1: the buckets are contiguous
           }
         }
       }
