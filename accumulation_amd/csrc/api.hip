@@ -61,6 +61,7 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   size_t h_pinned_bytes = 0;
   MsmGeom geom = {};
   bool busy = false;
+  hipStream_t tail = nullptr;  // the stream this slot's tail (and its result copy) was queued on
 };
 
 struct ShardWorker {  // one persistent host thread per non-primary shard
@@ -136,6 +137,7 @@ struct amsm_ctx {
   int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x resident 256-lane blocks per CU x 4
   int K1 = 1024;  // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew only)
   int red_s = 4;
+  bool one_stream = true;  // a lone blocking MSM runs its whole chain on the caller's stream (AMSM_ONE_STREAM=0: per-stage streams, A/B)
   bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
   bool profiling = false;
   float stage_ms[ST_COUNT] = {};  // mean over the MSMs of the last call
@@ -143,6 +145,7 @@ struct amsm_ctx {
   int stage_n = 0;
   Slot slot[N_SLOTS];
   hipEvent_t fork = nullptr;
+  hipEvent_t ip_ready = nullptr;  // amsm_ipa_round_fused: the inner products have reached the host
   DevBuf scalars;
   DevBuf xyzz_scratch;  // unconverted sums of large key folds / precompute levels (launch.h: batch_affine_pays)
   // ---- multi-device (amsm_ctx_create_multi) ----
@@ -451,7 +454,7 @@ int prep_fork(amsm_ctx* ctx) {
 // in sl->fold_out and queues their D2H into sl->h_pinned.
 template <class Fq, class Fr>
 int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
-                int scalars_mont, int group_shift = -1, bool exposed_tail = true) {
+                int scalars_mont, int group_shift = -1, bool exposed_tail = true, bool alone = true) {
   // exposed_tail: nothing is queued behind this MSM, so the caller waits for its tail (bucket reduce + fold, a chain of
   // dependent point operations on a few waves): run it on the quad-cooperative kernels (-0.08 ms).  Inside a batch the
   // tail is hidden behind the next MSM's accumulation and the one-lane kernels cost less ALU time (measured: 1 % of the
@@ -460,8 +463,12 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   MsmGeom g;
   TRY(make_geom(ctx, bases, base_off, n, &g, group_shift));
   sl->geom = g;
-  hipStream_t st = ctx->s_prep;  // digits / sort / bounds
-  hipStream_t sm = ctx->stream;  // accumulate L0
+  // alone: the only MSM of a blocking call.  Nothing can overlap, and every hand-over between streams (an event wait on
+  // another hardware queue) costs ~10 us of idle GPU -- three of them in a chain of 0.4 ms at 2^16 (rocprofv3 timeline of an
+  // IPA round, round 2): the whole chain goes on the caller's stream.
+  const bool one = ctx->one_stream && alone && exposed_tail;
+  hipStream_t st = one ? ctx->stream : ctx->s_prep;  // digits / sort / bounds
+  hipStream_t sm = ctx->stream;                      // accumulate L0
   const u32 max_items = g.n_chunks + g.B + 1;
   const u32 red_blocks = cdiv(g.red_threads * (quad ? 4u : 1u), 256);
   TRY(ensure(sl->vals_a, (size_t)g.E * 4 + 64));
@@ -472,27 +479,30 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   TRY(ensure(sl->partials, (size_t)max_items * xyzz_bytes<Fq>()));
   TRY(ensure(sl->buckets, (size_t)g.B * xyzz_bytes<Fq>()));
   TRY(ensure(sl->red_out, (size_t)g.n_sets * red_blocks * xyzz_bytes<Fq>()));
-  TRY(ensure(sl->fold_out, (size_t)g.n_sets * xyzz_bytes<Fq>()));
+  TRY(ensure(sl->fold_out, (size_t)g.n_sets * xyzz_bytes<Fq>() + 64));
   TRY(ensure(sl->heavy, (size_t)(g.B + 1) * 4));
   // at most max_items / K1 buckets can hold more than K1 partials each
   TRY(ensure(sl->heavy_scratch, ((size_t)max_items / std::max<u32>(g.K1, 1u) + 2) * accum_l2_slices<Fq>() * xyzz_bytes<Fq>()));
-  TRY(ensure(sl->misc, 64));
   size_t rec = xyzz_bytes<Fq>();
   TRY(ensure_pinned(sl, g.n_sets * rec + 64));
-  u32* d_err = (u32*)sl->misc.p;
+  // 16 flag words (scalar-range error, heavy-bucket count).  With the short prep chain they lead its block of small
+  // arrays, so that ONE fill clears both (a fill is a 5 us dispatch at the head of every MSM's chain).
+  const bool short_prep = ctx->custom_prep && prep_supported(g);
+  if (short_prep) TRY(ensure(sl->prep_small, 64 + prep_small_words(g) * sizeof(u32) + 256));
+  else TRY(ensure(sl->misc, 64));
+  u32* d_err = short_prep ? (u32*)sl->prep_small.p : (u32*)sl->misc.p;
   u32* d_heavy_count = d_err + 1;
   u32* keys_a = (u32*)sl->keys_a.p;
   u32* keys_b = (u32*)sl->keys_b.p;
   u32* vals_a = (u32*)sl->vals_a.p;
   u32* vals_b = (u32*)sl->vals_b.p;
 
-  HIP_TRY(hipMemsetAsync(sl->misc.p, 0, 64, st));
+  if (!short_prep) HIP_TRY(hipMemsetAsync(sl->misc.p, 0, 64, st));
   stage_mark(ctx, sl, ST_DIGITS, st);
-  if (ctx->custom_prep && prep_supported(g)) {
+  if (short_prep) {
     // short prep chain (prep_kernels.h: 5 dispatches + 2 for skewed inputs); the stage marks keep their names: "sort" = scatter + local sort
-    TRY(ensure(sl->prep_small, prep_small_words(g) * sizeof(u32)));
     PrepBuffers pb;
-    pb.d_small = (u32*)sl->prep_small.p;
+    pb.d_small = d_err + 16;
     pb.part = vals_a;
     pb.vals_sorted = vals_b;
     pb.start = (u32*)sl->start.p;
@@ -543,8 +553,10 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   AMSM_DBG("pre-l0");
   }
   if (ctx->profiling) (void)hipEventRecord(sl->ev_prep_end, st);
-  HIP_TRY(hipEventRecord(sl->prep_done, st));
-  HIP_TRY(hipStreamWaitEvent(sm, sl->prep_done, 0));
+  if (!one) {
+    HIP_TRY(hipEventRecord(sl->prep_done, st));
+    HIP_TRY(hipStreamWaitEvent(sm, sl->prep_done, 0));
+  }
   stage_mark(ctx, sl, ST_ACCUM_L0, sm);
   launch_accum_l0<Fq>(sm, (const u32*)bases->d_table, (const u32*)vals_b, (const u32*)sl->start.p,
                       (const u32*)sl->item_off.p, g, (u32*)sl->partials.p,
@@ -552,9 +564,12 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
                       g.l0_per_cu == 1 ? 65536u : (g.l0_per_cu == 2 ? 24576u : ctx->l0_lds_pad));
   AMSM_DBG("l0");
   if (ctx->profiling) (void)hipEventRecord(sl->ev_l0_end, sm);
-  HIP_TRY(hipEventRecord(sl->l0_done, sm));
-  hipStream_t tl = ctx->s_tail;
-  HIP_TRY(hipStreamWaitEvent(tl, sl->l0_done, 0));
+  hipStream_t tl = one ? ctx->stream : ctx->s_tail;
+  sl->tail = tl;
+  if (!one) {
+    HIP_TRY(hipEventRecord(sl->l0_done, sm));
+    HIP_TRY(hipStreamWaitEvent(tl, sl->l0_done, 0));
+  }
   if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_ACCUM_L12], tl);
   launch_accum_l1<Fq>(tl, l1_lanes(g, !exposed_tail), (const u32*)sl->partials.p, (const u32*)sl->items.p, (const u32*)sl->item_off.p,
                       g, (u32*)sl->buckets.p, d_heavy_count, (u32*)sl->heavy.p);
@@ -570,15 +585,14 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
     launch_bucket_reduce<Fq>(tl, red_blocks, (const u32*)sl->buckets.p, g, (u32*)sl->red_out.p);
   AMSM_DBG("reduce");
   if (quad)
-    launch_fold_quad<Fq>(tl, g.n_sets, (const u32*)sl->red_out.p, red_blocks, (u32*)sl->fold_out.p);
+    launch_fold_quad<Fq>(tl, g.n_sets, (const u32*)sl->red_out.p, red_blocks, (u32*)sl->fold_out.p, d_err);
   else
-    launch_fold<Fq>(tl, g.n_sets, (const u32*)sl->red_out.p, red_blocks, (u32*)sl->fold_out.p);
+    launch_fold<Fq>(tl, g.n_sets, (const u32*)sl->red_out.p, red_blocks, (u32*)sl->fold_out.p, d_err);
   AMSM_DBG("fold");
   if (ctx->profiling) (void)hipEventRecord(sl->ev[ST_COUNT], tl);
   HIP_TRY(hipGetLastError());
   u32* h = (u32*)sl->h_pinned;
-  HIP_TRY(hipMemcpyAsync(h, sl->fold_out.p, g.n_sets * rec, hipMemcpyDeviceToHost, tl));
-  HIP_TRY(hipMemcpyAsync((char*)h + g.n_sets * rec, sl->misc.p, 8, hipMemcpyDeviceToHost, tl));
+  HIP_TRY(hipMemcpyAsync(h, sl->fold_out.p, g.n_sets * rec + 8, hipMemcpyDeviceToHost, tl));  // records + flag words
   HIP_TRY(hipEventRecord(sl->done, tl));
   sl->busy = true;
   return AMSM_OK;
@@ -664,14 +678,15 @@ int msm_multi_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t k, const size_
   std::vector<long> owner(N_SLOTS, -1);  // which MSM a busy slot carries
   size_t slot_rr = 0;
   size_t last = 0;  // the last non-empty MSM: the only one whose tail the caller waits for
+  size_t n_live = 0;
   for (size_t v = 0; v < k; v++)
-    if (len[v]) last = v;
+    if (len[v]) last = v, n_live++;
   for (size_t v = 0; v < k && rc == AMSM_OK; v++) {
     if (len[v] == 0) continue;  // identity
     Slot* sl = &ctx->slot[slot_rr % N_SLOTS];
     if (sl->busy) rc = msm_collect<Fq>(ctx, sl, &(*out)[owner[slot_rr % N_SLOTS]]);
     if (rc == AMSM_OK) {
-      rc = msm_enqueue<Fq, Fr>(ctx, sl, bases, offs[v], d_scalars[v], len[v], scalars_mont, -1, v == last);
+      rc = msm_enqueue<Fq, Fr>(ctx, sl, bases, offs[v], d_scalars[v], len[v], scalars_mont, -1, v == last, n_live == 1);
       owner[slot_rr % N_SLOTS] = (long)v;
       slot_rr++;
     }
@@ -955,6 +970,32 @@ struct FixedBaseCache {
   }
 };
 
+inline bool fixed_base_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("AMSM_HOST_FIXED_BASE");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+template <class Fq>
+FixedBaseCache<Fq>& fixed_base_cache() {
+  thread_local FixedBaseCache<Fq> cache;
+  return cache;
+}
+// k * P for a point that recurs over calls (h' of an IPA opening): the thread's fixed-base table once it exists
+template <class Fq, class Fr>
+host::HXYZZ<Fq> host_mul_cached(const uint64_t* xy, const host::HFe<Fr>& k_mont) {
+  host::HFe<Fr> k = host::h_from_mont<Fr>(k_mont);
+  host::HXYZZ<Fq> p = host::hx_from_affine<Fq>(xy, false);
+  const host::HFixedBase<Fq>* fb = nullptr;
+  if (fixed_base_enabled() && host::hx_scalar_bits(k.v) > 128) {
+    FixedBaseCache<Fq>& cache = fixed_base_cache<Fq>();
+    cache.call++;
+    fb = cache.lookup(xy, p);
+  }
+  return fb ? fb->mul(k.v) : host::hx_mul<Fq>(p, k.v);
+}
+
 template <class Fq, class Fr>
 int host_lincomb_impl(const uint64_t* xy, const uint8_t* is_inf, const uint64_t* scalars_mont, size_t n,
                       uint64_t* out_xy, uint8_t* out_inf) {
@@ -962,11 +1003,8 @@ int host_lincomb_impl(const uint64_t* xy, const uint8_t* is_inf, const uint64_t*
   std::vector<host::HXYZZ<Fq>> pts(n);
   std::vector<std::array<uint64_t, 4>> ks(n);
   std::vector<const host::HFixedBase<Fq>*> fixed(n, nullptr);
-  static const bool use_cache = [] {
-    const char* e = getenv("AMSM_HOST_FIXED_BASE");
-    return !(e && atoi(e) == 0);
-  }();
-  thread_local FixedBaseCache<Fq> cache;
+  const bool use_cache = fixed_base_enabled();
+  FixedBaseCache<Fq>& cache = fixed_base_cache<Fq>();
   cache.call++;
   for (size_t i = 0; i < n; i++) {
     host::HFe<Fr> s;
@@ -1021,32 +1059,38 @@ int msm_grouped_impl(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, co
 // stream and run beside the MSM's tail.
 template <class Fq, class Fr>
 int ipa_round_impl(amsm_ctx* ctx, const amsm_bases* key, const uint64_t* xi_mont, size_t j, size_t log_key, const void* d_coeffs,
-                   const void* d_z, size_t half, void* d_u, uint64_t* out_lr_xy, uint8_t* out_lr_inf, uint64_t* out_ip_mont) {
+                   const void* d_z, size_t half, void* d_u, uint64_t* out_lr_xy, uint8_t* out_lr_inf, uint64_t* out_ip_mont,
+                   const uint64_t* fold_x_mont = nullptr, const uint64_t* h_prime_xy = nullptr) {
   const size_t n = (size_t)1 << log_key;
   if (n > key->n) return AMSM_E_INVALID_ARG;
-  launch_ipa_round_scalars<Fr>(ctx->stream, (const u32*)xi_mont, (u32)j, (u32)log_key, (const u32*)d_coeffs, (u32*)d_u, nullptr);
-  HIP_TRY(hipGetLastError());
+  // The two inner products first: their per-workgroup partial sums go straight to pinned host memory (no copy in the
+  // chain), and the host turns them into the h' multiples while the MSM runs.  With a fold pending (the previous round's
+  // c <- c_l + x^-1 c_r, z <- z_l + x z_r over the 4 * half elements the buffers still hold) the same launch folds in place.
   const u32 blocks = std::min<u32>(1024u, cdiv((u32)half, 256));
-  TRY(ensure(ctx->scalars, (size_t)2 * blocks * 32 + 4096));
   Slot* aux = &ctx->slot[1];  // only its pinned buffer: slot 1 carries no MSM during a single-MSM call
   TRY(ensure_pinned(aux, (size_t)2 * blocks * 32));
+  u32* co = (u32*)d_coeffs;
+  u32* z = (u32*)d_z;
+  u32* part = (u32*)aux->h_pinned;
+  if (fold_x_mont) {
+    host::HFe<Fr> x, xinv;
+    memcpy(x.v, fold_x_mont, 32);
+    xinv = host::h_inv<Fr>(x);
+    launch_ipa_fold_ip<Fr>(ctx->stream, co, z, (u32)half, (const u32*)x.v, (const u32*)xinv.v, blocks, part);
+  } else {
+    launch_vec_inner_product_pair<Fr>(ctx->stream, co + half * 8, z, co, z + half * 8, (u32)half, blocks, part);  // <c_r, z_l>, <c_l, z_r>
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ctx->ip_ready, ctx->stream));
+  launch_ipa_round_scalars<Fr>(ctx->stream, (const u32*)xi_mont, (u32)j, (u32)log_key, (const u32*)d_coeffs, (u32*)d_u, nullptr);
+  HIP_TRY(hipGetLastError());
   std::vector<host::HXYZZ<Fq>> r(2, host::hx_inf<Fq>());
   stage_begin(ctx);
   TRY(prep_fork(ctx));
   TRY((msm_enqueue<Fq, Fr>(ctx, &ctx->slot[0], key, 0, d_u, n, 1, (int)(log_key - 1 - j))));
-  const u32* co = (const u32*)d_coeffs;
-  const u32* z = (const u32*)d_z;
-  u32* part = (u32*)ctx->scalars.p;
-  launch_vec_inner_product<Fr>(ctx->stream, co + half * 8, z, (u32)half, blocks, part);               // <c_r, z_l>
-  launch_vec_inner_product<Fr>(ctx->stream, co, z + half * 8, (u32)half, blocks, part + blocks * 8);  // <c_l, z_r>
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(aux->h_pinned, part, (size_t)2 * blocks * 32, hipMemcpyDeviceToHost, ctx->stream));
-  int rc = msm_collect<Fq>(ctx, &ctx->slot[0], r.data());
-  stage_end(ctx);
-  if (rc != AMSM_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  write_affine_batch<Fq>(r, out_lr_xy, out_lr_inf);
+  HIP_TRY(hipEventSynchronize(ctx->ip_ready));
   const u64* h = (const u64*)aux->h_pinned;
+  host::HXYZZ<Fq> hterm[2] = {host::hx_inf<Fq>(), host::hx_inf<Fq>()};
   for (int k = 0; k < 2; k++) {
     host::HFe<Fr> acc = host::h_zero<Fr>(), t;
     for (u32 i = 0; i < blocks; i++) {
@@ -1054,7 +1098,14 @@ int ipa_round_impl(amsm_ctx* ctx, const amsm_bases* key, const uint64_t* xi_mont
       acc = host::h_add<Fr>(acc, t);
     }
     memcpy(out_ip_mont + 4 * k, acc.v, 32);
+    if (h_prime_xy) hterm[k] = host_mul_cached<Fq, Fr>(h_prime_xy, acc);
   }
+  int rc = msm_collect<Fq>(ctx, &ctx->slot[0], r.data());
+  stage_end(ctx);
+  if (rc != AMSM_OK) return rc;
+  if (h_prime_xy)
+    for (int k = 0; k < 2; k++) r[k] = host::hx_add<Fq>(r[k], hterm[k]);
+  write_affine_batch<Fq>(r, out_lr_xy, out_lr_inf);
   return AMSM_OK;
 }
 
@@ -1130,8 +1181,8 @@ int msm_partial_impl(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, co
   if (sl->geom.n_sets == 1) {
     // single folded record: it stays on the device (copied record-to-record); the host only waits for
     // the range flag
-    HIP_TRY(hipMemcpyAsync(d_out, sl->fold_out.p, xyzz_bytes<Fq>(), hipMemcpyDeviceToDevice, ctx->s_tail));
-    HIP_TRY(hipEventRecord(sl->done, ctx->s_tail));
+    HIP_TRY(hipMemcpyAsync(d_out, sl->fold_out.p, xyzz_bytes<Fq>(), hipMemcpyDeviceToDevice, sl->tail));
+    HIP_TRY(hipEventRecord(sl->done, sl->tail));
     host::HXYZZ<Fq> unused;
     int rc = msm_collect<Fq>(ctx, sl, &unused);
     stage_end(ctx);
@@ -1508,6 +1559,7 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
     ok = ok && hipEventCreateWithFlags(&c->slot[k].prep_done, hipEventDisableTiming) == hipSuccess;
   }
   ok = ok && hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ip_ready, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
     amsm_ctx_destroy(c);
@@ -1531,6 +1583,7 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   if (const char* e = getenv("AMSM_L0_SPREAD")) c->small_spread = atoi(e) != 0;
   if (const char* e = getenv("AMSM_K0_2PHASE")) c->two_phase = atoi(e) != 0;
   if (const char* e = getenv("AMSM_TAIL_QUAD")) c->tail_quad = atoi(e) != 0;
+  if (const char* e = getenv("AMSM_ONE_STREAM")) c->one_stream = atoi(e) != 0;
   if (const char* e = getenv("AMSM_K1")) c->K1 = std::max(1, atoi(e));
   if (const char* e = getenv("AMSM_RED_S")) c->red_s = std::max(1, atoi(e));
   if (const char* e = getenv("AMSM_WINDOW")) c->window_override = atoi(e);
@@ -1577,6 +1630,7 @@ void amsm_ctx_destroy(amsm_ctx* c) {
     if (sl->prep_done) (void)hipEventDestroy(sl->prep_done);
   }
   if (c->fork) (void)hipEventDestroy(c->fork);
+  if (c->ip_ready) (void)hipEventDestroy(c->ip_ready);
   if (c->s_prep) (void)hipStreamDestroy(c->s_prep);
   if (c->s_tail) (void)hipStreamDestroy(c->s_tail);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -2553,6 +2607,26 @@ int amsm_ipa_round(amsm_ctx* c, const amsm_bases* key, const uint64_t* xi_mont, 
                                                           out_ip_mont)),
                   (ipa_round_impl<Bls12381Fq, Bls12381Fr>(c, key, xi_mont, j, log_key, d_coeffs, d_z, half, d_u, out_lr_xy,
                                                           out_lr_inf, out_ip_mont)));
+}
+
+int amsm_ipa_round_fused(amsm_ctx* c, const amsm_bases* key, const uint64_t* xi_mont, size_t j, size_t log_key, void* d_coeffs,
+                         void* d_z, const uint64_t* fold_x_mont, const uint64_t* h_prime_xy, void* d_u, uint64_t* out_lr_xy,
+                         uint8_t* out_lr_inf, uint64_t* out_ip_mont) {
+  if (!c || !key || !d_coeffs || !d_z || !d_u || !out_lr_xy || !out_ip_mont || (j && !xi_mont) || log_key == 0 || log_key > 30 ||
+      j >= log_key || key->curve != c->curve || key->device != c->device)
+    return AMSM_E_INVALID_ARG;
+  if (key_sharded(key)) return AMSM_E_UNSUPPORTED;
+  if (fold_x_mont) {
+    bool zero = true;
+    for (int k = 0; k < 4; k++) zero = zero && fold_x_mont[k] == 0;
+    if (zero) return AMSM_E_INVALID_ARG;  // a zero challenge has no inverse (the reference's verifier rejects it too)
+  }
+  TRY(bind_device(c));
+  const size_t half = (size_t)1 << (log_key - j - 1);
+  return DISPATCH(c, (ipa_round_impl<PallasFq, PallasFr>(c, key, xi_mont, j, log_key, d_coeffs, d_z, half, d_u, out_lr_xy, out_lr_inf,
+                                                          out_ip_mont, fold_x_mont, h_prime_xy)),
+                  (ipa_round_impl<Bls12381Fq, Bls12381Fr>(c, key, xi_mont, j, log_key, d_coeffs, d_z, half, d_u, out_lr_xy,
+                                                          out_lr_inf, out_ip_mont, fold_x_mont, h_prime_xy)));
 }
 
 int amsm_matrix_load(amsm_ctx* c, const uint32_t* row_ptr, const uint32_t* col_idx, const uint64_t* vals, size_t n_rows,

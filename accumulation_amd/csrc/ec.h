@@ -191,8 +191,9 @@ AMSM_DEV Affine<P> affine_neg_if(const Affine<P>& p, bool negate) {
 // Quad-cooperative group law for the latency-bound tail kernels (bucket reduce, fold): the four lanes of an aligned quad
 // hold the SAME operands (replicated state); the independent field multiplications of one level of the formula run on
 // different lanes of the quad and the products are broadcast back, so a full addition is 4 multiplication-times deep
-// instead of 14 and a doubling 3 instead of 9.  The operations and their operand roles are exactly those of xyzz_add /
-// xyzz_dbl above (same primitives on the same values -> same bounds, same limbs); only the schedule differs.  A lone
+// instead of 14 and a doubling 3 instead of 9 (a squaring rides as a product on a level that has a free lane: one
+// level less than squaring first).  The operations and their operand roles are those of xyzz_add / xyzz_dbl above, so
+// the same bounds hold; only the schedule differs.  A lone
 // product on a lane of a fused level is written as the two-product form with a zero second product.
 // All four lanes of the quad must be active and hold equal operands.
 template <class P, int K>
@@ -224,10 +225,9 @@ AMSM_DEV XYZZ<P> xyzz_dbl_quad(const XYZZ<P>& p) {
   Fe<P> sq = fe_sqr<P>(fe_sel<P>(k == 1u, p.x, u));  // lane 0: v = u^2, lane 1: xx = x^2
   Fe<P> v = quad_bcast<P, 0>(sq), xx = quad_bcast<P, 1>(sq);
   Fe<P> m = fe_triple<P>(xx);
-  // lane 0: w = u v, lane 1: s = x v, lane 2: zz3 = v zz
-  Fe<P> m2 = fe_mul<P>(fe_sel4<P>(k, u, p.x, v, v), fe_sel4<P>(k, v, v, p.zz, p.zz));
-  Fe<P> mm = fe_sqr<P>(m);
-  Fe<P> w = quad_bcast<P, 0>(m2), s = quad_bcast<P, 1>(m2);
+  // lane 0: w = u v, lane 1: s = x v, lane 2: zz3 = v zz, lane 3: mm = m^2 (as a product: one level instead of two)
+  Fe<P> m2 = fe_mul<P>(fe_sel4<P>(k, u, p.x, v, m), fe_sel4<P>(k, v, v, p.zz, m));
+  Fe<P> w = quad_bcast<P, 0>(m2), s = quad_bcast<P, 1>(m2), mm = quad_bcast<P, 3>(m2);
   XYZZ<P> r;
   r.zz = quad_bcast<P, 2>(m2);
   r.x = fe_sub_bcc_k<P, 4>(mm, zero, s);
@@ -259,9 +259,9 @@ AMSM_DEV void xyzz_add_quad(XYZZ<P>& acc, const XYZZ<P>& q) {
     else acc = xyzz_inf<P>();
     return;
   }
-  Fe<P> sq = fe_sqr<P>(fe_sel<P>(k == 1u, r, p));                                                      // lane 0: pp, lane 1: rr
-  Fe<P> m2 = fe_mul<P>(fe_sel<P>(k == 3u, acc.zzz, acc.zz), fe_sel<P>(k == 3u, q.zzz, q.zz));        // lane 2: ZZ1 ZZ2, lane 3: ZZZ1 ZZZ2
-  Fe<P> pp = quad_bcast<P, 0>(sq), rr = quad_bcast<P, 1>(sq);
+  // lane 0: pp = p^2, lane 1: rr = r^2 (as products: ONE level for all four), lane 2: ZZ1 ZZ2, lane 3: ZZZ1 ZZZ2
+  Fe<P> m2 = fe_mul<P>(fe_sel4<P>(k, p, r, acc.zz, acc.zzz), fe_sel4<P>(k, p, r, q.zz, q.zzz));
+  Fe<P> pp = quad_bcast<P, 0>(m2), rr = quad_bcast<P, 1>(m2);
   Fe<P> zz12 = quad_bcast<P, 2>(m2), zzz12 = quad_bcast<P, 3>(m2);
   // lane 0: ppp = p pp, lane 1: qq = u1 pp, lane 2: zz3 = zz12 pp
   Fe<P> m3 = fe_mul<P>(fe_sel4<P>(k, p, u1, zz12, zz12), pp);

@@ -113,8 +113,15 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
     hv.ids = hv.cnt + prep_heavy_words(g);                                                                           \
     hv.cur = hv.ids + PREP_MAX_HEAVY;                                                                                \
     hv.end = hv.cur + prep_heavy_words(g);                                                                           \
-    if (hipMemsetAsync(b.d_small, 0, (4 * (PREP_MAX_P + 1) + 1 + prep_heavy_words(g)) * sizeof(u32), st) != hipSuccess) \
-      return -1;                                                                                                     \
+    /* one fill: the 16 flag words in front of d_small (b.err) and the arrays that must start at zero; a whole number */ \
+    /* of 256-byte lines (an odd size made the runtime split the fill into two dispatches); the words it spills into */ \
+    /* (hv.ids) are written before they are read */                                                                  \
+    {                                                                                                                \
+      size_t zero_bytes = (16 + 4 * (PREP_MAX_P + 1) + 1 + prep_heavy_words(g)) * sizeof(u32);                       \
+      zero_bytes = (zero_bytes + 255) & ~(size_t)255;                                                                \
+      if (b.err != b.d_small - 16) return -1;                                                                        \
+      if (hipMemsetAsync(b.err, 0, zero_bytes, st) != hipSuccess) return -1;                                         \
+    }                                                                                                                \
     u32 blocks = cdiv_(g.n, pg.SPB);                                                                                 \
     size_t lds_scatter = prep_scatter_lds(g, pg);                                                                    \
     if (lds_scatter > 64 * 1024) { /* rare (P above ~1300): opt in for this launch's instantiation */                \
@@ -194,6 +201,19 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
   template <>                                                                                                        \
   void launch_vec_inner_product<FR>(hipStream_t st, const u32* a, const u32* b, u32 n, u32 blocks, u32* out) {       \
     hipLaunchKernelGGL((k_vec_inner_product<FR>), dim3(blocks), dim3(256), 0, st, a, b, n, out);                     \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  void launch_vec_inner_product_pair<FR>(hipStream_t st, const u32* a0, const u32* b0, const u32* a1, const u32* b1, \
+                                         u32 n, u32 blocks, u32* out) {                                              \
+    hipLaunchKernelGGL((k_vec_inner_product_pair<FR>), dim3(blocks, 2), dim3(256), 0, st, a0, b0, a1, b1, n, out);   \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  void launch_ipa_fold_ip<FR>(hipStream_t st, u32* c, u32* z, u32 half, const u32 x[8], const u32 xinv[8], u32 blocks, \
+                              u32* out) {                                                                            \
+    IpaFoldArgs a;                                                                                                   \
+    memcpy(a.x, x, 32);                                                                                              \
+    memcpy(a.xinv, xinv, 32);                                                                                        \
+    hipLaunchKernelGGL((k_ipa_fold_ip<FR>), dim3(blocks), dim3(256), 0, st, c, z, half, a, out);                     \
   }                                                                                                                  \
   template <>                                                                                                        \
   void launch_check_poly_coeffs<FR>(hipStream_t st, const u32* xi, u32 k, u32* out) {                                \

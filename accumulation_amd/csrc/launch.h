@@ -27,12 +27,13 @@ u32 accum_l2_slices();  // scratch records per heavy bucket
 template <class Fq>
 void launch_bucket_reduce(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* out);
 template <class Fq>
-void launch_fold(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out);
+// flags (may be null): two words copied behind the n_sets records (out needs 8 bytes more)
+void launch_fold(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags);
 // the same two kernels with a quad of lanes per logical lane (ec.h: xyzz_add_quad): red_blocks = 4x
 template <class Fq>
 void launch_bucket_reduce_quad(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* out);
 template <class Fq>
-void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out);
+void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags);
 template <class Fq>
 void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c, u32* xyzz_scratch);
 template <class Fq>
@@ -66,13 +67,13 @@ void launch_digits(hipStream_t st, const u32* scalars, int mont, MsmGeom g, void
 // zeroes what needs it.
 size_t prep_small_words(const MsmGeom& g);
 struct PrepBuffers {
-  u32* d_small;       // >= prep_small_words(g) words
+  u32* d_small;       // >= prep_small_words(g) words (+ 256 bytes of slack), directly behind the 16 words at `err`
   u32* part;          // E words: entries grouped by partition
   u32* vals_sorted;   // E + 16 words
   u32* start;         // B + 2 words
   u32* items;         // B + 2 words
   u32* item_off;      // B + 2 words
-  u32* err;
+  u32* err;           // == d_small - 16: the MSM's flag words, cleared by the same fill
 };
 bool prep_supported(const MsmGeom& g);
 template <class Fr>
@@ -95,6 +96,13 @@ template <class Fr>
 void launch_vec_powers(hipStream_t st, const u32 point_mont[8], u32 n, u32* out);
 template <class Fr>
 void launch_vec_inner_product(hipStream_t st, const u32* a, const u32* b, u32 n, u32 blocks, u32* out);
+template <class Fr>
+void launch_vec_inner_product_pair(hipStream_t st, const u32* a0, const u32* b0, const u32* a1, const u32* b1, u32 n,
+                                   u32 blocks, u32* out);
+// in-place fold of c and z (2 * 2 * half elements -> 2 * half) + the two inner products of the folded halves
+template <class Fr>
+void launch_ipa_fold_ip(hipStream_t st, u32* c, u32* z, u32 half, const u32 x_mont[8], const u32 xinv_mont[8], u32 blocks,
+                        u32* out);
 template <class Fr>
 void launch_ipa_round_scalars(hipStream_t st, const u32* xi_mont, u32 j, u32 log_n, const u32* c, u32* out_l, u32* out_r);
 template <class Fr>

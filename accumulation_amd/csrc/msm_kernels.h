@@ -385,7 +385,8 @@ __global__ void __launch_bounds__(256)
 
 // fold: wave b sums records [b*n, (b+1)*n) (lane-strided + shuffle butterfly) and writes out[b] (C-ABI radix).
 template <class Fq>
-__global__ void __launch_bounds__(64) k_fold(const u32* __restrict__ in, u32 n, u32* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_fold(const u32* __restrict__ in, u32 n, u32* __restrict__ out,
+                                             const u32* __restrict__ flags) {
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   for (u32 k = threadIdx.x; k < n; k += 64) {
     XYZZ<Fq> p = xyzz_load<Fq>(in, (size_t)blockIdx.x * n + k);
@@ -400,6 +401,11 @@ __global__ void __launch_bounds__(64) k_fold(const u32* __restrict__ in, u32 n, 
     e.zz = fe_export<Fq>(acc.zz);
     e.zzz = fe_export<Fq>(acc.zzz);
     xyzz_store<Fq>(out, blockIdx.x, e);
+    // the MSM's flag words ride behind the records: one copy takes both to the host
+    if (flags && blockIdx.x == 0) {
+      out[(size_t)gridDim.x * (4 * Fq::W)] = flags[0];
+      out[(size_t)gridDim.x * (4 * Fq::W) + 1] = flags[1];
+    }
   }
 }
 
@@ -415,10 +421,13 @@ __global__ void __launch_bounds__(256)
   if (t < g.red_threads) {
     u32 lo = t * g.red_s;
     XYZZ<Fq> run = xyzz_inf<Fq>(), sum = xyzz_inf<Fq>();
+    XYZZ<Fq> bk = xyzz_load<Fq>(buckets, (size_t)set * g.nb + lo + g.red_s - 1);
     for (int k = (int)g.red_s - 1; k >= 0; k--) {
-      XYZZ<Fq> bk = xyzz_load<Fq>(buckets, (size_t)set * g.nb + lo + k);
+      XYZZ<Fq> nx = bk;  // the next bucket is requested before this one's two additions
+      if (k > 0) nx = xyzz_load<Fq>(buckets, (size_t)set * g.nb + lo + k - 1);
       xyzz_add_quad<Fq>(run, bk);
       xyzz_add_quad<Fq>(sum, run);
+      bk = nx;
     }
     total = xyzz_mul_small_quad<Fq>(run, lo);
     xyzz_add_quad<Fq>(total, sum);
@@ -427,11 +436,18 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)set * gridDim.x + blockIdx.x, total);
 }
 template <class Fq>
-__global__ void __launch_bounds__(64) k_fold_quad(const u32* __restrict__ in, u32 n, u32* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_fold_quad(const u32* __restrict__ in, u32 n, u32* __restrict__ out,
+                                                  const u32* __restrict__ flags) {
   XYZZ<Fq> acc = xyzz_inf<Fq>();
-  for (u32 k = threadIdx.x >> 2; k < n; k += 16) {  // 16 quads
-    XYZZ<Fq> p = xyzz_load<Fq>(in, (size_t)blockIdx.x * n + k);
-    xyzz_add_quad<Fq>(acc, p);
+  {
+    const u32 k0 = threadIdx.x >> 2;  // 16 quads
+    XYZZ<Fq> p = k0 < n ? xyzz_load<Fq>(in, (size_t)blockIdx.x * n + k0) : acc;
+    for (u32 k = k0; k < n; k += 16) {
+      XYZZ<Fq> nx = p;
+      if (k + 16 < n) nx = xyzz_load<Fq>(in, (size_t)blockIdx.x * n + k + 16);
+      xyzz_add_quad<Fq>(acc, p);
+      p = nx;
+    }
   }
   wave_reduce_xyzz_quad<Fq>(acc);
   if (threadIdx.x == 0) {
@@ -441,6 +457,11 @@ __global__ void __launch_bounds__(64) k_fold_quad(const u32* __restrict__ in, u3
     e.zz = fe_export<Fq>(acc.zz);
     e.zzz = fe_export<Fq>(acc.zzz);
     xyzz_store<Fq>(out, blockIdx.x, e);
+    // the MSM's flag words ride behind the records: one copy takes both to the host
+    if (flags && blockIdx.x == 0) {
+      out[(size_t)gridDim.x * (4 * Fq::W)] = flags[0];
+      out[(size_t)gridDim.x * (4 * Fq::W) + 1] = flags[1];
+    }
   }
 }
 

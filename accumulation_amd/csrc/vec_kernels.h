@@ -244,6 +244,78 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x == 0) fe_store<Fr>(out + (size_t)blockIdx.x * 8, fe_load<Fr>(lds));
 }
 
+// two inner products in one launch (an IPA round's <c_r, z_l> and <c_l, z_r>): blockIdx.y picks the pair;
+// out[y * gridDim.x + blockIdx.x] = this workgroup's partial sum
+template <class Fr>
+__global__ void __launch_bounds__(256)
+    k_vec_inner_product_pair(const u32* __restrict__ a0, const u32* __restrict__ b0, const u32* __restrict__ a1,
+                             const u32* __restrict__ b1, u32 n, u32* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u32 lds[256 * 8];
+  const u32* a = blockIdx.y ? a1 : a0;
+  const u32* b = blockIdx.y ? b1 : b0;
+  Fe<Fr> acc = fe_zero<Fr>();
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    acc = fe_add<Fr>(acc, fe_mul<Fr>(fe_load<Fr>(a + (size_t)i * 8), fe_load<Fr>(b + (size_t)i * 8)));
+  fe_store<Fr>(lds + threadIdx.x * 8, acc);
+  __syncthreads();
+  for (u32 s = 128; s >= 1; s >>= 1) {
+    if (threadIdx.x < s) {
+      Fe<Fr> x = fe_load<Fr>(lds + threadIdx.x * 8), y = fe_load<Fr>(lds + (threadIdx.x + s) * 8);
+      fe_store<Fr>(lds + threadIdx.x * 8, fe_add<Fr>(x, y));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fe_store<Fr>(out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8, fe_load<Fr>(lds));
+}
+
+// An IPA round's vector work in ONE launch (three dispatches otherwise, each a launch latency on an idle GPU): the previous
+// round's fold, in place, c[i] += x^-1 c[cur + i], z[i] += x z[cur + i] (i < cur = 2 half), and on the folded vectors the
+// two inner products <c_r, z_l>, <c_l, z_r> (halves of length `half`).  Lane i owns elements i and half + i of both
+// vectors: it reads and writes nothing another lane touches.  out: as k_vec_inner_product_pair.
+struct IpaFoldArgs {
+  u32 x[8], xinv[8];
+};
+template <class Fr>
+__global__ void __launch_bounds__(256) k_ipa_fold_ip(u32* __restrict__ c, u32* __restrict__ z, u32 half, IpaFoldArgs a,
+                                                     u32* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u32 lds[256 * 8];
+  Fe<Fr> x, xinv;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    x.v[k] = a.x[k];
+    xinv.v[k] = a.xinv[k];
+  }
+  const size_t cur = (size_t)2 * half;
+  Fe<Fr> acc0 = fe_zero<Fr>(), acc1 = fe_zero<Fr>();
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < half; i += gridDim.x * blockDim.x) {
+    const size_t lo = (size_t)i * 8, hi = ((size_t)half + i) * 8;
+    Fe<Fr> cl = fe_add<Fr>(fe_load<Fr>(c + lo), fe_mul<Fr>(xinv, fe_load<Fr>(c + cur * 8 + lo)));
+    Fe<Fr> cr = fe_add<Fr>(fe_load<Fr>(c + hi), fe_mul<Fr>(xinv, fe_load<Fr>(c + cur * 8 + hi)));
+    Fe<Fr> zl = fe_add<Fr>(fe_load<Fr>(z + lo), fe_mul<Fr>(x, fe_load<Fr>(z + cur * 8 + lo)));
+    Fe<Fr> zr = fe_add<Fr>(fe_load<Fr>(z + hi), fe_mul<Fr>(x, fe_load<Fr>(z + cur * 8 + hi)));
+    fe_store<Fr>(c + lo, cl);
+    fe_store<Fr>(c + hi, cr);
+    fe_store<Fr>(z + lo, zl);
+    fe_store<Fr>(z + hi, zr);
+    acc0 = fe_add<Fr>(acc0, fe_mul<Fr>(cr, zl));
+    acc1 = fe_add<Fr>(acc1, fe_mul<Fr>(cl, zr));
+  }
+#pragma unroll 1
+  for (int which = 0; which < 2; which++) {
+    fe_store<Fr>(lds + threadIdx.x * 8, which ? acc1 : acc0);
+    __syncthreads();
+    for (u32 s = 128; s >= 1; s >>= 1) {
+      if (threadIdx.x < s) {
+        Fe<Fr> p = fe_load<Fr>(lds + threadIdx.x * 8), q = fe_load<Fr>(lds + (threadIdx.x + s) * 8);
+        fe_store<Fr>(lds + threadIdx.x * 8, fe_add<Fr>(p, q));
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) fe_store<Fr>(out + ((size_t)which * gridDim.x + blockIdx.x) * 8, fe_load<Fr>(lds));
+    __syncthreads();
+  }
+}
+
 // coefficients of the succinct-check polynomial h(X) = prod_{i=1..k} (1 + xi_i X^(2^(k-i)))
 // (`SuccinctCheckPolynomial::compute_coeffs`, ext; called at src/ipa_pc_as/mod.rs:400): coefficient p is the
 // product of the challenges xi_i whose bit (k-i) is set in p.  challenges in a.coeff[0..k) (k <= VEC_MAX*4).

@@ -119,6 +119,7 @@ SIGNATURES = {
     "amsm_ipa_check_poly_coeffs": (C.c_int, [_vp, _vp, _sz, _vp]),
     "amsm_ipa_round_scalars": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "amsm_ipa_round": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amsm_ipa_round_fused": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amsm_matrix_load": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, C.POINTER(_vp)]),
     "amsm_matrix_rows": (_sz, [_vp]),
     "amsm_matrix_free": (None, [_vp]),

@@ -220,30 +220,30 @@ class InnerProductArgPC:
         xs: List[int] = []
         l_vec, r_vec = [], []
         cur_key, log_key = key, log_n  # the key the current round's scalars are expressed over
+        # One library call per round (amsm_ipa_round_fused): the previous round's fold of c and z (in place), the scalar
+        # expansion, the grouped MSM, both inner products, their h' multiples and one normalisation of L and R.
+        hp_xy = None if h_prime[1] else np.ascontiguousarray(h_prime[0], dtype=np.uint64)
+        prev_x = None
         while n > 1:
             half = n // 2
-            c_l, c_r = coeffs.view(0, half), coeffs.view(half, half)
-            z_l, z_r = z.view(0, half), z.view(half, half)
             j = len(xs) - (log_n - log_key)  # challenges since cur_key was formed
             xi = fr.to_limbs_many(xs[len(xs) - j:]) if j else None
-            # one library call per round: scalar expansion, grouped MSM and both inner products, one synchronisation
             xy = np.zeros((2, 2 * ctx.fq_limbs), dtype=np.uint64)
             inf = np.zeros((2,), dtype=np.uint8)
             ips = np.zeros((2, 4), dtype=np.uint64)
-            ffi.check(ctx._lib.amsm_ipa_round(ctx._h, cur_key._h, _ptr(xi), j, log_key, coeffs.ptr, z.ptr, u_l.ptr, _ptr(xy),
-                                              _ptr(inf), _ptr(ips)), "amsm_ipa_round")
-            l_pt = _lincomb(ctx, [(xy[0], bool(inf[0])), h_prime], [1, fr.from_limbs(ips[0])], fr)   # + <c_r, z_l> h'
-            r_pt = _lincomb(ctx, [(xy[1], bool(inf[1])), h_prime], [1, fr.from_limbs(ips[1])], fr)   # + <c_l, z_r> h'
+            ffi.check(ctx._lib.amsm_ipa_round_fused(ctx._h, cur_key._h, _ptr(xi), j, log_key, coeffs.ptr, z.ptr, _ptr(prev_x),
+                                                    _ptr(hp_xy), u_l.ptr, _ptr(xy), _ptr(inf), _ptr(ips)),
+                      "amsm_ipa_round_fused")
+            l_pt = (xy[0], bool(inf[0]))   # <c_r, key_l> + <c_r, z_l> h'
+            r_pt = (xy[1], bool(inf[1]))   # <c_l, key_r> + <c_l, z_r> h'
             l_vec.append(l_pt)
             r_vec.append(r_pt)
             round_challenge = cls._challenge(fr, [round_challenge.to_bytes(16, "little"), l_pt, r_pt])
-            inv = pow(round_challenge, -1, fr.r)
-            coeffs = combine_vectors(ctx, [c_l, c_r], np.stack([one, fr.to_limbs(inv)]))
-            z = combine_vectors(ctx, [z_l, z_r], np.stack([one, fr.to_limbs(round_challenge)]))
             xs.append(round_challenge)
+            prev_x = fr.to_limbs(round_challenge)
             if len(xs) <= fold_rounds:  # physical fold: the next round sees a key of `half` generators
                 assert j == 0
-                folded = cur_key.fold(half, fr.to_limbs(round_challenge), CHALLENGE_SIZE)
+                folded = cur_key.fold(half, prev_x, CHALLENGE_SIZE)
                 if cur_key is not key:
                     cur_key.free()
                 cur_key, log_key = folded, log_key - 1
@@ -258,7 +258,11 @@ class InnerProductArgPC:
             final_key = fk[0]
         if cur_key is not key:
             cur_key.free()
-        c = fr.from_limbs(coeffs.download()[0])
+        # the last fold happens here: c = c_0 + x^-1 c_1 over the two coefficients the last round left
+        head = coeffs.view(0, min(2, coeffs.n)).download()
+        c = fr.from_limbs(head[0])
+        if xs:
+            c = (c + pow(xs[-1], -1, fr.r) * fr.from_limbs(head[1])) % fr.r
         return Proof(l_vec, r_vec, (final_key, not final_key.any()), c, hiding_comm, proof_rand)
 
     @staticmethod

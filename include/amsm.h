@@ -344,6 +344,19 @@ int amsm_ipa_round_scalars(amsm_ctx* ctx, const uint64_t* xi_mont, size_t j, siz
 int amsm_ipa_round(amsm_ctx* ctx, const amsm_bases* key, const uint64_t* xi_mont, size_t j, size_t log_key,
                    const void* d_coeffs, const void* d_z, void* d_u, uint64_t* out_lr_xy, uint8_t* out_lr_inf,
                    uint64_t* out_ip_mont);
+/* amsm_ipa_round with the round's host algebra behind the same call (the opening loop of ext, under
+ * src/ipa_pc_as/mod.rs:454, per round: `l = cm_commit(key_l, c_r) + h' <c_r, z_l>`, `r = ...`, then
+ * `c_l += x^-1 c_r; z_l += x z_r`):
+ *  - fold_x_mont != NULL: the PREVIOUS round's challenge x; d_coeffs / d_z still hold that round's vectors
+ *    (2^(log_key - j + 1) elements) and are folded in place first, c[i] += x^-1 c[cur + i], z[i] += x z[cur + i],
+ *    cur = 2^(log_key - j); the round then runs on their first cur elements.  x = 0 is AMSM_E_INVALID_ARG.
+ *  - h_prime_xy != NULL (affine, Montgomery, finite): out_lr = L_j + <c_r, z_l> h', R_j + <c_l, z_r> h' -- the two
+ *    multiples are computed on the host while the MSM's tail runs, added in extended coordinates and L, R normalised
+ *    with ONE inversion (amsm_ipa_round + two amsm_host_lincomb calls: three).
+ * With both NULL it is amsm_ipa_round.  The driver's loop is one call per round plus the round's challenge. */
+int amsm_ipa_round_fused(amsm_ctx* ctx, const amsm_bases* key, const uint64_t* xi_mont, size_t j, size_t log_key,
+                         void* d_coeffs, void* d_z, const uint64_t* fold_x_mont, const uint64_t* h_prime_xy, void* d_u,
+                         uint64_t* out_lr_xy, uint8_t* out_lr_inf, uint64_t* out_ip_mont);
 /* d_out[p] (p < 2^k) = coefficients of prod_{i=1..k} (1 + xi_i X^(2^(k-i))):
  * `SuccinctCheckPolynomial::compute_coeffs` (ext), call sites src/ipa_pc_as/mod.rs:400 and under :836. k <= 32. */
 int amsm_ipa_check_poly_coeffs(amsm_ctx* ctx, const uint64_t* xi_mont, size_t k, void* d_out);

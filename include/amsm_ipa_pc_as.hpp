@@ -250,33 +250,28 @@ struct InnerProductArgPC {
     const amsm::CommitterKey* cur_key = &key;
     size_t log_key = log_n;
     size_t cur = n;
+    // One library call per round (amsm_ipa_round_fused): the previous round's fold of c and z (in place), the scalar
+    // expansion, the grouped MSM, both inner products, their h' multiples and one normalisation of L and R.
+    const size_t w = 2 * (size_t)ctx.fq_limbs();
     while (cur > 1) {
       size_t half = cur / 2, j = xs.size() - (log_n - log_key);  // challenges since cur_key was formed
-      // one library call per round: scalar expansion, grouped MSM and both inner products, one synchronisation
-      const size_t w = 2 * (size_t)ctx.fq_limbs();
       std::vector<uint64_t> lr_xy(2 * w);
       uint8_t lr_inf[2] = {0, 0};
-      Fr ips[2];
-      amsm::check(amsm_ipa_round(ctx.get(), cur_key->get(), j ? reinterpret_cast<const uint64_t*>(xs.data() + (xs.size() - j)) : nullptr, j,
-                                 log_key, coeffs.ptr(), z.ptr(), u.ptr(), lr_xy.data(), lr_inf, reinterpret_cast<uint64_t*>(ips)),
-                  "amsm_ipa_round");
+      Fr ips[2];  // <c_r, z_l>, <c_l, z_r>
+      amsm::check(amsm_ipa_round_fused(ctx.get(), cur_key->get(), j ? reinterpret_cast<const uint64_t*>(xs.data() + (xs.size() - j)) : nullptr,
+                                       j, log_key, coeffs.ptr(), z.ptr(), xs.empty() ? nullptr : xs.back().data(),
+                                       h_prime.infinity ? nullptr : h_prime.xy.data(), u.ptr(), lr_xy.data(), lr_inf,
+                                       reinterpret_cast<uint64_t*>(ips)),
+                  "amsm_ipa_round_fused");
       Affine lr[2];
       for (int g = 0; g < 2; g++) {
         lr[g].xy.assign(lr_xy.begin() + (long)(g * w), lr_xy.begin() + (long)((g + 1) * w));
         lr[g].infinity = lr_inf[g] != 0;
       }
-      const Fr &ip_l = ips[0], &ip_r = ips[1];  // <c_r, z_l>, <c_l, z_r>
-      Affine l_pt = host_lincomb(ctx, {&lr[0], &h_prime}, {one, ip_l});
-      Affine r_pt = host_lincomb(ctx, {&lr[1], &h_prime}, {one, ip_r});
-      proof.l_vec.push_back(l_pt);
-      proof.r_vec.push_back(r_pt);
-      rc_canon = Challenge(fr).bytes(le_bytes(rc_canon, 16)).point(l_pt).point(r_pt).squeeze_canonical();
+      proof.l_vec.push_back(lr[0]);
+      proof.r_vec.push_back(lr[1]);
+      rc_canon = Challenge(fr).bytes(le_bytes(rc_canon, 16)).point(lr[0]).point(lr[1]).squeeze_canonical();
       round_challenge = fr.to_mont(rc_canon);
-      Fr inv = fr.inv(round_challenge);
-      FrVector nc = combine2(ctx, at(coeffs, 0), half, one, at(coeffs, half), half, inv, half);
-      FrVector nz = combine2(ctx, at(z, 0), half, one, at(z, half), half, round_challenge, half);
-      coeffs = std::move(nc);
-      z = std::move(nz);
       xs.push_back(round_challenge);
       if (xs.size() <= n_fold) {  // physical fold: the next round sees a key of `half` generators
         folded.reset(new amsm::CommitterKey(cur_key->fold(half, round_challenge, CHALLENGE_SIZE)));
@@ -293,7 +288,12 @@ struct InnerProductArgPC {
       proof.final_comm_key.xy = cur_key->read(0, 1);
       proof.final_comm_key.infinity = false;
     }
-    proof.c = coeffs.to_host().at(0);
+    // the last fold happens here: c = c_0 + x^-1 c_1 over the two coefficients the last round left
+    {
+      std::vector<Fr> head(std::min<size_t>(2, n));
+      amsm::check(amsm_dev_download(ctx.get(), head.data(), coeffs.ptr(), head.size() * sizeof(Fr)), "amsm_dev_download");
+      proof.c = xs.empty() ? head.at(0) : fr.add(head.at(0), fr.mul(fr.inv(xs.back()), head.at(1)));
+    }
     proof.hiding_comm = hiding_comm;
     proof.rand = proof_rand;
     return proof;

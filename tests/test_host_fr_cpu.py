@@ -94,3 +94,23 @@ def test_host_lincomb_vs_oracle(built_lib, c):
         sel = [bases[(rnd + j) % 7] for j in range(1 + rnd % 6)]
         sc = [o.rng_scalar(90 + rnd, j) % c.r for j in range(len(sel))]
         assert lincomb(sel, sc) == expect(sel, sc), rnd
+
+
+@pytest.mark.parametrize("c", [o.PALLAS, o.BLS12_381_G1], ids=lambda c: c.name)
+def test_host_fr_inverse_many(built_lib, c):
+    """amsm_fr_inv (binary extended Euclid on the host) against Python's modular inverse: small values, powers of two and
+    their neighbours (long runs of halvings), values next to the modulus, and random ones."""
+    from accumulation_amd import ffi
+    from accumulation_amd.engine import _ptr
+    lib = ffi.load()
+    R = 1 << 256
+    vals = list(range(0, 40)) + [c.r - k for k in range(1, 40)]
+    vals += [(1 << k) % c.r for k in range(1, 256, 5)] + [((1 << k) - 1) % c.r for k in range(2, 256, 7)]
+    vals += [((1 << k) + 1) % c.r for k in range(2, 256, 9)] + [(c.r - 1) // 2, (c.r + 1) // 2, c.r // 3]
+    vals += [o.rng_scalar(0x1A7, i) % c.r for i in range(600)]
+    n = len(vals)
+    a = h.scalars_to_np(vals)
+    am, inv = np.zeros_like(a), np.zeros_like(a)
+    ffi.check(lib.amsm_fr_to_mont(c.curve_id, _ptr(a), n, _ptr(am)), "to_mont")
+    ffi.check(lib.amsm_fr_inv(c.curve_id, _ptr(am), n, _ptr(inv)), "inv")
+    assert h.np_to_ints(inv) == [(pow(x, -1, c.r) if x else 0) * R % c.r for x in vals]

@@ -326,3 +326,69 @@ def test_ipa_round_entry_point_equals_its_parts(env):
     assert ctx._lib.amsm_ipa_round(ctx._h, key._h, None, 0, 7, coeffs.ptr, z.ptr, u.ptr, _ptr(xy), _ptr(inf), _ptr(ips)) == \
         ffi.AMSM_E_INVALID_ARG  # 2^7 generators asked of a 64-point key
     key.free()
+
+
+def test_ipa_round_fused_equals_round_plus_host_algebra(env):
+    """amsm_ipa_round_fused (previous fold in place + round + h' terms, one normalisation) against amsm_ipa_round followed
+    by the driver's own algebra (amsm_vec_combine folds, amsm_host_lincomb for the h' terms): rounds 1 and 3 of a
+    64-point key, with and without the fold / the h' term."""
+    from accumulation_amd import CommitterKey, ffi
+    from accumulation_amd.engine import _ptr
+    from accumulation_amd.hp_as import combine_vectors
+    from accumulation_amd.ipa_pc import _lincomb
+    from accumulation_amd.scalar_field import Fr
+    ctx, _ = env
+    c = o.PALLAS
+    fr = Fr(ctx.curve)
+    log_key = 6
+    key = CommitterKey.load(ctx, h.points_to_np(c, o.rng_points(c, 0x1F, 64))[0], None, ffi.AMSM_BASES_DEFAULT)
+    hp_xy, hp_inf = h.points_to_np(c, o.rng_points(c, 0x5F, 1))
+    h_prime = (hp_xy[0], False)
+    xs_all = [o.rng_scalar(0x2F, i) % (1 << 128) for i in range(4)]
+    one = fr.to_limbs(1)
+    for j in (1, 3):
+        for with_fold in (False, True):
+            for with_h in (False, True):
+                m = 1 << (log_key - j)  # length of the round's vectors
+                pre = 2 * m if with_fold else m
+                cv = [o.rng_scalar(0x6F + j, i) % c.r for i in range(pre)]
+                zv = [o.rng_scalar(0x7F + j, i) % c.r for i in range(pre)]
+                x = xs_all[j - 1]
+                xi = fr.to_limbs_many(xs_all[:j])
+                # expected: fold with the vector kernels, plain round, host algebra
+                coeffs, z = ctx.upload(h.fr_mont_np(c, cv)), ctx.upload(h.fr_mont_np(c, zv))
+                if with_fold:
+                    coeffs = combine_vectors(ctx, [coeffs.view(0, m), coeffs.view(m, m)],
+                                             np.stack([one, fr.to_limbs(pow(x, -1, c.r))]))
+                    z = combine_vectors(ctx, [z.view(0, m), z.view(m, m)], np.stack([one, fr.to_limbs(x)]))
+                u = ctx.vector(64)
+                exy = np.zeros((2, 2 * ctx.fq_limbs), dtype=np.uint64)
+                einf = np.zeros((2,), dtype=np.uint8)
+                eips = np.zeros((2, 4), dtype=np.uint64)
+                ffi.check(ctx._lib.amsm_ipa_round(ctx._h, key._h, _ptr(xi), j, log_key, coeffs.ptr, z.ptr, u.ptr, _ptr(exy),
+                                                  _ptr(einf), _ptr(eips)), "amsm_ipa_round")
+                expect = [(exy[g].copy(), bool(einf[g])) for g in range(2)]
+                if with_h:
+                    expect = [_lincomb(ctx, [expect[g], h_prime], [1, fr.from_limbs(eips[g])], fr) for g in range(2)]
+                # fused
+                coeffs2, z2 = ctx.upload(h.fr_mont_np(c, cv)), ctx.upload(h.fr_mont_np(c, zv))
+                xy = np.zeros((2, 2 * ctx.fq_limbs), dtype=np.uint64)
+                inf = np.zeros((2,), dtype=np.uint8)
+                ips = np.zeros((2, 4), dtype=np.uint64)
+                fx = fr.to_limbs(x) if with_fold else None
+                hx = np.ascontiguousarray(h_prime[0]) if with_h else None
+                ffi.check(ctx._lib.amsm_ipa_round_fused(ctx._h, key._h, _ptr(xi), j, log_key, coeffs2.ptr, z2.ptr, _ptr(fx),
+                                                        _ptr(hx), u.ptr, _ptr(xy), _ptr(inf), _ptr(ips)), "amsm_ipa_round_fused")
+                tag = (j, with_fold, with_h)
+                assert np.array_equal(ips, eips), tag
+                for g in range(2):
+                    assert np.array_equal(xy[g], expect[g][0]) and bool(inf[g]) == expect[g][1], tag
+                # the buffers now hold the folded vectors in their first m elements, the rest untouched
+                assert np.array_equal(coeffs2.view(0, m).download(), coeffs.view(0, m).download()), tag
+                assert np.array_equal(z2.view(0, m).download(), z.view(0, m).download()), tag
+                if with_fold:
+                    assert np.array_equal(coeffs2.view(m, m).download(), h.fr_mont_np(c, cv[m:])), tag
+    zero = np.zeros(4, dtype=np.uint64)
+    assert ctx._lib.amsm_ipa_round_fused(ctx._h, key._h, _ptr(xi), 3, log_key, coeffs2.ptr, z2.ptr, _ptr(zero), None, u.ptr,
+                                         _ptr(xy), _ptr(inf), _ptr(ips)) == ffi.AMSM_E_INVALID_ARG  # x = 0 has no inverse
+    key.free()
