@@ -256,10 +256,16 @@ inline int ilog2_ceil(size_t n) {
 // that window in a handful of buckets, which then take the heavy-bucket path; c = 8, 10, 13, 15, 16 do not.
 //   precomputed key (all windows share one bucket set): 2^10-2^12 -> 8, 2^13-2^14 -> 10, 2^15 -> 13, 2^16 -> 15,
 //   >= 2^17 -> 16 (2^18: 518 vs 361 Mpairs/s at the old lg-4 rule; 2^22: 774 vs 440).
+//   Round 2: c = 17 from 2^20 up (and at 2^17).  15 windows of 17 bits cover the 255-bit scalars, so the 16th holds only the
+//   recoding's carry -- never set for Pallas (r < 2^254 + 2^126), set for the 45 % of BLS12-381 scalars above 2^254, whose
+//   entries share ONE bucket (heavy-bucket path): 15 instead of 16 entries per scalar.  Same-process A/B against c = 16
+//   (tools/ab_pipeline.py, batches): 2^17 380 vs 370 Mpairs/s, 2^18 562 vs 585, 2^19 757 vs 767, 2^20 862 vs 838, 2^21 870 vs 824,
+//   2^22 854 vs 829; BLS12-381 2^20 379 vs 372.  (c = 18 / 19 need more than the 31 bits of the prep's entry word.)
 //   plain key (one bucket set per window): lg - 6 moved to the nearest width of that list.
 int choose_window(size_t n, bool precomp) {
   int lg = ilog2_ceil(n < 2 ? 2 : n);
   if (precomp) {
+    if (lg >= 20 || lg == 17) return 17;
     if (lg >= 17) return 16;
     if (lg == 16) return 15;
     if (lg == 15) return 13;
@@ -1796,6 +1802,11 @@ int amsm_bases_read(amsm_ctx* c, const amsm_bases* b, size_t off, size_t n, uint
 }
 size_t amsm_bases_len(const amsm_bases* b) { return b ? b->n : 0; }
 int amsm_bases_precomputed(const amsm_bases* b) { return b ? b->precomp : 0; }
+int amsm_bases_window_bits(const amsm_bases* b) {
+  if (!b) return 0;
+  if (!b->shards.empty()) return b->shards[0] ? b->shards[0]->c : 0;
+  return b->precomp ? b->c : 0;
+}
 int amsm_bases_num_shards(const amsm_bases* b) { return !b ? 0 : (key_sharded(b) ? (int)b->shards.size() : 1); }
 int amsm_bases_shard_range(const amsm_bases* b, int g, size_t* lo, size_t* hi) {
   if (!b || !lo || !hi || g < 0 || g >= amsm_bases_num_shards(b)) return AMSM_E_INVALID_ARG;

@@ -357,6 +357,11 @@ class CommitterKey:
     def precomputed(self) -> bool:
         return bool(self.ctx._lib.amsm_bases_precomputed(self._h))
 
+    @property
+    def window_bits(self) -> int:
+        """Window width of a precomputed key, 0 for a plain one."""
+        return int(self.ctx._lib.amsm_bases_window_bits(self._h))
+
     def read(self, off: int = 0, n: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
         n = len(self) - off if n is None else n
         xy = np.empty((n, 2 * self.ctx.fq_limbs), dtype=np.uint64)

@@ -62,6 +62,7 @@ SIGNATURES = {
     "amsm_bases_num_shards": (C.c_int, [_vp]),
     "amsm_bases_shard_range": (C.c_int, [_vp, C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
     "amsm_bases_precomputed": (C.c_int, [_vp]),
+    "amsm_bases_window_bits": (C.c_int, [_vp]),
     "amsm_bases_free": (None, [_vp]),
     "amsm_msm": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_msm_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),

@@ -137,6 +137,10 @@ size_t amsm_bases_len(const amsm_bases* bases);
 int amsm_bases_num_shards(const amsm_bases* bases);
 int amsm_bases_shard_range(const amsm_bases* bases, int g, size_t* lo, size_t* hi);
 int amsm_bases_precomputed(const amsm_bases* bases);
+/* Window width c of a precomputed key (its table holds ceil-ish(256 / c) window multiples of every generator; fixed at
+ * creation from the key's size), 0 for a plain key.  For reporting: an MSM over it gathers one point per non-zero c-bit
+ * digit of every scalar. */
+int amsm_bases_window_bits(const amsm_bases* bases);
 void amsm_bases_free(amsm_bases* bases);
 
 /* ---- MSM ------------------------------------------------------------------------------------ */

@@ -208,6 +208,39 @@ def test_north_star_size_pallas_2_20(ctxs, cref):
     ck.free()
 
 
+def test_carry_window_at_north_star_size(ctxs, cref):
+    """Keys of 2^20 generators and more use 17-bit windows: 15 of them cover the 255-bit scalars and the 16th holds only
+    the signed recoding's carry (amsm_bases_window_bits).  For Pallas that carry needs a scalar
+    above 2^254 -- one in 2^128 at random -- so the batch path would never see it in the other tests: here every 997th
+    scalar sits at the top of the field (r - 1, r - 2, 2^254 + k), and one vector is ALL r - 1 (every entry of the carry
+    window in ONE bucket).  Bit-exact against the CPU restatement, blocking and in a batch."""
+    from accumulation_amd import CommitterKey, VariableBaseMSM, ffi
+    c = o.PALLAS
+    ctx = ctxs[c.name]
+    n = 1 << 20
+    ck = CommitterKey.generate(ctx, 0x5EED1011, n)
+    assert ck.precomputed and ck.window_bits == 17
+    small = CommitterKey.generate(ctx, 0x5EED1012, 1 << 18)
+    plain = CommitterKey.generate(ctx, 0x5EED1013, 1 << 10, ffi.AMSM_BASES_NO_PRECOMPUTE)
+    assert small.window_bits == 16 and plain.window_bits == 0
+    small.free()
+    plain.free()
+    sc = ctx.random_vector(0x5EED0011, n, mont=False).download()
+    top = [c.r - 1, c.r - 2, 1 << 254, (1 << 254) + 12345, c.r - (1 << 200)]
+    for k, i in enumerate(range(0, n, 997)):
+        sc[i] = h.scalars_to_np([top[k % len(top)]])[0]
+    all_top = np.tile(h.scalars_to_np([c.r - 1])[0], (n, 1))
+    xy, _ = ck.read()
+    dv, dt = ctx.upload(sc), ctx.upload(all_top)
+    for vec, host in ((dv, sc), (dt, all_top)):
+        ref, rinf = cref.msm(c.curve_id, xy, host, threads=17)
+        out, oinf = VariableBaseMSM.multi_scalar_mul(ck, vec)
+        assert oinf == rinf and np.array_equal(out, ref)
+        outs, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [vec, dv, vec], mont=False)
+        assert np.array_equal(outs[0], ref) and np.array_equal(outs[2], ref) and not infs.any()
+    ck.free()
+
+
 def test_config5_size_pallas_2_22(ctxs, cref):
     """BASELINE.json config 5 size: 2^22 Pallas pairs (4 GiB of precomputed key).  Size-independent properties --
     the whole MSM equals the sum of the MSMs over its four 2^20-generator windows, and commit(a + 3b) = commit(a) +

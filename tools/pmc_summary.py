@@ -23,7 +23,8 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
         if "k_accum_l0" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = {k: sum(v) / len(v) for k, v in sorted(acc.items())}
-n, windows = 1 << 20, 16
+# windows that hold digits: 15 at c = 17 (the default for 2^20 since round 2), 16 at c = 16 (AMSM_WINDOW=16); argv[3] overrides
+n, windows = 1 << 20, (int(sys.argv[3]) if len(sys.argv) > 3 else 15)
 entries = n * windows
 stream_bytes = entries * 4  # entry words, read once (dwordx4 per 4 entries)
 fetch = mean.get("FETCH_SIZE", 0.0) * 1024.0
@@ -32,14 +33,14 @@ write = mean.get("WRITE_SIZE", 0.0) * 1024.0
 true_fetch = (fetch - stream_bytes / 2.0) + stream_bytes if fetch else 0.0
 out = {
     "kernel": "k_accum_l0",
-    "workload": "2^20 Pallas, precomputed key (c = 16, W = 16), bench.py --sync",
+    "workload": f"2^20 Pallas, precomputed key ({windows} entries per scalar), bench.py --sync",
     "launches_averaged": {k: len(v) for k, v in sorted(acc.items())},
     "counters_mean_per_launch": mean,
     "fetch_bytes_counter_x1": fetch,
     "fetch_bytes_counter_x2": 2.0 * fetch,
     "hbm_traffic_bytes_per_launch": true_fetch + write,
     "correction": "FETCH_SIZE KiB x1.00 for the random 64-B-record LDS-DMA gather (calibrated, tools/calib_gather.hip) and "
-                  "x2.00 for the 64 MiB of streamed entry words (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
+                  "x2.00 for the streamed entry words (4 B each) (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
     "algorithmic_bytes_per_launch": n * 96,
     "gather_bytes_if_every_point_missed_cache": entries * 64,
 }
