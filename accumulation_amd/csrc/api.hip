@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -110,6 +111,43 @@ struct ShardWorker {  // one persistent host thread per non-primary shard
     }
     cv.notify_all();
     if (th.joinable()) th.join();
+  }
+};
+
+// Host threads for the schemes' host-side group algebra (amsm_host_lincomb[_batch]: rows a11 of the scope table -- the
+// blinded commitments, the beta-combinations, the IPA verifier's 2 log n + 2 point combination are 50-500 us each and come
+// in independent groups).  A small persistent pool; the caller works too.  AMSM_HOST_THREADS=0 disables it (default: up
+// to 3 helpers).  One parallel region at a time: a second caller that finds the pool busy runs its tasks itself.
+struct HostPool {
+  std::vector<std::unique_ptr<ShardWorker>> workers;
+  std::mutex busy;
+  HostPool() {
+    int want = 3;
+    if (const char* e = getenv("AMSM_HOST_THREADS")) want = atoi(e);
+    const int hw = (int)std::thread::hardware_concurrency();
+    want = std::max(0, std::min(want, std::min(15, hw > 1 ? hw - 1 : 0)));
+    for (int i = 0; i < want; i++) workers.emplace_back(new ShardWorker());
+  }
+  static HostPool& get() {
+    static HostPool pool;
+    return pool;
+  }
+  // fn(i) for i in [0, n), each exactly once
+  template <class F>
+  void run(size_t n, F&& fn) {
+    std::unique_lock<std::mutex> lk(busy, std::try_to_lock);
+    if (!lk.owns_lock() || workers.empty() || n < 2) {
+      for (size_t i = 0; i < n; i++) fn(i);
+      return;
+    }
+    std::atomic<size_t> next{0};
+    auto loop = [&] {
+      for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(i);
+    };
+    const size_t helpers = std::min(workers.size(), n - 1);
+    for (size_t w = 0; w < helpers; w++) workers[w]->submit(loop);
+    loop();
+    for (size_t w = 0; w < helpers; w++) workers[w]->wait();
   }
 };
 
@@ -1002,15 +1040,29 @@ host::HXYZZ<Fq> host_mul_cached(const uint64_t* xy, const host::HFe<Fr>& k_mont)
   return fb ? fb->mul(k.v) : host::hx_mul<Fq>(p, k.v);
 }
 
+// sum_i k_i P_i as an XYZZ point (k Montgomery).  Jobs of LINCOMB_SPLIT_MIN points and more are split over the host pool:
+// every part pays the shared doublings again (128 for challenge-sized scalars) but the additions -- 32 per point -- divide.
+constexpr size_t LINCOMB_SPLIT_MIN = 8;
 template <class Fq, class Fr>
-int host_lincomb_impl(const uint64_t* xy, const uint8_t* is_inf, const uint64_t* scalars_mont, size_t n,
-                      uint64_t* out_xy, uint8_t* out_inf) {
+host::HXYZZ<Fq> host_lincomb_xyzz(const uint64_t* xy, const uint8_t* is_inf, const uint64_t* scalars_mont, size_t n,
+                                  bool may_split) {
   constexpr int N = host::HFe<Fq>::N;
+  if (may_split && n >= LINCOMB_SPLIT_MIN && !HostPool::get().workers.empty()) {
+    const size_t parts = std::min(HostPool::get().workers.size() + 1, n / (LINCOMB_SPLIT_MIN / 2));
+    std::vector<host::HXYZZ<Fq>> part(parts, host::hx_inf<Fq>());
+    HostPool::get().run(parts, [&](size_t t) {
+      const size_t lo = n * t / parts, hi = n * (t + 1) / parts;
+      part[t] = host_lincomb_xyzz<Fq, Fr>(xy + lo * 2 * N, is_inf ? is_inf + lo : nullptr, scalars_mont + 4 * lo, hi - lo, false);
+    });
+    host::HXYZZ<Fq> acc = part[0];
+    for (size_t t = 1; t < parts; t++) acc = host::hx_add<Fq>(acc, part[t]);
+    return acc;
+  }
   std::vector<host::HXYZZ<Fq>> pts(n);
   std::vector<std::array<uint64_t, 4>> ks(n);
   std::vector<const host::HFixedBase<Fq>*> fixed(n, nullptr);
   const bool use_cache = fixed_base_enabled();
-  FixedBaseCache<Fq>& cache = fixed_base_cache<Fq>();
+  FixedBaseCache<Fq>& cache = fixed_base_cache<Fq>();  // per thread
   cache.call++;
   for (size_t i = 0; i < n; i++) {
     host::HFe<Fr> s;
@@ -1021,8 +1073,26 @@ int host_lincomb_impl(const uint64_t* xy, const uint8_t* is_inf, const uint64_t*
     if (use_cache && !host::hx_is_inf<Fq>(pts[i]) && host::hx_scalar_bits(s.v) > 128)
       fixed[i] = cache.lookup(xy + i * 2 * N, pts[i]);
   }
-  host::HXYZZ<Fq> acc = host::hx_lincomb<Fq>(pts.data(), reinterpret_cast<const uint64_t(*)[4]>(ks.data()), n, fixed.data());
-  write_affine<Fq>(acc, out_xy, out_inf);
+  return host::hx_lincomb<Fq>(pts.data(), reinterpret_cast<const uint64_t(*)[4]>(ks.data()), n, fixed.data());
+}
+
+template <class Fq, class Fr>
+int host_lincomb_impl(const uint64_t* xy, const uint8_t* is_inf, const uint64_t* scalars_mont, size_t n,
+                      uint64_t* out_xy, uint8_t* out_inf) {
+  write_affine<Fq>(host_lincomb_xyzz<Fq, Fr>(xy, is_inf, scalars_mont, n, true), out_xy, out_inf);
+  return AMSM_OK;
+}
+
+// independent combinations, one per pool task (large ones are not split again: the pool is taken), ONE batched normalisation
+template <class Fq, class Fr>
+int host_lincomb_batch_impl(size_t n_jobs, const size_t* n_terms, const uint64_t* const* xy, const uint8_t* const* is_inf,
+                            const uint64_t* const* scalars_mont, uint64_t* out_xy, uint8_t* out_inf) {
+  std::vector<host::HXYZZ<Fq>> r(n_jobs, host::hx_inf<Fq>());
+  HostPool::get().run(n_jobs, [&](size_t j) {
+    r[j] = host_lincomb_xyzz<Fq, Fr>(xy[j], is_inf ? is_inf[j] : nullptr, scalars_mont[j], n_terms[j], false);
+  });
+  if (out_inf) memset(out_inf, 0, n_jobs);
+  write_affine_batch<Fq>(r, out_xy, out_inf);
   return AMSM_OK;
 }
 
@@ -2021,6 +2091,18 @@ int amsm_host_lincomb(int curve, const uint64_t* xy, const uint8_t* is_inf, cons
   if (curve == AMSM_PALLAS) return host_lincomb_impl<PallasFq, PallasFr>(xy, is_inf, scalars_mont, n, out_xy, out_inf);
   if (curve == AMSM_BLS12_381_G1)
     return host_lincomb_impl<Bls12381Fq, Bls12381Fr>(xy, is_inf, scalars_mont, n, out_xy, out_inf);
+  return AMSM_E_INVALID_ARG;
+}
+
+int amsm_host_lincomb_batch(int curve, size_t n_jobs, const size_t* n_terms, const uint64_t* const* xy, const uint8_t* const* is_inf,
+                            const uint64_t* const* scalars_mont, uint64_t* out_xy, uint8_t* out_inf) {
+  if (n_jobs && (!n_terms || !xy || !scalars_mont || !out_xy)) return AMSM_E_INVALID_ARG;
+  for (size_t j = 0; j < n_jobs; j++)
+    if (n_terms[j] && (!xy[j] || !scalars_mont[j])) return AMSM_E_INVALID_ARG;
+  if (curve == AMSM_PALLAS)
+    return host_lincomb_batch_impl<PallasFq, PallasFr>(n_jobs, n_terms, xy, is_inf, scalars_mont, out_xy, out_inf);
+  if (curve == AMSM_BLS12_381_G1)
+    return host_lincomb_batch_impl<Bls12381Fq, Bls12381Fr>(n_jobs, n_terms, xy, is_inf, scalars_mont, out_xy, out_inf);
   return AMSM_E_INVALID_ARG;
 }
 

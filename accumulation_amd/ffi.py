@@ -78,6 +78,7 @@ SIGNATURES = {
     "amsm_pedersen_commit": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "amsm_pedersen_commit_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "amsm_host_lincomb": (C.c_int, [C.c_int, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "amsm_host_lincomb_batch": (C.c_int, [C.c_int, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amsm_fr_mul": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),
     "amsm_fr_add": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),
     "amsm_fr_sub": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),

@@ -260,6 +260,35 @@ class ASForHadamardProducts:
                   "amsm_host_lincomb")
         return (out, bool(inf.value))
 
+    @staticmethod
+    def _lincomb_batch(ctx, jobs, fr: Fr):
+        """Independent host combinations in one library call (amsm_host_lincomb_batch: host threads, one normalisation);
+        jobs = [(points, scalars), ...].  Same results as _lincomb job by job."""
+        nj = len(jobs)
+        if nj == 0:
+            return []
+        w = 2 * ctx.fq_limbs
+        keep = []
+        n_terms = (C.c_size_t * nj)()
+        xy_p, inf_p, sc_p = (C.c_void_p * nj)(), (C.c_void_p * nj)(), (C.c_void_p * nj)()
+        for j, (points, scalars) in enumerate(jobs):
+            k = len(points)
+            n_terms[j] = k
+            xy = np.stack([np.asarray(p[0], dtype=np.uint64) for p in points]) if k else np.zeros((1, w), dtype=np.uint64)
+            infs = np.array([1 if p[1] else 0 for p in points] or [0], dtype=np.uint8)
+            sc = fr.to_limbs_many([s % fr.r for s in scalars[:k]]) if k else np.zeros((1, 4), dtype=np.uint64)
+            keep.append((xy, infs, sc))
+            xy_p[j], inf_p[j], sc_p[j] = xy.ctypes.data, infs.ctypes.data, sc.ctypes.data
+        out = np.zeros((nj, w), dtype=np.uint64)
+        oinf = np.zeros((nj,), dtype=np.uint8)
+        ffi.check(ctx._lib.amsm_host_lincomb_batch(ctx.curve, nj, n_terms, xy_p, inf_p, sc_p, _ptr(out), _ptr(oinf)),
+                  "amsm_host_lincomb_batch")
+        res = []
+        for j in range(nj):
+            inf = bool(oinf[j]) or n_terms[j] == 0
+            res.append((np.zeros((w,), dtype=np.uint64) if inf else out[j].copy(), inf))
+        return res
+
     @classmethod
     def _compute_combined_hp_commitments(cls, ctx, fr, instances, proof: Proof, mu, nu, chi) -> InputInstance:
         """:409-479 (one host linear combination per output commitment)"""
@@ -279,7 +308,8 @@ class ASForHadamardProducts:
             s2.append(mu[1])
             p3.append(hc.comm_3)
             s3.append(mu[n] * nu[n - 1] % fr.r)
-        return InputInstance(cls._lincomb(ctx, p1, s1, fr), cls._lincomb(ctx, p2, s2, fr), cls._lincomb(ctx, p3, s3, fr))
+        c1, c2, c3 = cls._lincomb_batch(ctx, [(p1, s1), (p2, s2), (p3, s3)], fr)  # three independent combinations
+        return InputInstance(c1, c2, c3)
 
     @staticmethod
     def _generate_prover_randomness(pk: CommitterKey, fr: Fr, hp_vec_len: int, witnesses, rng):

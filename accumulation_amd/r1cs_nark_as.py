@@ -152,22 +152,26 @@ class ASForR1CSNark:
     @staticmethod
     def _compute_blinded_commitments(ctx, fr, nark_matrices_hash, input_instances, nark_sponge):
         """:220-286"""
-        L = ASForHadamardProducts._lincomb
-        A, B, Cc, P = [], [], [], []
-        for inst in input_instances:
+        # the four combinations of every input that carries randomness are independent: one batched library call
+        jobs, job_of = [], {}
+        for k, inst in enumerate(input_instances):
             m = inst.first_round_message
-            a, b, c, prod = m.comm_a, m.comm_b, m.comm_c, m.comm_c
-            if m.randomness is not None:
-                g = compute_challenge(fr, nark_matrices_hash, inst.r1cs_input, m, nark_sponge.fork(b""))
-                r = m.randomness
-                a = L(ctx, [a, r.comm_r_a], [1, g], fr)
-                b = L(ctx, [b, r.comm_r_b], [1, g], fr)
-                c = L(ctx, [c, r.comm_r_c], [1, g], fr)
-                prod = L(ctx, [prod, r.comm_1, r.comm_2], [1, g, g * g % fr.r], fr)
-            A.append(a)
-            B.append(b)
-            Cc.append(c)
-            P.append(prod)
+            if m.randomness is None:
+                continue
+            g = compute_challenge(fr, nark_matrices_hash, inst.r1cs_input, m, nark_sponge.fork(b""))
+            r = m.randomness
+            job_of[k] = len(jobs)
+            jobs += [([m.comm_a, r.comm_r_a], [1, g]), ([m.comm_b, r.comm_r_b], [1, g]), ([m.comm_c, r.comm_r_c], [1, g]),
+                     ([m.comm_c, r.comm_1, r.comm_2], [1, g, g * g % fr.r])]
+        res = ASForHadamardProducts._lincomb_batch(ctx, jobs, fr)
+        A, B, Cc, P = [], [], [], []
+        for k, inst in enumerate(input_instances):
+            m = inst.first_round_message
+            j = job_of.get(k)
+            A.append(m.comm_a if j is None else res[j])
+            B.append(m.comm_b if j is None else res[j + 1])
+            Cc.append(m.comm_c if j is None else res[j + 2])
+            P.append(m.comm_c if j is None else res[j + 3])
         return A, B, Cc, P
 
     @staticmethod
@@ -192,7 +196,6 @@ class ASForR1CSNark:
     @staticmethod
     def _instance_components(ctx, fr, input_instances, A, B, Cc, acc_instances, beta, proof_randomness):
         """:452-542: accumulators first, then (blinded) inputs, then the prover's randomness"""
-        L = ASForHadamardProducts._lincomb
         r1cs_inputs = [a.r1cs_input for a in acc_instances] + [i.r1cs_input for i in input_instances]
         ca = [a.comm_a for a in acc_instances] + list(A)
         cb = [a.comm_b for a in acc_instances] + list(B)
@@ -208,7 +211,8 @@ class ASForR1CSNark:
         for j, v in enumerate(r1cs_inputs):
             for i, x in enumerate(v):
                 combined[i] = (combined[i] + beta[j] * x) % fr.r
-        return combined, L(ctx, ca, beta, fr), L(ctx, cb, beta, fr), L(ctx, cc, beta, fr)
+        oa, ob, oc = ASForHadamardProducts._lincomb_batch(ctx, [(ca, beta), (cb, beta), (cc, beta)], fr)
+        return combined, oa, ob, oc
 
     # ---- prove ------------------------------------------------------------------------------------
     @classmethod

@@ -221,6 +221,16 @@ int amsm_pedersen_commit_device(amsm_ctx* ctx, const amsm_bases* ck, const void*
  * counterparts (these stay on the host).  scalars_mont: n*4 u64 Montgomery. */
 int amsm_host_lincomb(int curve, const uint64_t* xy_mont, const uint8_t* is_inf, const uint64_t* scalars_mont,
                       size_t n, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+/* n_jobs INDEPENDENT combinations in one call: job j is sum_i scalars_mont[j][i] * xy_mont[j][i] over n_terms[j] points
+ * (is_inf may be NULL, or hold NULL for a job without points at infinity); out_xy_mont[j], out_is_inf[j] its result.
+ * The groups the provers form -- the four blinded commitments of every input and the three beta-combinations of
+ * src/r1cs_nark_as/mod.rs:220-286,452-542, the three combined commitments of src/hp_as/mod.rs:391-479 -- run on a small
+ * pool of host threads (AMSM_HOST_THREADS, default up to 3 helpers beside the caller; the reference's `parallel` feature
+ * does the same with rayon) and are normalised with one inversion.  A single amsm_host_lincomb of 8 points or more (the IPA
+ * verifier's 2 log n + 2 point combination) is split over the same pool.  Results do not depend on the thread count. */
+int amsm_host_lincomb_batch(int curve, size_t n_jobs, const size_t* n_terms, const uint64_t* const* xy_mont,
+                            const uint8_t* const* is_inf, const uint64_t* const* scalars_mont, uint64_t* out_xy_mont,
+                            uint8_t* out_is_inf);
 
 /* ---- device buffers for scalar-field vectors ------------------------------------------------- */
 int amsm_dev_alloc(amsm_ctx* ctx, size_t bytes, void** d_ptr);

@@ -216,6 +216,45 @@ inline Affine host_lincomb(Context& ctx, const std::vector<const Affine*>& point
   return out;
 }
 
+// host: independent combinations in one library call (amsm_host_lincomb_batch: a small pool of host threads, one
+// normalisation); jobs[j] = (points, Montgomery scalars).  Same results as host_lincomb job by job.
+using LincombJob = std::pair<std::vector<const Affine*>, std::vector<Fr>>;
+inline std::vector<Affine> host_lincomb_batch(Context& ctx, const std::vector<LincombJob>& jobs) {
+  const size_t nj = jobs.size(), w = 2 * (size_t)ctx.fq_limbs();
+  std::vector<Affine> out(nj);
+  if (nj == 0) return out;
+  std::vector<std::vector<uint64_t>> xy(nj);
+  std::vector<std::vector<uint8_t>> inf(nj);
+  std::vector<size_t> n_terms(nj);
+  std::vector<const uint64_t*> xy_p(nj), sc_p(nj);
+  std::vector<const uint8_t*> inf_p(nj);
+  for (size_t j = 0; j < nj; j++) {
+    const size_t k = jobs[j].first.size();
+    if (jobs[j].second.size() < k) throw Error(AMSM_E_INVALID_ARG, "host_lincomb_batch: fewer scalars than points");
+    n_terms[j] = k;
+    xy[j].resize(k * w);
+    inf[j].resize(k);
+    for (size_t i = 0; i < k; i++) {
+      std::copy(jobs[j].first[i]->xy.begin(), jobs[j].first[i]->xy.end(), xy[j].begin() + (long)(i * w));
+      inf[j][i] = jobs[j].first[i]->infinity ? 1 : 0;
+    }
+    xy_p[j] = xy[j].data();
+    inf_p[j] = inf[j].data();
+    sc_p[j] = reinterpret_cast<const uint64_t*>(jobs[j].second.data());
+  }
+  std::vector<uint64_t> oxy(nj * w);
+  std::vector<uint8_t> oinf(nj, 0);
+  check(amsm_host_lincomb_batch(amsm_ctx_curve(ctx.get()), nj, n_terms.data(), xy_p.data(), inf_p.data(), sc_p.data(), oxy.data(),
+                                oinf.data()),
+        "amsm_host_lincomb_batch");
+  for (size_t j = 0; j < nj; j++) {
+    out[j].infinity = oinf[j] != 0 || n_terms[j] == 0;
+    if (out[j].infinity) out[j].xy.assign(w, 0);
+    else out[j].xy.assign(oxy.begin() + (long)(j * w), oxy.begin() + (long)((j + 1) * w));
+  }
+  return out;
+}
+
 // ---- data structures (src/hp_as/data_structures.rs) ------------------------------------------------------------
 struct InputInstance {  // :14-33
   Affine comm_1, comm_2, comm_3;
@@ -531,7 +570,8 @@ class ASForHadamardProducts {
       p3.push_back(&proof.hiding_comms->comm_3);
       s3.push_back(fr.mul(mu[n], nu[n - 1]));
     }
-    return InputInstance{lincomb(ctx, p1, s1), lincomb(ctx, p2, s2), lincomb(ctx, p3, s3)};
+    std::vector<Affine> c = host_lincomb_batch(ctx, {{p1, s1}, {p2, s2}, {p3, s3}});  // three independent combinations
+    return InputInstance{c[0], c[1], c[2]};
   }
 };
 

@@ -309,23 +309,31 @@ class ASForR1CSNark {
   static Blinded blinded_commitments(Context& ctx, const FrOps& fr, const std::array<uint8_t, 32>& nark_hash,
                                      const std::vector<const InputInstance*>& instances, const Sponge& nark_sponge) {  // :220-286
     Blinded out;
-    for (auto* inst : instances) {
-      const FirstRoundMessage& m = inst->first_round_message;
-      Affine a = m.comm_a, b = m.comm_b, c = m.comm_c, prod = m.comm_c;
-      if (m.randomness) {
-        Sponge s = nark_sponge;  // `nark_sponge.clone()`
-        Fr g = Nark::compute_challenge(fr, nark_hash, inst->r1cs_input, m, s);
-        const FirstRoundMessageRandomness& r = *m.randomness;
-        Fr one = fr.one(), g2 = fr.mul(g, g);
-        a = host_lincomb(ctx, {&m.comm_a, &r.comm_r_a}, {one, g});
-        b = host_lincomb(ctx, {&m.comm_b, &r.comm_r_b}, {one, g});
-        c = host_lincomb(ctx, {&m.comm_c, &r.comm_r_c}, {one, g});
-        prod = host_lincomb(ctx, {&m.comm_c, &r.comm_1, &r.comm_2}, {one, g, g2});
-      }
-      out.a.push_back(a);
-      out.b.push_back(b);
-      out.c.push_back(c);
-      out.prod.push_back(prod);
+    // the four combinations of every input that carries randomness are independent of each other and of the other
+    // inputs': one batched library call for all of them
+    std::vector<hp_as::LincombJob> jobs;
+    std::vector<size_t> job_of(instances.size(), (size_t)-1);
+    for (size_t k = 0; k < instances.size(); k++) {
+      const FirstRoundMessage& m = instances[k]->first_round_message;
+      if (!m.randomness) continue;
+      Sponge s = nark_sponge;  // `nark_sponge.clone()`
+      Fr g = Nark::compute_challenge(fr, nark_hash, instances[k]->r1cs_input, m, s);
+      const FirstRoundMessageRandomness& r = *m.randomness;
+      Fr one = fr.one(), g2 = fr.mul(g, g);
+      job_of[k] = jobs.size();
+      jobs.push_back({{&m.comm_a, &r.comm_r_a}, {one, g}});
+      jobs.push_back({{&m.comm_b, &r.comm_r_b}, {one, g}});
+      jobs.push_back({{&m.comm_c, &r.comm_r_c}, {one, g}});
+      jobs.push_back({{&m.comm_c, &r.comm_1, &r.comm_2}, {one, g, g2}});
+    }
+    std::vector<Affine> res = hp_as::host_lincomb_batch(ctx, jobs);
+    for (size_t k = 0; k < instances.size(); k++) {
+      const FirstRoundMessage& m = instances[k]->first_round_message;
+      const bool blinded = job_of[k] != (size_t)-1;
+      out.a.push_back(blinded ? res[job_of[k]] : m.comm_a);
+      out.b.push_back(blinded ? res[job_of[k] + 1] : m.comm_b);
+      out.c.push_back(blinded ? res[job_of[k] + 2] : m.comm_c);
+      out.prod.push_back(blinded ? res[job_of[k] + 3] : m.comm_c);
     }
     return out;
   }
@@ -392,9 +400,10 @@ class ASForR1CSNark {
     out.r1cs_input.resize(n_in);
     if (n_in) check(amsm_fr_from_mont(fr.curve, acc[0].data(), n_in, out.r1cs_input[0].data()), "amsm_fr_from_mont");
     std::vector<Fr> b(beta.begin(), beta.begin() + (long)ca.size());
-    out.ca = host_lincomb(ctx, ca, b);
-    out.cb = host_lincomb(ctx, cb, b);
-    out.cc = host_lincomb(ctx, cc, b);
+    std::vector<Affine> comb = hp_as::host_lincomb_batch(ctx, {{ca, b}, {cb, b}, {cc, b}});
+    out.ca = comb[0];
+    out.cb = comb[1];
+    out.cc = comb[2];
     return out;
   }
 };

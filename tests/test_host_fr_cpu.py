@@ -114,3 +114,53 @@ def test_host_fr_inverse_many(built_lib, c):
     ffi.check(lib.amsm_fr_to_mont(c.curve_id, _ptr(a), n, _ptr(am)), "to_mont")
     ffi.check(lib.amsm_fr_inv(c.curve_id, _ptr(am), n, _ptr(inv)), "inv")
     assert h.np_to_ints(inv) == [(pow(x, -1, c.r) if x else 0) * R % c.r for x in vals]
+
+
+@pytest.mark.parametrize("c", [o.PALLAS, o.BLS12_381_G1], ids=lambda c: c.name)
+def test_host_lincomb_batch_equals_single_calls_and_oracle(built_lib, c):
+    """amsm_host_lincomb_batch (independent jobs on the host pool, one normalisation) against amsm_host_lincomb job by job
+    and against the big-int oracle: empty jobs, a job that sums to infinity, points at infinity, 128-bit and full-size
+    scalars, and one 40-point job (a single call of that size is itself split over the pool)."""
+    from accumulation_amd import ffi
+    from accumulation_amd.engine import _ptr
+    lib = ffi.load()
+    g = o.generator(c)
+    pts = [o.mul(c, 11 + 3 * i, g) for i in range(40)]
+    sc128 = [o.rng_scalar(0x51, i) % (1 << 128) for i in range(40)]
+    sc255 = [o.rng_scalar(0x52, i) % c.r for i in range(40)]
+    jobs = [
+        (pts[:2], [1, sc128[0]]),
+        (pts[2:5], [1, sc128[1], sc128[1] * sc128[1] % c.r]),
+        ([], []),
+        ([pts[5], pts[5]], [7, c.r - 7]),                      # cancels
+        ([None, pts[6], None], [5, sc255[2], 9]),              # points at infinity
+        (pts, sc128),                                          # 40 points, challenge-sized scalars
+        (pts[:9], sc255[:9]),
+        ([pts[7]], [0]),
+    ]
+    nj = len(jobs)
+    w = 2 * c.limbs
+    n_terms = (C.c_size_t * nj)()
+    xy_p, inf_p, sc_p = (C.c_void_p * nj)(), (C.c_void_p * nj)(), (C.c_void_p * nj)()
+    keep = []
+    for j, (P, S) in enumerate(jobs):
+        n_terms[j] = len(P)
+        xy, inf = h.points_to_np(c, P) if P else (np.zeros((1, w), dtype=np.uint64), np.zeros((1,), dtype=np.uint8))
+        sc = h.fr_mont_np(c, S) if S else np.zeros((1, 4), dtype=np.uint64)
+        keep.append((xy, inf, sc))
+        xy_p[j], inf_p[j], sc_p[j] = xy.ctypes.data, inf.ctypes.data, sc.ctypes.data
+    out = np.zeros((nj, w), dtype=np.uint64)
+    oinf = np.zeros((nj,), dtype=np.uint8)
+    ffi.check(lib.amsm_host_lincomb_batch(c.curve_id, nj, n_terms, xy_p, inf_p, sc_p, _ptr(out), _ptr(oinf)), "batch")
+    for j, (P, S) in enumerate(jobs):
+        expect = None
+        for p, s in zip(P, S):
+            expect = o.add(c, expect, o.mul(c, s, p))
+        assert h.np_to_point(c, out[j], bool(oinf[j])) == expect, j
+        xy, inf, sc = keep[j]
+        one = np.zeros((w,), dtype=np.uint64)
+        one_inf = C.c_uint8(0)
+        ffi.check(lib.amsm_host_lincomb(c.curve_id, _ptr(xy), _ptr(inf), _ptr(sc), len(P), _ptr(one), C.byref(one_inf)), "single")
+        assert bool(one_inf.value) == bool(oinf[j]) and (bool(oinf[j]) or np.array_equal(one, out[j])), j
+    assert lib.amsm_host_lincomb_batch(c.curve_id, nj, None, xy_p, inf_p, sc_p, _ptr(out), _ptr(oinf)) == ffi.AMSM_E_INVALID_ARG
+    assert lib.amsm_host_lincomb_batch(c.curve_id, 0, None, None, None, None, None, None) == ffi.AMSM_OK
