@@ -76,3 +76,26 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "libark_msm" not in txt and "ark_msm.c" not in txt, f
+
+
+def test_every_entry_point_survives_null_arguments(built_lib):
+    """Each of the ABI's entry points called with NULL handles / NULL buffers / zero sizes returns (an error status, or
+    the neutral value of a query) instead of dereferencing: the boundary is what a foreign host binds, and a binding bug
+    must come back as a status.  Runs in a child process so that a crash is a test failure, not the end of the session."""
+    import subprocess
+    import sys
+    probe = r"""
+import ctypes as C, sys
+from accumulation_amd import ffi
+lib = ffi.load()
+for name, (restype, argtypes) in ffi.SIGNATURES.items():
+    args = [t(0) if t in (C.c_int, C.c_uint, C.c_size_t, C.c_uint64) else None for t in argtypes]
+    r = getattr(lib, name)(*args)
+    if restype is C.c_int and name not in ("amsm_device_count", "amsm_stage_count", "amsm_bases_precomputed", "amsm_bases_num_shards",
+                                           "amsm_bases_window_bits") and argtypes and argtypes[0] is C.c_void_p:
+        assert r in (ffi.AMSM_E_INVALID_ARG, ffi.AMSM_OK), (name, r)
+print("survived", len(ffi.SIGNATURES))
+"""
+    p = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
+    assert "survived" in p.stdout
