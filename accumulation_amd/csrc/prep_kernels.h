@@ -145,6 +145,37 @@ AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont,
   }
 }
 
+// The same walk over a scalar already in registers (canonical form): k_prep_scatter walks every scalar twice and keeps
+// it (8 registers) instead of loading -- and converting from Montgomery form -- a second time.
+template <class Fr, int MAXW, class F>
+AMSM_DEV void scalar_entries_unrolled_reg(Fe<Fr> s, const MsmGeom& g, u32 i, F&& f) {
+  const u32 c = g.c;
+  const u32 mask = (1u << c) - 1u;
+  const u32 half = 1u << (c - 1);
+  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W);
+  u32 carry = 0;
+#pragma unroll
+  for (int w = 0; w < MAXW; w++) {
+    if ((u32)w < g.W) {
+      u32 raw = (s.v[0] & mask) + carry;
+#pragma unroll
+      for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
+      s.v[7] >>= c;
+      u32 set = set0 + (g.precomp ? 0u : (u32)w);
+      u32 idx = g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
+      u32 neg = 0;
+      carry = 0;
+      u32 d = raw;
+      if (raw > half) {
+        d = (1u << c) - raw;
+        neg = 1;
+        carry = 1;
+      }
+      if (d != 0) f(w, set * g.nb + (d - 1), idx | (neg << 31));
+    }
+  }
+}
+
 // dynamic LDS: P counters
 template <class Fr>
 __global__ void __launch_bounds__(1024)
@@ -228,26 +259,36 @@ __global__ void __launch_bounds__(512)
   const u32 t = threadIdx.x, T = blockDim.x;
   for (u32 p = t; p < pg.P; p += T) cnt[p] = 0;
   __syncthreads();
-  // 1. rank every entry inside its partition; the ranks (< SPB * W <= 8192) stay in registers, two per word
+  // 1. rank every entry inside its partition; the ranks (< SPB * W <= 8192) stay in registers, two per word, and so does
+  //    the scalar (canonical form) for the second walk in step 3
   u32 rk[SPT][MAXW / 2];
+  Fe<Fr> sreg[SPT];
 #pragma unroll
   for (int r = 0; r < SPT; r++) {
 #pragma unroll
     for (int k = 0; k < MAXW / 2; k++) rk[r][k] = 0;
     u32 i = blockIdx.x * pg.SPB + r * T + t;
-    if (i < g.n)
-      scalar_entries_unrolled<Fr, MAXW>(scalars, mont, g, i, [&](int w, u32 key, u32) {
+    if (i < g.n) {
+      sreg[r] = fe_load<Fr>(scalars + (size_t)i * 8);
+      if (mont) sreg[r] = fe_from_mont<Fr>(sreg[r]);
+      scalar_entries_unrolled_reg<Fr, MAXW>(sreg[r], g, i, [&](int w, u32 key, u32) {
         u32 rank = atomicAdd(&cnt[key >> pg.SH], 1u);
         rk[r][w >> 1] |= rank << ((w & 1) * 16);
       });
+    }
   }
   __syncthreads();
   // 2. block-local exclusive prefix over partitions (slice per lane + Hillis-Steele over the slice sums) and the
-  //    global run reservation
+  //    global run reservation.  The reservation is one returning atomicAdd per (workgroup, partition) on 512 addresses that
+  //    all 2048 workgroups hit: its round trip (measured: 30 of the kernel's 78 us at 2^20) is only NEEDED by the copy-out of
+  //    step 4, so the first RSV_MAX of a lane's partitions keep the returned offset in a register and step 3 -- pure ALU
+  //    and LDS now that the scalar stays in registers -- runs while the atomics are in flight.
+  constexpr u32 RSV_MAX = 4;
+  u32 rsv[RSV_MAX], rsv_base[RSV_MAX];
+  u32 per = (pg.P + T - 1) / T;
+  u32 lo = min(t * per, pg.P), hi = min(lo + per, pg.P);
   {
     u32* sl = reinterpret_cast<u32*>(staged);  // scratch: T words, before staging starts
-    u32 per = (pg.P + T - 1) / T;
-    u32 lo = min(t * per, pg.P), hi = min(lo + per, pg.P);
     u32 sum = 0;
     for (u32 p = lo; p < hi; p++) sum += cnt[p];
     sl[t] = sum;
@@ -259,7 +300,22 @@ __global__ void __launch_bounds__(512)
       __syncthreads();
     }
     u32 run = sl[t] - sum;
-    for (u32 p = lo; p < hi; p++) {
+#pragma unroll
+    for (u32 q = 0; q < RSV_MAX; q++) {
+      u32 p = lo + q;
+      rsv[q] = 0;
+      rsv_base[q] = 0;
+      if (p < hi) {
+        u32 v = cnt[p];
+        loff[p] = run;
+        if (v) {
+          rsv_base[q] = part_start[p];
+          rsv[q] = atomicAdd(&part_cursor[p], v);
+        }
+        run += v;
+      }
+    }
+    for (u32 p = lo + RSV_MAX; p < hi; p++) {  // more partitions per lane than registers kept for them
       u32 v = cnt[p];
       loff[p] = run;
       gbase[p] = v ? part_start[p] + atomicAdd(&part_cursor[p], v) : 0u;
@@ -267,13 +323,13 @@ __global__ void __launch_bounds__(512)
     }
   }
   __syncthreads();
-  // 3. regroup by partition in LDS (the digits are recomputed: cheaper than keeping 2 W entry words in registers)
+  // 3. regroup by partition in LDS (the digits are recomputed from the registers: cheaper than keeping 2 W entry words)
   const u32 low = (1u << pg.SH) - 1u;
 #pragma unroll
   for (int r = 0; r < SPT; r++) {
     u32 i = blockIdx.x * pg.SPB + r * T + t;
     if (i < g.n)
-      scalar_entries_unrolled<Fr, MAXW>(scalars, mont, g, i, [&](int w, u32 key, u32 val) {
+      scalar_entries_unrolled_reg<Fr, MAXW>(sreg[r], g, i, [&](int w, u32 key, u32 val) {
         u32 p = key >> pg.SH;
         u32 rank = (rk[r][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
         u32 slot = loff[p] + rank;
@@ -281,6 +337,9 @@ __global__ void __launch_bounds__(512)
         staged_p[slot] = (uint16_t)p;
       });
   }
+#pragma unroll
+  for (u32 q = 0; q < RSV_MAX; q++)
+    if (lo + q < hi) gbase[lo + q] = rsv_base[q] + rsv[q];
   __syncthreads();
   // 4. copy out: consecutive lanes -> consecutive slots -> (mostly) consecutive global words
   u32 total = loff[pg.P - 1] + cnt[pg.P - 1];
