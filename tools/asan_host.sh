@@ -25,7 +25,7 @@ sys.path.insert(0, "$R")
 import accumulation_amd.ffi as ffi
 ffi.LIB_PATH = "$D/libamsm_asan.so"
 import pytest
-sys.exit(pytest.main(["-x", "-q", "$R/tests/test_host_fr_cpu.py", "-p", "no:cacheprovider"]))
+sys.exit(pytest.main(["-x", "-q", "$R/tests/test_host_fr_cpu.py", "$R/tests/test_wire_format_cpu.py", "$R/tests/test_poseidon_cpu.py", "-p", "no:cacheprovider"]))
 PY
 cd $R
 ASAN_LIB=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
