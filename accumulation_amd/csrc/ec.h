@@ -84,7 +84,7 @@ AMSM_DEV XYZZ<P> xyzz_dbl(const XYZZ<P>& p) {
 
 // mdbl-2008-s-1 with a = 0 (affine input): 3M + 3S
 template <class P>
-AMSM_DEV XYZZ<P> xyzz_dbl_affine(const Affine<P>& p) {  // p.x, p.y < 2p, tight
+AMSM_DEV XYZZ<P> xyzz_dbl_affine(const Affine<P>& p) {  // p.x < 2p, p.y <= 2p (a lazily negated y through fe_tight), tight
   Fe<P> u = fe_dbl<P>(p.y);                                  // [< 4p]
   Fe<P> v = fe_sqr<P>(u);                                    // [< 1.2p]
   Fe<P> w = fe_mul<P>(u, v);                                 // [< 1.1p]
@@ -95,7 +95,11 @@ AMSM_DEV XYZZ<P> xyzz_dbl_affine(const Affine<P>& p) {  // p.x, p.y < 2p, tight
   XYZZ<P> r;
   r.x = fe_sub_bcc_k<P, 4>(fe_sqr<P>(m), zero, s);           // [< 5.2p]
   Fe<P> t = fe_sub_k<P, 8>(s, r.x);                          // [< 9.1p]
-  r.y = fe_mul_sub_mul_k<P, 2>(m, t, p.y, w);                // (m t + (2p - y) w) / R'  [< 1.3p]
+  // K = 4, not 2: y reaches 2p when xyzz_madd doubles a NEGATED point (q.y = 2p - y, y small), and K p - y is formed limb-wise
+  // without a carry pass -- its top limb must not go negative, i.e. y < K p - 2^(B (L - 1)).  With K = 2 a point whose y lies
+  // (in the internal Montgomery radix) below 2^(B (L - 1)) (one in 2^17 for BLS12-381, one in 2^22 for Pallas) doubled to garbage on that path: found by
+  // tools/fuzz_msm.py as ONE wrong point in a 124 124-point key fold by x = r - 2 (tests/golden/bls12_381_negated_doubling.json).
+  r.y = fe_mul_sub_mul_k<P, 4>(m, t, p.y, w);                // (m t + (4p - y) w) / R': (30 + 4.4) / 128  [< 1.3p]
   r.zz = v;
   r.zzz = w;
   return r;

@@ -178,7 +178,7 @@ AMSM_DEV Fe<P> u_mul_add_mul(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, con
 }
 
 // K*p - y with lazy limbs (< 2^(B+1)): multiplication operand only.  Needs y tight and y < (K - 1)*p, so that the
-// (unnormalised) top limb cannot go negative.
+// (unnormalised) top limb cannot go negative (exactly: y < K*p - 2^(B (L - 1)); there is no carry pass to repair it).
 template <class P, u32 K>
 AMSM_DEV Fe<P> u_kp_minus_lazy(const Fe<P>& y) {
   constexpr UKpBp<P, K, 1> c{};

@@ -619,3 +619,66 @@ def test_skewed_scalars_heavy_partitions_vs_c_oracle(ctxs, cref, mode):
         ref, rinf = cref.msm(c.curve_id, xy, masked, threads=8)
         assert bool(inf[g]) == rinf and np.array_equal(out[g], ref), (mode, "grouped", g)
     ck.free()
+
+
+def _negated_doubling_pair():
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bls12_381_negated_doubling.json")))
+    return np.array([[int(v, 16) for v in d["l"]], [int(v, 16) for v in d["r"]]], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("flags", [1, 2], ids=["precomputed", "plain"])
+def test_doubling_of_a_negated_duplicate_base(ctxs, flags):
+    """Two equal bases whose signed digits are both negative land in one bucket: the second mixed addition finds
+    acc == q and doubles the NEGATED affine point (y -> 2p - y, lazy limbs).  For a point whose Montgomery y is tiny
+    (tests/golden/bls12_381_negated_doubling.json: found by the fuzzer as one wrong point in 124 124) the doubling's
+    `K p - y` went negative in its top limb with K = 2.  Checked against the big-int oracle for several digit patterns."""
+    from accumulation_amd import CommitterKey, VariableBaseMSM
+    c = o.BLS12_381_G1
+    ctx = ctxs[c.name]
+    pair = _negated_doubling_pair()
+    R = h.np_to_point(c, pair[1], False)
+    L = h.np_to_point(c, pair[0], False)
+    for pts_np, pts in ((np.stack([pair[1], pair[1]]), [R, R]), (np.stack([pair[1], pair[0], pair[1], pair[1]]), [R, L, R, R])):
+        ck = CommitterKey.load(ctx, pts_np, None, flags)
+        for s in (15, (1 << 16) - 1, (1 << 17) - 1, c.r - 1, c.r - 2, 7, (1 << 200) - 1):
+            scal = [s] * len(pts)
+            out, inf = VariableBaseMSM.multi_scalar_mul(ck, ctx.upload(h.scalars_to_np(scal)), mont=False)
+            want = None
+            for P_, s_ in zip(pts, scal):
+                want = o.add(c, want, o.mul(c, s_, P_))
+            assert h.np_to_point(c, out, inf) == want, (flags, len(pts), hex(s))
+        ck.free()
+
+
+def test_key_fold_that_ends_in_a_negated_doubling(ctxs):
+    """amsm_bases_fold (l + x r by a NAF ladder) with x = r_order - 2: the ladder's last step adds -r to -r.  For the pair
+    of tests/golden/bls12_381_negated_doubling.json that doubling went wrong (see the test above); x = r_order - 1 / - 3 and
+    a 128-bit x take other paths and are checked as well, the pair alone and inside a 64-point fold."""
+    from accumulation_amd import CommitterKey
+    from accumulation_amd.scalar_field import Fr
+    c = o.BLS12_381_G1
+    ctx = ctxs[c.name]
+    fr = Fr(ctx.curve)
+    pair = _negated_doubling_pair()
+    L, R = h.np_to_point(c, pair[0], False), h.np_to_point(c, pair[1], False)
+    filler = [o.mul(c, 5 + 3 * i, o.generator(c)) for i in range(126)]
+    fxy, _ = h.points_to_np(c, filler)
+    for x, nbits in ((c.r - 2, 255), (c.r - 1, 255), (c.r - 3, 255), ((1 << 128) - 1, 128), (o.rng_scalar(0x77, 1) % c.r, 255)):
+        ck = CommitterKey.load(ctx, pair, None, 2)
+        f = ck.fold(1, fr.to_limbs(x), nbits)
+        got, ginf = f.read()
+        assert h.np_to_point(c, got[0], bool(ginf[0])) == o.add(c, L, o.mul(c, x, R)), (hex(x), nbits)
+        f.free()
+        ck.free()
+        # position 36 of the left half / of the right half of a 128-point key (the lane the fuzzer's case sat on, mod 64)
+        xy = np.concatenate([fxy[:36], pair[:1], fxy[36:63], fxy[63:99], pair[1:], fxy[99:126]])
+        pts = filler[:36] + [L] + filler[36:63] + filler[63:99] + [R] + filler[99:126]
+        ck = CommitterKey.load(ctx, xy, None, 2)
+        f = ck.fold(64, fr.to_limbs(x), nbits)
+        got, ginf = f.read()
+        for i in (0, 35, 36, 37, 63):
+            assert h.np_to_point(c, got[i], bool(ginf[i])) == o.add(c, pts[i], o.mul(c, x, pts[64 + i])), (hex(x), nbits, i)
+        f.free()
+        ck.free()
