@@ -175,6 +175,8 @@ struct amsm_ctx {
   int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x resident 256-lane blocks per CU x 4
   int K1 = 1024;  // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew only)
   int red_s = 4;
+  int split_log2 = 21;      // MSMs of 2^split_min_log2 pairs and more over a precomputed key run as windows of 2^split_log2
+  int split_min_log2 = 22;  // generators (msm_multi_split_xyzz; AMSM_SPLIT_LOG2=0 disables, AMSM_SPLIT_MIN_LOG2)
   bool one_stream = true;  // a lone blocking MSM runs its whole chain on the caller's stream (AMSM_ONE_STREAM=0: per-stage streams, A/B)
   bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
   bool profiling = false;
@@ -531,6 +533,20 @@ int msm_enqueue(amsm_ctx* ctx, Slot* sl, const amsm_bases* bases, size_t base_of
   TRY(ensure_pinned(sl, g.n_sets * rec + 64));
   // 16 flag words (scalar-range error, heavy-bucket count).  With the short prep chain they lead its block of small
   // arrays, so that ONE fill clears both (a fill is a 5 us dispatch at the head of every MSM's chain).
+  // An MSM over a window of a longer precomputed key: the interchange word of the partition pass carries the index relative
+  // to the window (MsmGeom::idx_rel_bits), so that its bucket-id bits -- the number of partitions -- follow the MSM's size,
+  // not the key's
+  if (ctx->custom_prep && g.precomp && g.groups == 1u) {
+    u32 b = 1;
+    while ((1ull << b) < n) b++;
+    unsigned long long abs_max = (unsigned long long)g.base_off + n - 1ull + (unsigned long long)(g.W - 1u) * g.table_stride;
+    unsigned long long rel_max = ((unsigned long long)(g.W - 1u) << b) | ((1ull << b) - 1ull);
+    if (rel_max < abs_max) {
+      MsmGeom g2 = g;
+      g2.idx_rel_bits = b;
+      if (prep_supported(g2)) sl->geom = g = g2;
+    }
+  }
   const bool short_prep = ctx->custom_prep && prep_supported(g);
   if (short_prep) TRY(ensure(sl->prep_small, 64 + prep_small_words(g) * sizeof(u32) + 256));
   else TRY(ensure(sl->misc, 64));
@@ -688,6 +704,10 @@ void stage_end(amsm_ctx* ctx) {
 }
 
 template <class Fq, class Fr>
+int msm_multi_split_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t k, const size_t* offs, const void* const* d_scalars,
+                         const size_t* ns, int scalars_mont, std::vector<host::HXYZZ<Fq>>* out);
+
+template <class Fq, class Fr>
 int msm_device_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,
                     int scalars_mont, host::HXYZZ<Fq>* out) {
   if (base_off > bases->n) return AMSM_E_INVALID_ARG;
@@ -695,6 +715,12 @@ int msm_device_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, con
   if (n == 0) {
     *out = host::hx_inf<Fq>();
     return AMSM_OK;
+  }
+  if (ctx->split_log2 > 0 && bases->precomp && (n >> ctx->split_min_log2) != 0) {  // large: pipelined windows of the key
+    std::vector<host::HXYZZ<Fq>> r;
+    int rc = msm_multi_split_xyzz<Fq, Fr>(ctx, bases, 1, &base_off, &d_scalars, &n, scalars_mont, &r);
+    if (rc == AMSM_OK) *out = r[0];
+    return rc;
   }
   stage_begin(ctx);
   TRY(prep_fork(ctx));
@@ -747,12 +773,49 @@ int msm_multi_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t k, const size_
   return rc;
 }
 
+// Large MSMs over a precomputed key run as pipelined sub-MSMs over windows of 2^split_log2 generators, summed on the host.
+// The partition pass of the prep sorts entries by (bucket, index) in one 32-bit word: above 2^21 pairs the index bits leave
+// too few for bucket ids and the pass needs 2048-4096 partitions (8- to 4-byte runs: prep 7.2 ms at 2^23; 2^24 fell back to
+// the rocPRIM sort).  A window carries window-relative indices (MsmGeom::idx_rel_bits) and sorts like a 2^21-pair MSM
+// whatever the key's length; the extra bucket reductions hide behind the next window's accumulation, and a blocking call of
+// that size becomes a pipeline.  Measured (batches, M pairs/s, whole / 2^20 windows / 2^21 windows): 2^22 815 / 822 / 845,
+// 2^23 507 / 841 / 868, 2^24 725 / 848 / 874; the workspace of a 2^24-pair MSM drops from 25.6 GB to 1.5 GB.
+template <class Fq, class Fr>
+int msm_multi_split_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t k, const size_t* offs, const void* const* d_scalars,
+                         const size_t* ns, int scalars_mont, std::vector<host::HXYZZ<Fq>>* out) {
+  const size_t chunk = ctx->split_log2 > 0 ? (size_t)1 << ctx->split_log2 : 0;
+  bool any = false;
+  if (chunk && bases->precomp)
+    for (size_t v = 0; v < k; v++) any = any || (std::min(ns[v], offs[v] <= bases->n ? bases->n - offs[v] : 0) >> ctx->split_min_log2) != 0;
+  if (!any) return msm_multi_xyzz<Fq, Fr>(ctx, bases, k, offs, d_scalars, ns, scalars_mont, out);
+  std::vector<size_t> s_offs, s_ns, owner;
+  std::vector<const void*> s_ptrs;
+  for (size_t v = 0; v < k; v++) {
+    if (offs[v] > bases->n) return AMSM_E_INVALID_ARG;
+    const size_t len = std::min(ns[v], bases->n - offs[v]);
+    const bool split = (len >> ctx->split_min_log2) != 0;
+    const size_t step = split ? chunk : std::max<size_t>(len, 1);
+    for (size_t lo = 0; lo < len; lo += step) {
+      s_offs.push_back(offs[v] + lo);
+      s_ns.push_back(std::min(step, len - lo));
+      s_ptrs.push_back((const char*)d_scalars[v] + lo * 32);
+      owner.push_back(v);
+    }
+  }
+  std::vector<host::HXYZZ<Fq>> part;
+  int rc = msm_multi_xyzz<Fq, Fr>(ctx, bases, s_ns.size(), s_offs.data(), s_ptrs.data(), s_ns.data(), scalars_mont, &part);
+  out->assign(k, host::hx_inf<Fq>());
+  if (rc != AMSM_OK) return rc;
+  for (size_t j = 0; j < part.size(); j++) (*out)[owner[j]] = host::hx_add<Fq>((*out)[owner[j]], part[j]);
+  return AMSM_OK;
+}
+
 // n_vecs MSMs over the same generators (the prover's back-to-back commits)
 template <class Fq, class Fr>
 int msm_batch_xyzz(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* const* d_scalars,
                    size_t n_vecs, size_t n, int scalars_mont, std::vector<host::HXYZZ<Fq>>* out) {
   std::vector<size_t> offs(n_vecs, base_off), ns(n_vecs, n);
-  return msm_multi_xyzz<Fq, Fr>(ctx, bases, n_vecs, offs.data(), d_scalars, ns.data(), scalars_mont, out);
+  return msm_multi_split_xyzz<Fq, Fr>(ctx, bases, n_vecs, offs.data(), d_scalars, ns.data(), scalars_mont, out);
 }
 
 // batch_normalization_into_affine (src/hp_as/mod.rs:468): one inversion for the whole batch
@@ -1660,6 +1723,8 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream) {
   if (const char* e = getenv("AMSM_K0_2PHASE")) c->two_phase = atoi(e) != 0;
   if (const char* e = getenv("AMSM_TAIL_QUAD")) c->tail_quad = atoi(e) != 0;
   if (const char* e = getenv("AMSM_ONE_STREAM")) c->one_stream = atoi(e) != 0;
+  if (const char* e = getenv("AMSM_SPLIT_LOG2")) c->split_log2 = std::max(0, std::min(28, atoi(e)));
+  if (const char* e = getenv("AMSM_SPLIT_MIN_LOG2")) c->split_min_log2 = std::max(10, std::min(40, atoi(e)));
   if (const char* e = getenv("AMSM_K1")) c->K1 = std::max(1, atoi(e));
   if (const char* e = getenv("AMSM_RED_S")) c->red_s = std::max(1, atoi(e));
   if (const char* e = getenv("AMSM_WINDOW")) c->window_override = atoi(e);

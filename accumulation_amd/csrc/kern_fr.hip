@@ -49,6 +49,7 @@ static PrepGeom prep_geom(const MsmGeom& g) {
   pg.SPB = g.S <= 16u ? 512u : 256u;  // SPB * S <= 8192 staged entries
   unsigned long long max_idx = (unsigned long long)g.base_off + g.n - 1ull +
                                (g.precomp ? (unsigned long long)(g.W - 1u) * g.table_stride : 0ull);
+  if (g.idx_rel_bits) max_idx = ((unsigned long long)(g.W - 1u) << g.idx_rel_bits) | ((1ull << g.idx_rel_bits) - 1ull);
   pg.IB = 1;
   while ((max_idx >> pg.IB) != 0ull) pg.IB++;
   // the entry word has 31 bits for index + bucket-id low bits: trade partition size for partitions when it is tight
@@ -151,7 +152,7 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
     hipLaunchKernelGGL(k_prep_local, dim3(pg.P), dim3(1024), prep_local_lds(pg), st,                                 \
                        part_start, b.part, g, pg, b.vals_sorted, b.start, b.items, b.item_off, part_items, hv);      \
     if (pg.HEAVY != 0xffffffffu)                                                                                     \
-      hipLaunchKernelGGL(k_prep_heavy_place, dim3(PREP_HEAVY_GRID), dim3(256), lds_heavy, st, part_start, b.part, pg, hv, \
+      hipLaunchKernelGGL(k_prep_heavy_place, dim3(PREP_HEAVY_GRID), dim3(256), lds_heavy, st, part_start, b.part, g, pg, hv, \
                          b.vals_sorted);                                                                             \
     hipLaunchKernelGGL(k_prep_offsets, dim3(cdiv_(g.B, 256)), dim3(256), (pg.P + 256) * sizeof(u32), st, part_start, \
                        part_items, pg, g, b.start, b.items, b.item_off, b.vals_sorted);                              \

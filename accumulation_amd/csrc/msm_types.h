@@ -24,6 +24,10 @@ struct MsmGeom {
   u32 base_off;      // first generator used
   u32 table_stride;  // generators per table level (key length)
   u32 precomp;       // table has W levels
+  u32 idx_rel_bits;  // 0: the prep's interchange word carries the absolute table index base_off + i + w * table_stride.
+                     // b > 0 (an MSM over a b-bit window of a longer precomputed key): it carries (w << b) | i -- the bits a
+                     // partition pass has for bucket ids do not shrink with the KEY's length -- and k_prep_local /
+                     // k_prep_heavy_place expand it to the absolute index when they write the list accumulate L0 reads
   u32 K0;            // entries per accumulate-L0 work item (chunk) of phase A: chunks [0, nA)
   u32 K0b;           // ... of phase B: chunks [nA, n_chunks).  Two sizes (K0 > K0b, both multiples of 4) let the grid be a
                      // WHOLE number of rounds of the resident wave slots: with one size the last round of a 2^20-pair
@@ -43,6 +47,10 @@ struct MsmGeom {
 #else
 #define AMSM_GEOM_FN inline
 #endif
+// interchange index -> table index (see idx_rel_bits)
+AMSM_GEOM_FN u32 entry_abs_index(const MsmGeom& g, u32 v) {
+  return g.idx_rel_bits ? (g.base_off + (v & ((1u << g.idx_rel_bits) - 1u)) + (v >> g.idx_rel_bits) * g.table_stride) : v;
+}
 AMSM_GEOM_FN u32 chunk_of(const MsmGeom& g, u32 pos) { return pos < g.T0 ? pos / g.K0 : g.nA + (pos - g.T0) / g.K0b; }
 AMSM_GEOM_FN u32 chunk_start(const MsmGeom& g, u32 c) { return c < g.nA ? c * g.K0 : g.T0 + (c - g.nA) * g.K0b; }
 

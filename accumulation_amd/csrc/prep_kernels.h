@@ -94,7 +94,7 @@ AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const Msm
     for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
     s.v[7] >>= c;
     u32 set = set0 + (g.precomp ? 0u : w);
-    u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
+    u32 idx = g.idx_rel_bits ? ((w << g.idx_rel_bits) | i) : g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
     u32 neg = 0;
     carry = 0;
     u32 d = raw;
@@ -131,7 +131,7 @@ AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont,
       for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
       s.v[7] >>= c;
       u32 set = set0 + (g.precomp ? 0u : (u32)w);
-      u32 idx = g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
+      u32 idx = g.idx_rel_bits ? (((u32)w << g.idx_rel_bits) | i) : g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
       u32 neg = 0;
       carry = 0;
       u32 d = raw;
@@ -162,7 +162,7 @@ AMSM_DEV void scalar_entries_unrolled_reg(Fe<Fr> s, const MsmGeom& g, u32 i, F&&
       for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
       s.v[7] >>= c;
       u32 set = set0 + (g.precomp ? 0u : (u32)w);
-      u32 idx = g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
+      u32 idx = g.idx_rel_bits ? (((u32)w << g.idx_rel_bits) | i) : g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
       u32 neg = 0;
       carry = 0;
       u32 d = raw;
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(1024)
   auto place = [&](u32 e) {
     u32 k = (e >> pg.IB) & low;
     u32 pos = skew ? lds_count(off, k) : atomicAdd(&off[k], 1u);
-    u32 v = (e & 0x80000000u) | (e & idx_mask);
+    u32 v = (e & 0x80000000u) | entry_abs_index(g, e & idx_mask);
     if (pos + 1 == cnt[k]) v |= PREP_ENTRY_LAST;
     if (staged) stage[pos] = v;
     else vals_sorted[ps + pos] = v;
@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(256)
   }
 }
 __global__ void __launch_bounds__(256)
-    k_prep_heavy_place(const u32* __restrict__ part_start, const u32* __restrict__ part, PrepGeom pg, PrepHeavy hv,
+    k_prep_heavy_place(const u32* __restrict__ part_start, const u32* __restrict__ part, MsmGeom g, PrepGeom pg, PrepHeavy hv,
                        u32* __restrict__ vals_sorted) {
   extern __shared__ u32 prep_lds[];
   const u32 NB = 1u << pg.SH, low = NB - 1u, idx_mask = (1u << pg.IB) - 1u, t = threadIdx.x, T = blockDim.x;
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(256)
       u32 e = part[j];
       u32 k = (e >> pg.IB) & low;
       u32 pos = base[k] + lds_count(cnt, k);
-      u32 v = (e & 0x80000000u) | (e & idx_mask);
+      u32 v = (e & 0x80000000u) | entry_abs_index(g, e & idx_mask);
       if (pos + 1 == hv.end[b0 + k]) v |= PREP_ENTRY_LAST;
       vals_sorted[ps + pos] = v;
     }

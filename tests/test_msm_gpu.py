@@ -682,3 +682,37 @@ def test_key_fold_that_ends_in_a_negated_doubling(ctxs):
             assert h.np_to_point(c, got[i], bool(ginf[i])) == o.add(c, pts[i], o.mul(c, x, pts[64 + i])), (hex(x), nbits, i)
         f.free()
         ck.free()
+
+
+def test_large_msm_as_windows_of_the_key_equals_the_whole(ctxs):
+    """MSMs of 2^22 pairs and more over a precomputed key run as pipelined sub-MSMs over 2^21-generator windows with
+    window-relative indices in the prep (msm_multi_split_xyzz).  Same canonical results as the unsplit pipeline
+    (AMSM_SPLIT_LOG2=0), for a size that is not a multiple of the window, blocking and in a batch, and with 2^20 windows."""
+    import os
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    c = o.PALLAS
+    n = (1 << 22) + 12345
+    results = []
+    for split in ("21", "0", "20"):
+        old = os.environ.get("AMSM_SPLIT_LOG2")
+        os.environ["AMSM_SPLIT_LOG2"] = split
+        try:
+            ctx = Context(c.curve_id)
+        finally:
+            if old is None:
+                os.environ.pop("AMSM_SPLIT_LOG2", None)
+            else:
+                os.environ["AMSM_SPLIT_LOG2"] = old
+        ck = CommitterKey.generate(ctx, 0x5EED2211, n)
+        assert ck.precomputed
+        a = ctx.random_vector(0x5EED2212, n, mont=True)
+        b = ctx.random_vector(0x5EED2213, n, mont=False)
+        one, oinf = VariableBaseMSM.multi_scalar_mul(ck, a, mont=True)
+        outs, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [a, a, a], mont=True)
+        ob, _ = VariableBaseMSM.multi_scalar_mul(ck, b, mont=False)
+        assert np.array_equal(outs[0], one) and np.array_equal(outs[2], one) and not infs.any() and not oinf
+        results.append((one.copy(), ob.copy()))
+        ck.free()
+        ctx.close()
+    for r in results[1:]:
+        assert np.array_equal(r[0], results[0][0]) and np.array_equal(r[1], results[0][1])
