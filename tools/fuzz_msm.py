@@ -23,7 +23,16 @@ n_cases = 0
 ctxs = {c.name: Context(c.curve_id) for c in (o.PALLAS, o.BLS12_381_G1)}
 BIG = 1 << 18  # a few cases per minute at sizes where skewed scalars make heavy prep partitions and keys fold in batches
 pools = {c.name: cref.rng_points(c.curve_id, 1000 + seed, BIG) for c in (o.PALLAS, o.BLS12_381_G1)}
-n_big = n_fold = 0
+n_big = n_fold = n_adv = 0
+# points with extreme coordinates in the device's internal Montgomery radix (tests/golden/adversarial_points.json) and their
+# negatives: mixed into a third of the keys, with repetitions, so that equal / opposite / edge-valued operands meet in buckets
+import json  # noqa: E402
+_fix = json.load(open(os.path.join(ROOT, "tests", "golden", "adversarial_points.json")))
+adv = {}
+for _c in (o.PALLAS, o.BLS12_381_G1):
+    _pts = [(int(x, 16), int(y, 16)) for v in _fix["curves"][_c.name].values() for x, y in v]
+    _pts += [(P[0], (-P[1]) % _c.p) for P in _pts]
+    adv[_c.name] = h.points_to_np(_c, _pts)[0]
 
 
 def scalars(c, n, kind):
@@ -101,6 +110,11 @@ while time.time() < t_end:
     n_key = int(rs.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4097, 20000, 40000]))
     n_key = min(n_key, 40000)
     xy = pools[c.name][:n_key]
+    if rs.rand() < 0.35:
+        xy = xy.copy()
+        k = int(rs.randint(1, min(n_key, 24) + 1))
+        xy[rs.randint(0, n_key, size=k)] = adv[c.name][rs.randint(0, len(adv[c.name]), size=k)]
+        n_adv += 1
     w = int(rs.choice([0, 0, 0, 2, 3, 5, 8, 10, 13, 15, 16, 17, 19]))
     flags = int(rs.choice([1, 2]))
     ctx.set_window(w)
@@ -144,4 +158,4 @@ while time.time() < t_end:
     ck.free()
     ctx.set_window(0)
     n_cases += 1
-print(f"fuzz ok: {n_cases} cases ({n_big} large skewed, {n_fold} key folds) in {budget:.0f} s (seed {seed})")
+print(f"fuzz ok: {n_cases} cases ({n_big} large skewed, {n_fold} key folds, {n_adv} keys with adversarial points) in {budget:.0f} s (seed {seed})")
