@@ -156,3 +156,49 @@ def test_hp_accumulation_decider_identity(ctxs):
     got = decide_commitments(ck, a_new, b_new)
     got = [h.np_to_point(c, p, i) for p, i in got]
     assert got[0] == C1 and got[1] == C2 and got[2] == C3
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_scalar_field_kernels_on_edge_values(ctxs, c):
+    """The scalar-field kernels take Montgomery limbs as they are, so the limb patterns a carry chain cares about can be fed
+    directly: 0, 1, r - 1, r - 2, all-ones words, single high bits, 2^k - 1, values just below the modulus in every limb.
+    Every pair goes through the Hadamard product, a two-vector combination with edge coefficients, the inner product and
+    compute_t_vecs, against Python integers (Montgomery product = a b R^-1 mod r)."""
+    from accumulation_amd.hp_as import combine_vectors, compute_hp, compute_t_vecs
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
+    from accumulation_amd.scalar_field import Fr
+    ctx = ctxs[c.name]
+    fr = Fr(ctx.curve)
+    r = c.r
+    R = 1 << 256
+    Rinv = pow(R, -1, r)
+    w32 = (1 << 32) - 1
+    vals = [0, 1, 2, r - 1, r - 2, r - 3, (r - 1) // 2, (r + 1) // 2, R % r, (R * R) % r, (R - 1) % r]
+    vals += [(1 << k) % r for k in (31, 32, 33, 63, 64, 65, 127, 128, 191, 192, 223, 224, 253, 254)]
+    vals += [((1 << k) - 1) % r for k in (32, 64, 96, 128, 160, 192, 224, 254)]
+    vals += [sum(w32 << (32 * j) for j in range(8) if (m >> j) & 1) % r for m in (0x55, 0xAA, 0x0F, 0xF0, 0x7F, 0x81)]
+    vals += [r - (1 << k) for k in (1, 32, 64, 128, 200)]
+    vals = sorted(set(v % r for v in vals))
+    m = len(vals)
+    A = [a for a in vals for _ in vals]          # Montgomery representatives, all pairs
+    B = [b for _ in vals for b in vals]
+    dA, dB = ctx.upload(h.scalars_to_np(A)), ctx.upload(h.scalars_to_np(B))  # limbs as given = Montgomery form
+    mont_mul = lambda x, y: x * y * Rinv % r  # noqa: E731
+    got = h.np_to_ints(compute_hp(ctx, dA, dB).download())
+    assert got == [mont_mul(a, b) for a, b in zip(A, B)]
+    for ca, cb in ((vals[3], vals[4]), (R % r, 1), (0, r - 1), (vals[-1], vals[len(vals) // 2])):
+        coeffs = h.scalars_to_np([ca, cb])
+        got = h.np_to_ints(combine_vectors(ctx, [dA, dB], coeffs).download())
+        assert got == [(mont_mul(a, ca) + mont_mul(b, cb)) % r for a, b in zip(A, B)], (hex(ca), hex(cb))
+    ip = np.zeros(4, dtype=np.uint64)
+    from accumulation_amd import ffi
+    from accumulation_amd.engine import _ptr
+    ffi.check(ctx._lib.amsm_vec_inner_product(ctx._h, dA.ptr, dB.ptr, len(A), _ptr(ip)), "inner_product")
+    assert h.np_to_ints(ip.reshape(1, 4))[0] == sum(mont_mul(a, b) for a, b in zip(A, B)) % r
+    # compute_t_vecs with two inputs: t_0 = a_0 o b_1-ish cross terms; compare with the Python restatement on Montgomery ints
+    mu = [R % r, vals[4]]
+    t = compute_t_vecs(ctx, [dA, dB], [dB, dA], h.scalars_to_np(mu), len(A))
+    exp = o.compute_t_vecs(c, [[x * Rinv % r for x in A], [x * Rinv % r for x in B]],
+                           [[x * Rinv % r for x in B], [x * Rinv % r for x in A]], [x * Rinv % r for x in mu], len(A), None)
+    for k, tv in enumerate(t):
+        assert h.np_to_ints(tv.download()) == [x * R % r for x in exp[k]], k
