@@ -99,3 +99,18 @@ print("survived", len(ffi.SIGNATURES))
     p = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
     assert "survived" in p.stdout
+
+
+def test_header_is_plain_c(built_lib, tmp_path):
+    """include/amsm.h is the FFI surface a Rust / Go / C host binds: it must compile as C99 (no C++-isms) and link against
+    the library with nothing but the C runtime."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "amsm.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%s %d %d\\n", amsm_strerror(0), amsm_device_count() >= 0, amsm_stage_count()); return 0; }\n')
+    exe = tmp_path / "abi_c"
+    libdir = os.path.join(ROOT, "accumulation_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-lamsm", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert out.startswith("ok 1 ")
