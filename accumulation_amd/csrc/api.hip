@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <pthread.h>
 #include <thread>
 #include <unordered_map>
 #include <rocprim/rocprim.hpp>
@@ -127,6 +128,14 @@ struct HostPool {
     const int hw = (int)std::thread::hardware_concurrency();
     want = std::max(0, std::min(want, std::min(15, hw > 1 ? hw - 1 : 0)));
     for (int i = 0; i < want; i++) workers.emplace_back(new ShardWorker());
+    // a fork()ed child (Python multiprocessing, a host that forks verifier workers) inherits this object but none of its
+    // threads: the child drops the workers WITHOUT joining them and runs every region on the calling thread
+    pthread_atfork(nullptr, nullptr, [] {
+      HostPool& p = HostPool::get();
+      for (auto& w : p.workers) (void)w.release();
+      p.workers.clear();
+      new (&p.busy) std::mutex();  // the parent may have held it at the fork
+    });
   }
   static HostPool& get() {
     static HostPool pool;

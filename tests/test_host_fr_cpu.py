@@ -164,3 +164,51 @@ def test_host_lincomb_batch_equals_single_calls_and_oracle(built_lib, c):
         assert bool(one_inf.value) == bool(oinf[j]) and (bool(oinf[j]) or np.array_equal(one, out[j])), j
     assert lib.amsm_host_lincomb_batch(c.curve_id, nj, None, xy_p, inf_p, sc_p, _ptr(out), _ptr(oinf)) == ffi.AMSM_E_INVALID_ARG
     assert lib.amsm_host_lincomb_batch(c.curve_id, 0, None, None, None, None, None, None) == ffi.AMSM_OK
+
+
+def test_host_pool_survives_fork(built_lib):
+    """The host thread pool behind amsm_host_lincomb[_batch] must not hang a fork()ed child (Python multiprocessing's default
+    start method): the child inherits the pool object but none of its threads.  Parent uses the pool, forks, the child
+    runs a batch and a split combination and reports through its exit code."""
+    import os
+    from accumulation_amd import ffi
+    from accumulation_amd.engine import _ptr
+    lib = ffi.load()
+    c = o.PALLAS
+    g = o.generator(c)
+    pts = [o.mul(c, 3 + i, g) for i in range(12)]
+    sc = [o.rng_scalar(0x99, i) % (1 << 128) for i in range(12)]
+    xy, inf = h.points_to_np(c, pts)
+    scm = h.fr_mont_np(c, sc)
+    want = None
+    for P, s in zip(pts, sc):
+        want = o.add(c, want, o.mul(c, s, P))
+
+    def run():
+        out = np.zeros((2 * c.limbs,), dtype=np.uint64)
+        oinf = C.c_uint8(0)
+        ffi.check(lib.amsm_host_lincomb(c.curve_id, _ptr(xy), _ptr(inf), _ptr(scm), 12, _ptr(out), C.byref(oinf)), "lincomb")
+        return h.np_to_point(c, out, bool(oinf.value)) == want
+
+    assert run()  # creates the pool in the parent (12 points: split over it)
+    pid = os.fork()
+    if pid == 0:
+        ok = False
+        try:
+            ok = run() and run()
+        finally:
+            os._exit(0 if ok else 1)
+    import signal
+    import time
+    t0 = time.time()
+    while True:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        if time.time() - t0 > 60:
+            os.kill(pid, signal.SIGKILL)
+            os.waitpid(pid, 0)
+            raise AssertionError("the forked child hung in the host pool")
+        time.sleep(0.05)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+    assert run()  # the parent's pool still works
