@@ -19,9 +19,13 @@
  *
  * Ownership: the caller owns every host buffer; calls are synchronous (results are on the host when
  * the call returns) unless the name ends in `_device`/`_async`.  Device memory lives behind the
- * opaque handles.  A ctx is NOT thread-safe; an amsm_bases is immutable after creation.
+ * opaque handles.  A ctx is NOT thread-safe (one thread at a time per context; different contexts may run on different
+ * threads); an amsm_bases is immutable after creation.  The context-free host helpers (amsm_host_lincomb[_batch], amsm_fr_*,
+ * amsm_*_serialize / _deserialize, amsm_poseidon_* on distinct sponges) may be called from any thread concurrently, and from a
+ * fork()ed child of a process that used them.
  * Errors: 0 = OK, negative = AMSM_E_*; nothing throws across the boundary.
- * There is NO CPU fallback: every entry point fails with AMSM_E_NO_DEVICE when no gfx950 GPU is usable.
+ * There is NO CPU fallback: every entry point that computes on the device fails with AMSM_E_NO_DEVICE when no gfx950 GPU is
+ * usable (the host helpers above need none).
  *
  * Multi-GPU: ONE process drives the GPUs of a node through a multi-device context (amsm_ctx_create_multi, below): the
  * committer key is sharded over the devices by contiguous index ranges, every MSM entry point that takes a key accepts a
