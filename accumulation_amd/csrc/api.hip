@@ -303,7 +303,7 @@ inline int ilog2_ceil(size_t n) {
 // Window width.  Measured on MI355X (tools/sweep_window.py, Pallas, batches of MSMs), not derived: a width whose TOP
 // window holds only 2-3 scalar bits (255 mod c small: c = 9, 11, 12, 14, 18, 19) concentrates 2^-3 of all entries of
 // that window in a handful of buckets, which then take the heavy-bucket path; c = 8, 10, 13, 15, 16 do not.
-//   precomputed key (all windows share one bucket set): 2^10-2^12 -> 8, 2^13-2^14 -> 10, 2^15 -> 13, 2^16 -> 15,
+//   precomputed key (all windows share one bucket set): 2^10-2^12 -> 8, 2^13-2^14 -> 10, 2^15 -> 13, 2^16 -> 15 (round 2: 16),
 //   >= 2^17 -> 16 (2^18: 518 vs 361 Mpairs/s at the old lg-4 rule; 2^22: 774 vs 440).
 //   Round 2: c = 17 from 2^20 up (and at 2^17).  15 windows of 17 bits cover the 255-bit scalars, so the 16th holds only the
 //   recoding's carry -- never set for Pallas (r < 2^254 + 2^126), set for the 45 % of BLS12-381 scalars above 2^254, whose
@@ -315,8 +315,7 @@ int choose_window(size_t n, bool precomp) {
   int lg = ilog2_ceil(n < 2 ? 2 : n);
   if (precomp) {
     if (lg >= 20 || lg == 17) return 17;
-    if (lg >= 17) return 16;
-    if (lg == 16) return 15;
+    if (lg >= 16) return 16;  // 2^16: 16 (207 Mpairs/s in batches; 13: 210, 15: 193; a blocking IPA round is within 1 % for all three)
     if (lg == 15) return 13;
     if (lg >= 13) return 10;
     return 8;
