@@ -1,0 +1,226 @@
+// Private to api.hip (one translation unit): the context, key, slot and host-thread types of the C ABI implementation.
+#pragma once
+namespace {
+
+enum Stage { ST_DIGITS = 0, ST_SORT, ST_BOUNDS, ST_ACCUM_L0, ST_ACCUM_L12, ST_REDUCE, ST_COUNT };
+// Elapsed device time between the stage's first and last kernel on the stream the stage runs on (hipEvent pairs).  The first
+// three are the prep stream: with the short prep chain everything is in "prep_chain" (the other two only have work in the
+// rocPRIM fallback).  Inside a batch these are the times the kernels take WHILE SHARING the GPU with the other MSMs in flight
+// (prep_chain stretches to about one accumulate-L0 duration); a blocking call gives the stand-alone times.
+const char* kStageNames[ST_COUNT] = {"prep_chain", "prep_sort_rocprim", "prep_bounds_rocprim", "accum_l0", "accum_l1_l2",
+                                     "bucket_reduce_fold"};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+// One pipeline slot = one stream + one private workspace, so two MSMs of a batch can be in flight:
+// the latency-bound tail of MSM i (fold partials, bucket reduce) overlaps the throughput-bound head of
+// MSM i+1 on the other slot's stream.
+constexpr int N_SLOTS = 3;  // MSMs of one batch in flight
+
+struct Slot {  // buffers and events of one MSM in flight (the streams belong to the context: one per pipeline stage)
+  hipEvent_t l0_done = nullptr, prep_done = nullptr;
+  hipEvent_t ev[ST_COUNT + 1] = {};  // stage begins (each on the stream its stage runs on)
+  hipEvent_t ev_prep_end = nullptr, ev_l0_end = nullptr;  // ends of the stages whose successor starts on ANOTHER stream
+  hipEvent_t done = nullptr;
+  DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
+      sort_tmp, scan_tmp, prep_small, heavy_scratch;
+  void* h_pinned = nullptr;
+  size_t h_pinned_bytes = 0;
+  MsmGeom geom = {};
+  bool busy = false;
+  hipStream_t tail = nullptr;  // the stream this slot's tail (and its result copy) was queued on
+};
+
+struct ShardWorker {  // one persistent host thread per non-primary shard
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, stop = false, idle = true;
+  ShardWorker() {
+    th = std::thread([this] {
+      for (;;) {
+        std::function<void()> j;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return has_job || stop; });
+          if (stop) return;
+          j = std::move(job);
+          has_job = false;
+        }
+        j();
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          idle = true;
+        }
+        cv.notify_all();
+      }
+    });
+  }
+  void submit(std::function<void()> j) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = std::move(j);
+      has_job = true;
+      idle = false;
+    }
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return idle; });
+  }
+  ~ShardWorker() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+
+// Host threads for the schemes' host-side group algebra (amsm_host_lincomb[_batch]: rows a11 of the scope table -- the
+// blinded commitments, the beta-combinations, the IPA verifier's 2 log n + 2 point combination are 50-500 us each and come
+// in independent groups).  A small persistent pool; the caller works too.  AMSM_HOST_THREADS=0 disables it (default: up
+// to 3 helpers).  One parallel region at a time: a second caller that finds the pool busy runs its tasks itself.
+struct HostPool {
+  std::vector<std::unique_ptr<ShardWorker>> workers;
+  std::mutex busy;
+  HostPool() {
+    int want = 3;
+    if (const char* e = getenv("AMSM_HOST_THREADS")) want = atoi(e);
+    const int hw = (int)std::thread::hardware_concurrency();
+    want = std::max(0, std::min(want, std::min(15, hw > 1 ? hw - 1 : 0)));
+    for (int i = 0; i < want; i++) workers.emplace_back(new ShardWorker());
+    // a fork()ed child (Python multiprocessing, a host that forks verifier workers) inherits this object but none of its
+    // threads: the child drops the workers WITHOUT joining them and runs every region on the calling thread
+    pthread_atfork(nullptr, nullptr, [] {
+      HostPool& p = HostPool::get();
+      for (auto& w : p.workers) (void)w.release();
+      p.workers.clear();
+      new (&p.busy) std::mutex();  // the parent may have held it at the fork
+    });
+  }
+  static HostPool& get() {
+    static HostPool pool;
+    return pool;
+  }
+  // fn(i) for i in [0, n), each exactly once
+  template <class F>
+  void run(size_t n, F&& fn) {
+    std::unique_lock<std::mutex> lk(busy, std::try_to_lock);
+    if (!lk.owns_lock() || workers.empty() || n < 2) {
+      for (size_t i = 0; i < n; i++) fn(i);
+      return;
+    }
+    std::atomic<size_t> next{0};
+    auto loop = [&] {
+      for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(i);
+    };
+    const size_t helpers = std::min(workers.size(), n - 1);
+    for (size_t w = 0; w < helpers; w++) workers[w]->submit(loop);
+    loop();
+    for (size_t w = 0; w < helpers; w++) workers[w]->wait();
+  }
+};
+
+struct amsm_ctx {
+  int curve = 0;
+  int device = 0;
+  // One stream per pipeline STAGE, shared by all MSMs in flight (in-order per stage, so consecutive MSMs pipeline:
+  // prep(k+1) and tail(k-1) run beside accumulate L0 of MSM k).  One stream per MSM instead made the overlap depend on
+  // which hardware queues the runtime happened to map the streams to (measured 610-700 Mpairs/s for the same code).
+  hipStream_t stream = nullptr;  // main: the caller's stream -- accumulate L0 and every non-MSM kernel
+  hipStream_t s_prep = nullptr;  // digits, sort, bounds, scan (memory-bound)
+  hipStream_t s_tail = nullptr;  // fold partials, bucket reduce, fold, D2H (latency-bound)
+  bool own_stream = false;
+  bool custom_prep = true;  // AMSM_PREP=rocprim: digits + rocPRIM radix sort + bounds + rocPRIM scan instead (A/B, fallback)
+  int window_override = 0;
+  int K0 = 0;          // 0 = automatic (see make_geom)
+  int cu_count = 256;
+  // AMSM_L0_SPREAD=1: small launches as ONE round at 1-2 workgroups per CU (residency capped with unused LDS).  Built on the
+  // theory that the dispatcher packs a CU to the kernel's occupancy before moving on; measured in round 2 it changes nothing
+  // (2^16: 0.460 vs 0.447 ms per blocking call) -- the small-launch time was the per-flush bucket search.  Off.
+  bool small_spread = false;
+  u32 l0_lds_pad = 0;  // AMSM_L0_LDS_PAD: dynamic LDS bytes per accumulate-L0 workgroup that only cap its residency
+  int K0_max = 32;     // automatic choice: largest chunk (AMSM_K0_MAX); round 2, batches of 2^20-pair MSMs: 32 -> 811-816, 24 -> 805 Mpairs/s
+  bool two_phase = true;  // automatic choice: two chunk sizes so that the grid is a whole number of rounds (AMSM_K0_2PHASE=0: A/B)
+  int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x resident 256-lane blocks per CU x 4
+  int K1 = 1024;  // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew only)
+  int red_s = 4;
+  int split_log2 = 21;      // MSMs of 2^split_min_log2 pairs and more over a precomputed key run as windows of 2^split_log2
+  int split_min_log2 = 22;  // generators (msm_multi_split_xyzz; AMSM_SPLIT_LOG2=0 disables, AMSM_SPLIT_MIN_LOG2)
+  bool one_stream = true;  // a lone blocking MSM runs its whole chain on the caller's stream (AMSM_ONE_STREAM=0: per-stage streams, A/B)
+  bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
+  bool profiling = false;
+  float stage_ms[ST_COUNT] = {};  // mean over the MSMs of the last call
+  float stage_acc[ST_COUNT] = {};
+  int stage_n = 0;
+  Slot slot[N_SLOTS];
+  hipEvent_t fork = nullptr;
+  hipEvent_t ip_ready = nullptr;  // amsm_ipa_round_fused: the inner products have reached the host
+  DevBuf scalars;
+  DevBuf xyzz_scratch;  // unconverted sums of large key folds / precompute levels (launch.h: batch_affine_pays)
+  // ---- multi-device (amsm_ctx_create_multi) ----
+  // shard_ctx[0] == this (the primary); shard_ctx[g >= 1] are owned single-device contexts, each served by one host
+  // worker thread so that the blocking single-device pipeline runs on all devices at once.
+  std::vector<amsm_ctx*> shard_ctx;
+  std::vector<ShardWorker*> workers;  // workers[g - 1] drives shard_ctx[g]
+  amsm_ctx* parent = nullptr;
+  int collective = 0;            // 0 none, 1 RCCL all-gather, 2 peer copies
+  void** rccl_comms = nullptr;   // ncclComm_t per shard
+  DevBuf rec_send, rec_recv, stage;  // per device: this shard's partial records / the gathered ones / scalar slices
+  hipEvent_t multi_fork = nullptr;
+  // ---- caching allocator behind amsm_dev_alloc / amsm_dev_free ----
+  // hipMalloc / hipFree synchronise the device: a scheme driver that allocates its vectors per call (every `Vec<F>` the
+  // reference builds) would serialise the GPU on each one.  Freed buffers go to size-keyed free lists and are handed out
+  // again; reuse is safe in stream order because every kernel that touches them runs on this context's streams and the MSM
+  // calls that read them from the prep stream are blocking.  amsm_ctx_trim releases everything.
+  std::unordered_map<size_t, std::vector<void*>> pool;    // rounded size -> free buffers
+  std::unordered_map<void*, size_t> pool_size;            // every live or pooled buffer -> its rounded size
+  size_t pool_free_bytes = 0, pool_live_bytes = 0;
+  size_t pool_cap_bytes = (size_t)16 << 30;               // free-list budget (AMSM_POOL_MAX_MB); beyond it frees are real
+};
+
+struct amsm_bases {
+  int curve = 0;
+  int device = 0;
+  size_t n = 0;
+  int precomp = 0;
+  int c = 0;  // window bits fixed at creation when precomputed
+  int W = 0;
+  u32* d_table = nullptr;          // device-internal Montgomery radix (launch.h: device_internal_radix)
+  // C-ABI-radix copy of generators [0, n), made on the first amsm_bases_device_ptr (under abi_mu: the handle is
+  // shareable between threads)
+  mutable u32* d_abi = nullptr;
+  mutable std::mutex abi_mu;
+  // recorded by amsm_bases_fold behind the kernel that writes d_table (it returns without synchronising): consumers that
+  // are not ordered behind the folding context's stream (amsm_bases_device_ptr) wait for it
+  hipEvent_t ready = nullptr;
+  // sharded key of a multi-device context: shard g (a single-device key on shard_ctx[g]'s device) holds generators
+  // [bound[g], bound[g + 1]); n is the total, d_table stays null
+  std::vector<amsm_bases*> shards;
+  std::vector<size_t> bound;
+  const amsm_ctx* owner = nullptr;
+};
+
+struct amsm_sponge {  // host-side Poseidon sponge over the curve's base field (host_poseidon.h)
+  int curve = 0;
+  host::PoseidonSponge<PallasFq> pallas;
+  host::PoseidonSponge<Bls12381Fq> bls;
+};
+
+struct amsm_matrix {
+  int curve = 0;
+  int device = 0;
+  size_t n_rows = 0, nnz = 0;
+  u32* d_row_ptr = nullptr;
+  u32* d_col = nullptr;
+  u32* d_val = nullptr;
+};
