@@ -119,20 +119,19 @@ def hp_inputs(ctx, ck, n, count, make_zk, seed):
     return out
 
 
-@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
-@pytest.mark.parametrize("shape", [(1, 0), (3, 0), (2, 1), (0, 2), (0, 0)], ids=lambda s: f"in{s[0]}_acc{s[1]}")
-def test_hp_as_prove_vs_oracle(hp_env, make_zk, shape):
+def hp_case(ctx, ck, gens, H, n, make_zk, shape, seed=100):
+    """One hp_as prove over `shape` = (inputs, old accumulators) compared with the oracle (also driven by tools/fuzz_schemes.py
+    with random shapes, lengths and seeds)."""
     from accumulation_amd.hp_as import ASForHadamardProducts as AS
     from accumulation_amd.sponge import Sha256Sponge
-    ctx, ck, gens, H, n = hp_env
     n_in, n_acc = shape
-    ins = hp_inputs(ctx, ck, n, n_in, make_zk, 100)
+    ins = hp_inputs(ctx, ck, n, n_in, make_zk, seed)
     # old accumulators are real accumulators (outputs of earlier proves), as in the reference's template
     olds = []
     for k in range(n_acc):
-        a, _ = AS.prove(ck, hp_inputs(ctx, ck, n, 2, make_zk, 500 + 50 * k), [], SchemeRng(40 + k) if make_zk else None, None)
+        a, _ = AS.prove(ck, hp_inputs(ctx, ck, n, 2, make_zk, seed + 400 + 50 * k), [], SchemeRng(seed - 60 + k) if make_zk else None, None)
         olds.append(a)
-    rng = RecordingRng(99) if make_zk else None
+    rng = RecordingRng(seed - 1) if make_zk else None
     sp = RecordingSponge(Sha256Sponge())
     acc, proof = AS.prove(ck, ins, olds, rng, sp)
     sq = sp.squeezed()
@@ -147,6 +146,13 @@ def test_hp_as_prove_vs_oracle(hp_env, make_zk, shape):
                       supported=n)
     assert_hp_acc_equal(acc, proof, ref)
     assert oa.hp_decide(C, gens, H, ref) and AS.decide(ck, acc, None)
+
+
+@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
+@pytest.mark.parametrize("shape", [(1, 0), (3, 0), (2, 1), (0, 2), (0, 0)], ids=lambda s: f"in{s[0]}_acc{s[1]}")
+def test_hp_as_prove_vs_oracle(hp_env, make_zk, shape):
+    ctx, ck, gens, H, n = hp_env
+    hp_case(ctx, ck, gens, H, n, make_zk, shape)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,46 @@
+"""Randomised runs of the accumulation layers against the big-int oracle (oracle/pyref_as.py), beyond the fixed scenarios of
+tests/test_as_layers_vs_oracle_gpu.py: hp_as proves with random vector lengths, numbers of inputs / old accumulators, zk on or
+off and fresh seeds; every combined instance, witness vector, proof commitment and decide() must match the oracle bit for bit.
+Usage: python tools/fuzz_schemes.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402
+
+from accumulation_amd import Context, PedersenCommitment, ffi  # noqa: E402
+from oracle import pyref as o  # noqa: E402
+from tests import helpers as h  # noqa: E402
+from tests.test_as_layers_vs_oracle_gpu import hp_case  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rs = np.random.RandomState(seed)
+C = o.PALLAS
+ctx = Context(ffi.AMSM_PALLAS)
+t_end = time.time() + budget
+n_cases = 0
+while time.time() < t_end:
+    n = int(rs.choice([1, 2, 3, 7, 23, 64, 257]))
+    ck = PedersenCommitment.setup(ctx, n, seed=int(rs.randint(1 << 30)))
+    xy, _ = ck.read()
+    gens = [h.np_to_point(C, xy[i], 0) for i in range(n)]
+    H = h.np_to_point(C, ck.hiding_generator, 0)
+    for _ in range(3):
+        n_in = int(rs.randint(0, 5))
+        n_acc = int(rs.randint(0, 4))
+        make_zk = bool(rs.rand() < 0.5)
+        if n_in + n_acc + (1 if make_zk else 0) > 8:
+            continue
+        try:
+            hp_case(ctx, ck, gens, H, n, make_zk, (n_in, n_acc), seed=int(rs.randint(1000, 1 << 20)))
+        except AssertionError:
+            print("FAILED case", dict(n=n, n_in=n_in, n_acc=n_acc, make_zk=make_zk, seed=seed, case=n_cases), flush=True)
+            raise
+        n_cases += 1
+    ck.free()
+print(f"fuzz_schemes ok: {n_cases} hp_as proves against the oracle in {budget:.0f} s (seed {seed})")
