@@ -24,6 +24,7 @@ ctxs = {c.name: Context(c.curve_id) for c in (o.PALLAS, o.BLS12_381_G1)}
 BIG = 1 << 18  # a few cases per minute at sizes where skewed scalars make heavy prep partitions and keys fold in batches
 pools = {c.name: cref.rng_points(c.curve_id, 1000 + seed, BIG) for c in (o.PALLAS, o.BLS12_381_G1)}
 n_big = n_fold = n_adv = 0
+PALLAS_FRACTION = float(os.environ.get("FUZZ_PALLAS_FRACTION", "0.7"))  # the rest of the cases run on BLS12-381
 # points with extreme coordinates in the device's internal Montgomery radix (tests/golden/adversarial_points.json) and their
 # negatives: mixed into a third of the keys, with repetitions, so that equal / opposite / edge-valued operands meet in buckets
 import json  # noqa: E402
@@ -54,7 +55,7 @@ def scalars(c, n, kind):
 
 
 while time.time() < t_end:
-    c = o.PALLAS if rs.rand() < 0.7 else o.BLS12_381_G1
+    c = o.PALLAS if rs.rand() < PALLAS_FRACTION else o.BLS12_381_G1
     ctx = ctxs[c.name]
     roll = rs.rand()
     if roll < 0.02:
