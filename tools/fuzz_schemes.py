@@ -1,6 +1,7 @@
 """Randomised runs of the accumulation layers against the big-int oracle (oracle/pyref_as.py), beyond the fixed scenarios of
 tests/test_as_layers_vs_oracle_gpu.py: hp_as proves with random vector lengths, numbers of inputs / old accumulators, zk on or
-off and fresh seeds; every combined instance, witness vector, proof commitment and decide() must match the oracle bit for bit.
+off and fresh seeds, and r1cs_nark_as accumulation CHAINS of random shape (new inputs and subsets of the earlier accumulators per
+step); every combined instance, witness vector, proof commitment and decide() must match the oracle bit for bit.
 Usage: python tools/fuzz_schemes.py [seconds] [seed]"""
 import os
 import sys
@@ -15,7 +16,10 @@ import torch  # noqa: F401,E402
 from accumulation_amd import Context, PedersenCommitment, ffi  # noqa: E402
 from oracle import pyref as o  # noqa: E402
 from tests import helpers as h  # noqa: E402
+import tests.test_as_layers_vs_oracle_gpu as T  # noqa: E402
 from tests.test_as_layers_vs_oracle_gpu import hp_case  # noqa: E402
+from tests.test_hp_as_scheme_gpu import SchemeRng  # noqa: E402
+from tests.test_r1cs_nark_gpu import dummy_circuit  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -23,8 +27,46 @@ rs = np.random.RandomState(seed)
 C = o.PALLAS
 ctx = Context(ffi.AMSM_PALLAS)
 t_end = time.time() + budget
-n_cases = 0
+n_cases = n_chains = n_steps = 0
+
+
+def nark_env():
+    """the module fixture of the test file, built by hand"""
+    from accumulation_amd import r1cs_nark as nark
+    A, B, C_, _, _ = dummy_circuit(T.N_IN, T.N_CON, 2, 3, C.r)
+    ipk = nark.index(ctx, A, B, C_, T.N_IN + 1, T.N_IN + 3, key_seed=int(rs.randint(1 << 30)))
+    xy, _ = ipk.ck.read()
+    gens = [h.np_to_point(C, xy[i], 0) for i in range(T.N_CON)]
+    H = h.np_to_point(C, ipk.ck.hiding_generator, 0)
+    return ctx, ipk, (A, B, C_), gens, H
+
+
+def nark_chain():
+    global n_steps
+    from accumulation_amd.r1cs_nark_as import ASForR1CSNark as AS
+    env = nark_env()
+    make_zk = bool(rs.rand() < 0.5)
+    rng = SchemeRng(int(rs.randint(1, 1 << 20)))
+    accs, last = [], None
+    for step in range(int(rs.randint(1, 5))):
+        olds = [accs[i] for i in sorted(rs.choice(len(accs), size=min(len(accs), int(rs.randint(0, 3))), replace=False))] if accs else []
+        n_new = int(rs.randint(0, 3))
+        ins = T.nark_inputs(env, n_new, make_zk, rng)
+        acc, proof, ref, dk = T.nark_as_step(env, ins, olds, make_zk, int(rs.randint(1, 1 << 20)))
+        T.assert_nark_acc_equal(acc, proof, ref)
+        accs.append(acc)
+        last = (acc, ref, dk)
+        n_steps += 1
+    acc, ref, dk = last
+    A, B, C_ = env[2]
+    assert T.oa.nark_as_decide(C, A, B, C_, env[3], env[4], ref) and AS.decide(dk, acc, None)
+
+
 while time.time() < t_end:
+    if rs.rand() < 0.35:
+        nark_chain()
+        n_chains += 1
+        continue
     n = int(rs.choice([1, 2, 3, 7, 23, 64, 257]))
     ck = PedersenCommitment.setup(ctx, n, seed=int(rs.randint(1 << 30)))
     xy, _ = ck.read()
@@ -43,4 +85,4 @@ while time.time() < t_end:
             raise
         n_cases += 1
     ck.free()
-print(f"fuzz_schemes ok: {n_cases} hp_as proves against the oracle in {budget:.0f} s (seed {seed})")
+print(f"fuzz_schemes ok: {n_cases} hp_as proves and {n_chains} r1cs_nark_as chains ({n_steps} accumulation steps) against the oracle in {budget:.0f} s (seed {seed})")
