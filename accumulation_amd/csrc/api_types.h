@@ -153,7 +153,7 @@ struct amsm_ctx {
   bool two_phase = true;  // automatic choice: two chunk sizes so that the grid is a whole number of rounds (AMSM_K0_2PHASE=0: A/B)
   int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x resident 256-lane blocks per CU x 4
   int K1 = 1024;  // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew only)
-  int red_s = 4;
+  int red_s = 0;  // buckets per lane of the bucket reduction; 0 = automatic (make_geom), AMSM_RED_S overrides
   int split_log2 = 21;      // MSMs of 2^split_min_log2 pairs and more over a precomputed key run as windows of 2^split_log2
   int split_min_log2 = 22;  // generators (msm_multi_split_xyzz; AMSM_SPLIT_LOG2=0 disables, AMSM_SPLIT_MIN_LOG2)
   bool one_stream = true;  // a lone blocking MSM runs its whole chain on the caller's stream (AMSM_ONE_STREAM=0: per-stage streams, A/B)
