@@ -103,3 +103,20 @@ def test_rejections(built_lib, curve):
         assert rc_of(ser.point_serialize(c, (x, y))) != 0
         with pytest.raises(ValueError):
             ser.point_deserialize(c, ser.point_serialize(c, (x, y)))
+
+
+def test_bls12_381_generator_known_encoding(built_lib):
+    """One known-answer vector that does not come from this repo's own oracle: the compressed arkworks (0.2 / 0.3) encoding
+    of the BLS12-381 G1 generator as it circulates in arkworks-based projects -- x little-endian, no flag bit set (the
+    generator's y is the smaller of the two roots, infinity flag clear).  It pins the byte order, the position of the flag
+    bits and the sign convention of the point encoding; recalled from public material, /root/reference holds no vectors."""
+    c = o.CURVES["bls12_381_g1"]
+    known = bytes.fromhex("bbc622db0af03afbef1a7af93fe8556c58ac1b173f3a4ea105b974974f8c68c3"
+                          "0faca94f8c63952694d79731a7d3f117")
+    g = o.generator(c)
+    assert ser.point_serialize(c, g, True) == known
+    blobs, _ = lib_points_serialize(built_lib, c, [g, o.neg(c, g)], True)
+    assert blobs[0] == known
+    assert blobs[1] == known[:-1] + bytes([known[-1] | ser.FLAG_POSITIVE_Y])
+    rc, back = lib_points_deserialize(built_lib, c, [known], True)
+    assert rc == 0 and back == [g]
