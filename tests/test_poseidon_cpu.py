@@ -146,3 +146,12 @@ def test_encodings_fork_and_challenges(built_lib, curve):
     x, y = pp.PoseidonSponge(c.p), pp.PoseidonSponge(c.p)
     x.absorb([5]); y.absorb([5])
     assert x.squeeze_nonnative(128, 2)[1] != [y.squeeze_nonnative(128, 1), y.squeeze_nonnative(128, 1)][1][0]
+
+
+def test_chacha20_zero_key_keystream():
+    """the well-known all-zero key / counter / nonce keystream block (with the RFC 7539 block above: two published vectors for
+    the function that generates the Poseidon round constants)"""
+    import struct
+    ks = b"".join(struct.pack("<I", w) for w in pp.chacha20_block([0, 0, 0, 0], [0] * 8))
+    assert ks.hex() == ("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+                        "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
