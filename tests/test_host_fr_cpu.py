@@ -212,3 +212,46 @@ def test_host_pool_survives_fork(built_lib):
         time.sleep(0.05)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
     assert run()  # the parent's pool still works
+
+
+def test_host_helpers_from_concurrent_threads(built_lib):
+    """include/amsm.h promises that the context-free host helpers may be called from any thread concurrently: four Python
+    threads (ctypes releases the GIL) run single, split and batched combinations at once -- one of them gets the host pool,
+    the others fall back to their own thread -- and every result equals the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    from accumulation_amd import ffi
+    from accumulation_amd.engine import _ptr
+    lib = ffi.load()
+    c = o.PALLAS
+    g = o.generator(c)
+    pts = [o.mul(c, 7 + 2 * i, g) for i in range(16)]
+    xy, inf = h.points_to_np(c, pts)
+
+    def worker(seed):
+        ok = True
+        for it in range(12):
+            n = [1, 3, 9, 16][it % 4]
+            sc = [o.rng_scalar(seed, 16 * it + i) % (c.r if it % 3 == 0 else (1 << 128)) for i in range(n)]
+            scm = h.fr_mont_np(c, sc)
+            out = np.zeros((2 * c.limbs,), dtype=np.uint64)
+            oinf = C.c_uint8(0)
+            ffi.check(lib.amsm_host_lincomb(c.curve_id, _ptr(xy), _ptr(inf), _ptr(scm), n, _ptr(out), C.byref(oinf)), "lincomb")
+            want = None
+            for P, s in zip(pts, sc):
+                want = o.add(c, want, o.mul(c, s, P))
+            ok = ok and h.np_to_point(c, out, bool(oinf.value)) == want
+            # a batch of three jobs over the same inputs
+            nj = 3
+            n_terms = (C.c_size_t * nj)(n, max(n - 1, 0), 1)
+            xy_p, inf_p, sc_p = (C.c_void_p * nj)(), (C.c_void_p * nj)(), (C.c_void_p * nj)()
+            for j in range(nj):
+                xy_p[j], inf_p[j], sc_p[j] = xy.ctypes.data, inf.ctypes.data, scm.ctypes.data
+            bout = np.zeros((nj, 2 * c.limbs), dtype=np.uint64)
+            binf = np.zeros((nj,), dtype=np.uint8)
+            ffi.check(lib.amsm_host_lincomb_batch(c.curve_id, nj, n_terms, xy_p, inf_p, sc_p, _ptr(bout), _ptr(binf)), "batch")
+            ok = ok and h.np_to_point(c, bout[0], bool(binf[0])) == want
+            ok = ok and h.np_to_point(c, bout[2], bool(binf[2])) == o.mul(c, sc[0], pts[0])
+        return ok
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        assert all(ex.map(worker, [101, 202, 303, 404]))
