@@ -17,6 +17,7 @@
 #include <mutex>
 #include <new>
 #include <pthread.h>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <rocprim/rocprim.hpp>

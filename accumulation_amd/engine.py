@@ -182,6 +182,11 @@ class MultiContext(Context):
     def collective(self) -> str:
         return self._lib.amsm_ctx_collective(self._h).decode()
 
+    @property
+    def collectives(self) -> int:
+        """exchanges of partial records so far: one per sharded MSM / commit CALL (amsm_ctx_collectives)"""
+        return int(self._lib.amsm_ctx_collectives(self._h))
+
     def shard(self, g: int) -> Context:
         return self._shards[g]
 

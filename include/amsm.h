@@ -100,6 +100,10 @@ int amsm_ctx_num_devices(const amsm_ctx* ctx);
 amsm_ctx* amsm_ctx_shard(amsm_ctx* ctx, int g);
 /* "rccl", "peer-copy" (multi-device contexts) or "none". */
 const char* amsm_ctx_collective(const amsm_ctx* ctx);
+/* Exchanges of partial records (one RCCL all-gather, or one round of peer copies) this multi-device context has run:
+ * exactly ONE per sharded MSM / commit call however many vectors the call carries, so a prover's exchange count is its
+ * number of DEPENDENT commit rounds (tests/test_cpp_multi_device.py counts them).  0 for single-device contexts. */
+unsigned long long amsm_ctx_collectives(const amsm_ctx* ctx);
 void amsm_ctx_destroy(amsm_ctx* ctx);
 int amsm_ctx_curve(const amsm_ctx* ctx);
 /* limbs (u64) of a base-field element: 4 (Pallas) or 6 (BLS12-381). */

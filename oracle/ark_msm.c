@@ -606,3 +606,68 @@ int ark_fr_from_mont(int curve, const u64* a, size_t n, u64* out) {
   for (size_t i = 0; i < n; i++) f_from_mont(f, out + 4 * i, a + 4 * i);
   return 0;
 }
+
+/* compute_t_vecs, src/hp_as/mod.rs:288-349 (Montgomery in, Montgomery out): per index li the coefficients of
+ * (sum_j mu[j] a_j[li] X^j [+ hiding_a[li] mu[n]]) * (sum_j b_{n-1-j}[li] X^j [+ hiding_b[li] mu[1]]), missing entries
+ * read as zero (:306-318), the hiding terms added to coefficient 0 of each factor (:322-330), naive_mul (:335).
+ * a/b: n pointers + lengths; mu: n (+1 with hiding) elements; out: 2n-1 pointers to hp_len elements each. */
+#define ARK_T_MAX 16
+int ark_fr_t_vecs(int curve, const u64* const* a, const size_t* a_lens, const u64* const* b, const size_t* b_lens,
+                  size_t n, const u64* mu, size_t hp_len, const u64* hiding_a, size_t ha_len, const u64* hiding_b,
+                  size_t hb_len, u64* const* out) {
+  if (curve < 0 || curve > 1 || n == 0 || n > ARK_T_MAX) return -1;
+  curves_init();
+  const field_t* f = &g_curves[curve].fr;
+  const int hiding = hiding_a != NULL && hiding_b != NULL;
+  for (size_t li = 0; li < hp_len; li++) {
+    u64 ac[ARK_T_MAX][4], bc[ARK_T_MAX][4], t[2 * ARK_T_MAX][4], tmp[4];
+    for (size_t j = 0; j < n; j++) {
+      if (li < a_lens[j]) f_mul(f, ac[j], mu + 4 * j, a[j] + 4 * li);
+      else memset(ac[j], 0, 32);
+      /* b_coeffs.reverse() (:320): position j holds witness n-1-j */
+      size_t src = n - 1 - j;
+      if (li < b_lens[src]) memcpy(bc[j], b[src] + 4 * li, 32);
+      else memset(bc[j], 0, 32);
+    }
+    if (hiding) {
+      if (li < ha_len) {
+        f_mul(f, tmp, hiding_a + 4 * li, mu + 4 * n);
+        f_add(f, ac[0], ac[0], tmp);
+      }
+      if (li < hb_len) {
+        f_mul(f, tmp, hiding_b + 4 * li, mu + 4 * 1);
+        f_add(f, bc[0], bc[0], tmp);
+      }
+    }
+    memset(t, 0, sizeof(t));
+    for (size_t i = 0; i < n; i++)
+      for (size_t j = 0; j < n; j++) {
+        f_mul(f, tmp, ac[i], bc[j]);
+        f_add(f, t[i + j], t[i + j], tmp);
+      }
+    for (size_t k = 0; k < 2 * n - 1; k++) memcpy(out[k] + 4 * li, t[k], 32);
+  }
+  return 0;
+}
+
+/* matrix_vec_mul / inner_prod, src/r1cs_nark_as/r1cs_nark/mod.rs:443-462: out[r] = sum_k coeff[k] * z[col[k]] over the
+ * entries row_ptr[r] .. row_ptr[r+1] of a row-sparse matrix; z = input || witness, given as two arrays (index i reads
+ * input[i] if i < n_input else witness[i - n_input], :452-456).  Montgomery in, Montgomery out. */
+int ark_fr_spmv(int curve, const u64* row_ptr, const u64* col, const u64* coeff, size_t n_rows, const u64* input,
+                size_t n_input, const u64* witness, size_t n_witness, u64* out) {
+  if (curve < 0 || curve > 1) return -1;
+  curves_init();
+  const field_t* f = &g_curves[curve].fr;
+  for (size_t r = 0; r < n_rows; r++) {
+    u64 acc[4] = {0, 0, 0, 0}, t[4];
+    for (u64 k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+      u64 i = col[k];
+      if (i >= n_input + n_witness) return -2;
+      const u64* z = i < n_input ? input + 4 * i : witness + 4 * (i - n_input);
+      f_mul(f, t, z, coeff + 4 * k);
+      f_add(f, acc, acc, t);
+    }
+    memcpy(out + 4 * r, acc, 32);
+  }
+  return 0;
+}

@@ -44,6 +44,11 @@ def load():
         lib.ark_fr_to_mont.argtypes = [C.c_int, vp, sz, vp]
         lib.ark_fr_from_mont.restype = C.c_int
         lib.ark_fr_from_mont.argtypes = [C.c_int, vp, sz, vp]
+        lib.ark_fr_t_vecs.restype = C.c_int
+        lib.ark_fr_t_vecs.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), sz, vp, sz, vp, sz,
+                                      vp, sz, C.POINTER(vp)]
+        lib.ark_fr_spmv.restype = C.c_int
+        lib.ark_fr_spmv.argtypes = [C.c_int, vp, vp, vp, sz, vp, sz, vp, sz, vp]
         _lib = lib
     return _lib
 
@@ -118,4 +123,45 @@ def fr_from_mont(curve_id: int, a: np.ndarray) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
     out = np.empty_like(a)
     assert load().ark_fr_from_mont(curve_id, _p(a), a.shape[0], _p(out)) == 0
+    return out
+
+
+def _m4(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+
+
+def fr_t_vecs(curve_id: int, a_vecs: Sequence[np.ndarray], b_vecs: Sequence[np.ndarray], mu: np.ndarray, hp_len: int,
+              hiding: Optional[Tuple[np.ndarray, np.ndarray]] = None) -> list:
+    """compute_t_vecs (src/hp_as/mod.rs:288-349) over Montgomery (len, 4) uint64 arrays -> 2n-1 arrays of hp_len."""
+    a_vecs, b_vecs = [_m4(v) for v in a_vecs], [_m4(v) for v in b_vecs]
+    n = len(a_vecs)
+    assert n == len(b_vecs) and n >= 1
+    mu = _m4(mu)
+    assert mu.shape[0] >= n + (1 if hiding is not None else 0)
+    ap = (C.c_void_p * n)(*[v.ctypes.data for v in a_vecs])
+    al = (C.c_size_t * n)(*[v.shape[0] for v in a_vecs])
+    bp = (C.c_void_p * n)(*[v.ctypes.data for v in b_vecs])
+    bl = (C.c_size_t * n)(*[v.shape[0] for v in b_vecs])
+    out = [np.empty((hp_len, 4), dtype=np.uint64) for _ in range(2 * n - 1)]
+    op = (C.c_void_p * (2 * n - 1))(*[v.ctypes.data for v in out])
+    ha = hb = None
+    if hiding is not None:
+        ha, hb = _m4(hiding[0]), _m4(hiding[1])
+    rc = load().ark_fr_t_vecs(curve_id, ap, al, bp, bl, n, _p(mu), hp_len, _p(ha), 0 if ha is None else ha.shape[0], _p(hb),
+                              0 if hb is None else hb.shape[0], op)
+    assert rc == 0
+    return out
+
+
+def fr_spmv(curve_id: int, row_ptr: np.ndarray, col: np.ndarray, coeff: np.ndarray, inp: np.ndarray,
+            wit: np.ndarray) -> np.ndarray:
+    """matrix_vec_mul (src/r1cs_nark_as/r1cs_nark/mod.rs:443-462) on a CSR matrix; coeff / inp / wit Montgomery (k, 4)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+    col = np.ascontiguousarray(col, dtype=np.uint64)
+    coeff, inp, wit = _m4(coeff), _m4(inp), _m4(wit)
+    n_rows = row_ptr.shape[0] - 1
+    out = np.empty((n_rows, 4), dtype=np.uint64)
+    rc = load().ark_fr_spmv(curve_id, _p(row_ptr), _p(col), _p(coeff), n_rows, _p(inp), inp.shape[0], _p(wit), wit.shape[0],
+                            _p(out))
+    assert rc == 0, rc
     return out

@@ -33,6 +33,43 @@ from . import pyref as o
 Point = o.Point
 
 
+class PyOps:
+    """The O(len) steps on Python-int lists (oracle/pyref.py): the default.  The config-size tests (2^18 constraints, 2^22
+    elements) swap in oracle/fastref.py's NumpyOps -- the same steps over Montgomery limb arrays through the C restatement
+    oracle/ark_msm.c -- with `use_ops`; the accumulation algebra in this file is the same code either way."""
+    pedersen_commit = staticmethod(o.pedersen_commit)
+    compute_hp = staticmethod(o.compute_hp)
+    combine_vectors = staticmethod(o.combine_vectors)
+    scale_vector = staticmethod(o.scale_vector)
+    compute_t_vecs = staticmethod(o.compute_t_vecs)
+    matrix_vec_mul = staticmethod(o.matrix_vec_mul)
+
+    @staticmethod
+    def const(c, value: int, n: int) -> List[int]:
+        """`vec![value; n]` (src/hp_as/mod.rs:187-188, src/r1cs_nark_as/mod.rs:378-379)"""
+        return [value % c.r] * n
+
+
+ops = PyOps()
+
+
+class use_ops:
+    """with use_ops(NumpyOps(...)): ...  -- vector backend of this module for the duration of the block"""
+
+    def __init__(self, new):
+        self.new = new
+
+    def __enter__(self):
+        global ops
+        self.old, ops = ops, self.new
+        return self.new
+
+    def __exit__(self, *exc):
+        global ops
+        ops = self.old
+        return False
+
+
 # --------------------------------------------------------------------------------------------------------------
 # hp_as
 # --------------------------------------------------------------------------------------------------------------
@@ -96,10 +133,10 @@ def hp_combined_commitments(c, instances: Sequence[Tuple[Point, Point, Point]], 
 def hp_combined_openings(c, witnesses: Sequence[dict], mu, nu, chi, hiding_vecs, hiding_rands) -> dict:
     """src/hp_as/mod.rs:535-607.  witness = {"a": [...], "b": [...], "rand": None | (r1, r2, r3)}"""
     n = len(witnesses)
-    add1 = o.scale_vector(c, hiding_vecs[0], mu[n]) if hiding_vecs is not None else None
-    a_open = o.combine_vectors(c, [w["a"] for w in witnesses], chi, add1)
-    add2 = o.scale_vector(c, hiding_vecs[1], mu[1]) if hiding_vecs is not None else None
-    b_open = o.combine_vectors(c, [w["b"] for w in reversed(witnesses)], nu, add2)
+    add1 = ops.scale_vector(c, hiding_vecs[0], mu[n]) if hiding_vecs is not None else None
+    a_open = ops.combine_vectors(c, [w["a"] for w in witnesses], chi, add1)
+    add2 = ops.scale_vector(c, hiding_vecs[1], mu[1]) if hiding_vecs is not None else None
+    b_open = ops.combine_vectors(c, [w["b"] for w in reversed(witnesses)], nu, add2)
     rand = None
     if hiding_rands is not None:
         def col(k):
@@ -126,7 +163,7 @@ def hp_prove(c, gens: Sequence[Point], H: Point, inputs: Sequence[dict], accs: S
         hp_vec_len = supported if supported is not None else len(gens)
 
     def zero_input():
-        return {"inst": (None, None, None), "wit": {"a": [0] * hp_vec_len, "b": [0] * hp_vec_len, "rand": None}}
+        return {"inst": (None, None, None), "wit": {"a": ops.const(c, 0, hp_vec_len), "b": ops.const(c, 0, hp_vec_len), "rand": None}}
     if num_all == 0:
         inputs.append(zero_input())
         num_all += 1
@@ -138,19 +175,19 @@ def hp_prove(c, gens: Sequence[Point], H: Point, inputs: Sequence[dict], accs: S
     witnesses = [x["wit"] for x in all_]
     hiding_vecs = hiding_rands = hiding_comms = None
     if make_zk:  # generate_prover_randomness :179-230
-        a = [rnd["a"] % c.r] * hp_vec_len
-        b = [rnd["b"] % c.r] * hp_vec_len
+        a = ops.const(c, rnd["a"], hp_vec_len)
+        b = ops.const(c, rnd["b"], hp_vec_len)
         hiding_rands = (rnd["rand_1"], rnd["rand_2"], rnd["rand_3"])
-        comm_1 = o.pedersen_commit(c, gens, H, a, hiding_rands[0])
-        comm_2 = o.pedersen_commit(c, gens, H, b, hiding_rands[1])
-        p1 = o.compute_hp(c, a, witnesses[0]["b"])
-        p2 = o.compute_hp(c, witnesses[-1]["a"], b)
-        comm_3 = o.pedersen_commit(c, gens, H, o.combine_vectors(c, [p1, p2], [1, 1]), hiding_rands[2])
+        comm_1 = ops.pedersen_commit(c, gens, H, a, hiding_rands[0])
+        comm_2 = ops.pedersen_commit(c, gens, H, b, hiding_rands[1])
+        p1 = ops.compute_hp(c, a, witnesses[0]["b"])
+        p2 = ops.compute_hp(c, witnesses[-1]["a"], b)
+        comm_3 = ops.pedersen_commit(c, gens, H, ops.combine_vectors(c, [p1, p2], [1, 1]), hiding_rands[2])
         hiding_vecs, hiding_comms = (a, b), (comm_1, comm_2, comm_3)
     mu = hp_mu_challenges(c, mu_squeezed, num_all, make_zk)
-    t = o.compute_t_vecs(c, [w["a"] for w in witnesses], [w["b"] for w in witnesses], mu, hp_vec_len, hiding_vecs)
-    low = [o.pedersen_commit(c, gens, H, t[i], None) for i in range(num_all - 1)]
-    high = [o.pedersen_commit(c, gens, H, t[i], None) for i in range(num_all, 2 * num_all - 1)]
+    t = ops.compute_t_vecs(c, [w["a"] for w in witnesses], [w["b"] for w in witnesses], mu, hp_vec_len, hiding_vecs)
+    low = [ops.pedersen_commit(c, gens, H, t[i], None) for i in range(num_all - 1)]
+    high = [ops.pedersen_commit(c, gens, H, t[i], None) for i in range(num_all, 2 * num_all - 1)]
     nu = hp_nu_challenges(c, nu1, num_all)
     chi = [m * v % c.r for m, v in zip(mu, nu)]
     inst = hp_combined_commitments(c, instances, low, high, hiding_comms, mu, nu, chi)
@@ -163,10 +200,10 @@ def hp_decide(c, gens, H, acc: dict) -> bool:
     """src/hp_as/mod.rs:894-925"""
     w = acc["wit"]
     r = w["rand"] if w["rand"] is not None else (None, None, None)
-    prod = o.compute_hp(c, w["a"], w["b"])
-    c1 = o.pedersen_commit(c, gens, H, w["a"], r[0])
-    c2 = o.pedersen_commit(c, gens, H, w["b"], r[1])
-    c3 = o.pedersen_commit(c, gens, H, prod, r[2])
+    prod = ops.compute_hp(c, w["a"], w["b"])
+    c1 = ops.pedersen_commit(c, gens, H, w["a"], r[0])
+    c2 = ops.pedersen_commit(c, gens, H, w["b"], r[1])
+    c3 = ops.pedersen_commit(c, gens, H, prod, r[2])
     return (c1, c2, c3) == tuple(acc["inst"])
 
 
@@ -229,7 +266,7 @@ def nark_as_witness_components(c, input_witnesses, acc_witnesses, beta, prover_w
         wits.append(prover_witness_randomness[0])
         for k in range(3):
             cols[k].append(prover_witness_randomness[1 + k])
-    blinded = o.combine_vectors(c, wits, beta)
+    blinded = ops.combine_vectors(c, wits, beta)
     rand = None
     if prover_witness_randomness is not None:
         rand = tuple(combine_randomness(c, cols[k], beta, None) for k in range(3))
@@ -249,17 +286,17 @@ def nark_as_prove(c, A_m, B_m, C_m, gens, H, num_input: int, num_witness: int, i
     if not inputs and not accs:  # default input :761-768
         zero_msg = {"comm_a": None, "comm_b": None, "comm_c": None, "randomness": None}
         inputs.append({"inst": {"r1cs_input": [0] * num_input, "first_msg": zero_msg},
-                       "wit": {"blinded_witness": [0] * num_witness, "randomness": None}})
+                       "wit": {"blinded_witness": ops.const(c, 0, num_witness), "randomness": None}})
     proof_randomness = prover_wit_rand = None
     if make_zk:  # generate_prover_randomness :366-420
         r_in = [rnd["r_input"] % c.r] * num_input
-        r_wit = [rnd["r_witness"] % c.r] * num_witness
+        r_wit = ops.const(c, rnd["r_witness"], num_witness)
         r1, r2, r3 = rnd["rand_1"], rnd["rand_2"], rnd["rand_3"]
         proof_randomness = {
             "r1cs_r_input": r_in,
-            "comm_r_a": o.pedersen_commit(c, gens, H, o.matrix_vec_mul(c, A_m, r_in, r_wit), r1),
-            "comm_r_b": o.pedersen_commit(c, gens, H, o.matrix_vec_mul(c, B_m, r_in, r_wit), r2),
-            "comm_r_c": o.pedersen_commit(c, gens, H, o.matrix_vec_mul(c, C_m, r_in, r_wit), r3),
+            "comm_r_a": ops.pedersen_commit(c, gens, H, ops.matrix_vec_mul(c, A_m, r_in, r_wit), r1),
+            "comm_r_b": ops.pedersen_commit(c, gens, H, ops.matrix_vec_mul(c, B_m, r_in, r_wit), r2),
+            "comm_r_c": ops.pedersen_commit(c, gens, H, ops.matrix_vec_mul(c, C_m, r_in, r_wit), r3),
         }
         prover_wit_rand = (r_wit, r1, r2, r3)
     in_insts = [x["inst"] for x in inputs]
@@ -268,8 +305,8 @@ def nark_as_prove(c, A_m, B_m, C_m, gens, H, num_input: int, num_witness: int, i
     hp_inputs = []
     for x, a, b, p in zip(inputs, A, B, P):  # compute_hp_input_instances / _witnesses :289-363
         w = x["wit"]
-        a_vec = o.matrix_vec_mul(c, A_m, x["inst"]["r1cs_input"], w["blinded_witness"])
-        b_vec = o.matrix_vec_mul(c, B_m, x["inst"]["r1cs_input"], w["blinded_witness"])
+        a_vec = ops.matrix_vec_mul(c, A_m, x["inst"]["r1cs_input"], w["blinded_witness"])
+        b_vec = ops.matrix_vec_mul(c, B_m, x["inst"]["r1cs_input"], w["blinded_witness"])
         s = w["randomness"]  # HPInputWitnessRandomness{rand_1: sigma_a, rand_2: sigma_b, rand_3: sigma_o}  (:341-352)
         hp_inputs.append({"inst": (a, b, p), "wit": {"a": a_vec, "b": b_vec, "rand": None if s is None else (s[0], s[1], s[3])}})
     hp_accs = [{"inst": x["inst"]["hp_instance"], "wit": x["wit"]["hp_witness"]} for x in accs]
@@ -290,10 +327,10 @@ def nark_as_decide(c, A_m, B_m, C_m, gens, H, acc: dict) -> bool:
     """src/r1cs_nark_as/mod.rs:1031-1112"""
     inst, wit = acc["inst"], acc["wit"]
     s = wit["randomness"] if wit["randomness"] is not None else (None, None, None)
-    za, zb, zc = (o.matrix_vec_mul(c, M, inst["r1cs_input"], wit["r1cs_blinded_witness"]) for M in (A_m, B_m, C_m))
-    ok = (o.pedersen_commit(c, gens, H, za, s[0]) == inst["comm_a"] and
-          o.pedersen_commit(c, gens, H, zb, s[1]) == inst["comm_b"] and
-          o.pedersen_commit(c, gens, H, zc, s[2]) == inst["comm_c"])
+    za, zb, zc = (ops.matrix_vec_mul(c, M, inst["r1cs_input"], wit["r1cs_blinded_witness"]) for M in (A_m, B_m, C_m))
+    ok = (ops.pedersen_commit(c, gens, H, za, s[0]) == inst["comm_a"] and
+          ops.pedersen_commit(c, gens, H, zb, s[1]) == inst["comm_b"] and
+          ops.pedersen_commit(c, gens, H, zc, s[2]) == inst["comm_c"])
     return ok and hp_decide(c, gens, H, {"inst": inst["hp_instance"], "wit": wit["hp_witness"]})
 
 

@@ -33,8 +33,10 @@ def test_default_line_n1(built_lib):
     assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(d["roofline"])
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_result_bit_exact_vs_cpu"] is True
     assert d["cpu_baseline"]["timed_batch_msms_checked"] == 12  # every MSM of the timed batch against the CPU result
-    acc = {k: v for k, v in d["accumulations"].items() if isinstance(v, dict)}
+    acc = {k: v for k, v in d["accumulations"].items() if isinstance(v, dict) and "accumulations_per_s" in v}
     assert len(acc) == 8 and all(v.get("verified") for v in acc.values()), d["accumulations"]  # 4 schemes x 2 shapes
+    assert all(v["sponge"] == "poseidon" for v in acc.values())  # the reference's sponge, not the SHA-256 stand-in
+    assert len(d["accumulations"]["sha256_standin_prove_ms"]) == 8
     assert any(k.endswith("harness_1in_2acc_zk") for k in acc)
     assert "workload" in d["config"] and d["config"]["ms_per_msm_host_scalars"] > d["config"]["ms_per_msm_synchronous_call"] * 0.9
     assert d["roofline"]["traffic_source"] and set(d["stage_ms"]) == {"in_batch", "blocking_call"}

@@ -3,6 +3,7 @@ the one GPU of the test box, each holds half of the generators and half of every
 unchanged on the slices -- commitments go through dist.ShardedMSM (per-rank partial records + one all-gather; gloo here,
 RCCL on a multi-GPU node).  The accumulator instances and proofs must equal the unsharded run's bit for bit, the
 accumulator's witness vectors must be the corresponding slices, and verify / decide must pass on every rank."""
+import hashlib
 import os
 import tempfile
 
@@ -19,7 +20,7 @@ def _pt(p):
     return (np.asarray(p[0], dtype=np.uint64).tolist(), bool(p[1]))
 
 
-def _run(ctx, ck, lo, hi, make_zk, commit, AS):
+def _run(ctx, ck, lo, hi, make_zk, commit, AS, N=N):
     """Two inputs -> accumulator; a third input + that accumulator -> second accumulator; verify both, decide the last."""
     from accumulation_amd.hp_as import Accumulator, InputInstance, InputWitness, InputWitnessRandomness, compute_hp
     from accumulation_amd.scalar_field import Fr
@@ -47,12 +48,17 @@ def _run(ctx, ck, lo, hi, make_zk, commit, AS):
     inst = [_pt(acc2.instance.comm_1), _pt(acc2.instance.comm_2), _pt(acc2.instance.comm_3)]
     low = [_pt(p) for p in proof2.product_poly_comm.low]
     return {"ok": [bool(ok1), bool(ok2), bool(dec)], "instance": inst, "low": low,
-            "a": acc2.witness.a_vec.download().tolist(), "b": acc2.witness.b_vec.download().tolist(),
+            "a": acc2.witness.a_vec.download(), "b": acc2.witness.b_vec.download(),
             "rand": None if acc2.witness.randomness is None else
             [acc2.witness.randomness.rand_1, acc2.witness.randomness.rand_2, acc2.witness.randomness.rand_3]}
 
 
-def _worker(rank, world, init_file, make_zk, q):
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()
+
+
+def _worker(rank, world, init_file, make_zk, q, N=N, digest=False):
+    """digest: the witness slices travel back as SHA-256 (config-size runs: 2^22 elements)"""
     import torch.distributed as dist
     from accumulation_amd import CommitterKey, Context, PedersenCommitment, ffi
     from accumulation_amd.dist import ShardedCommitterKey
@@ -64,8 +70,10 @@ def _worker(rank, world, init_file, make_zk, q):
         xy, _ = tmp.read()
         ck = ShardedCommitterKey.from_global(ctx, xy[:N], hiding_generator=xy[N].copy())
         assert ck.supported_num_elems() == N and ck.local_num_elems() == ck.hi - ck.lo
-        res = _run(ctx, ck, ck.lo, ck.hi, make_zk, PedersenCommitment.commit, AS)
+        res = _run(ctx, ck, ck.lo, ck.hi, make_zk, PedersenCommitment.commit, AS, N)
         res["range"] = (ck.lo, ck.hi)
+        for k in ("a", "b"):
+            res[k] = sha(res[k]) if digest else res[k].tolist()
         # the no-input default accumulator on a sharded key (src/hp_as/mod.rs:685-696): local-length zero vectors
         acc0, proof0 = AS.prove(ck, [], [], None, None)
         res["default_ok"] = bool(AS.verify(ctx, N, [], [], acc0.instance, proof0, None)) and bool(AS.decide(ck, acc0, None)) \
@@ -76,19 +84,17 @@ def _worker(rank, world, init_file, make_zk, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
-def test_hp_as_sharded_equals_unsharded(built_lib, make_zk, world):
+def run_sharded_vs_unsharded(make_zk, world, N=N, digest=False, timeout=600):
     import torch.multiprocessing as mp
     from accumulation_amd import CommitterKey, Context, PedersenCommitment, ffi
     from accumulation_amd.hp_as import ASForHadamardProducts as AS
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     with tempfile.TemporaryDirectory() as d:
-        procs = [mpc.Process(target=_worker, args=(r, world, os.path.join(d, "init"), make_zk, q)) for r in range(world)]
+        procs = [mpc.Process(target=_worker, args=(r, world, os.path.join(d, "init"), make_zk, q, N, digest)) for r in range(world)]
         for p in procs:
             p.start()
-        got = dict(q.get(timeout=600) for _ in range(world))
+        got = dict(q.get(timeout=timeout) for _ in range(world))
         for p in procs:
             p.join(timeout=120)
             assert p.exitcode == 0
@@ -96,8 +102,9 @@ def test_hp_as_sharded_equals_unsharded(built_lib, make_zk, world):
     tmp = CommitterKey.generate(ctx, KEY_SEED, N + 1, ffi.AMSM_BASES_NO_PRECOMPUTE)
     xy, _ = tmp.read()
     ck = CommitterKey.load(ctx, xy[:N], None, ffi.AMSM_BASES_DEFAULT, hiding_generator=xy[N].copy())
-    ref = _run(ctx, ck, 0, N, make_zk, PedersenCommitment.commit, AS)
+    ref = _run(ctx, ck, 0, N, make_zk, PedersenCommitment.commit, AS, N)
     assert ref["ok"] == [True, True, True]
+    cut = (lambda v, lo, hi: sha(v[lo:hi])) if digest else (lambda v, lo, hi: v[lo:hi].tolist())
     covered = 0
     for rank in range(world):
         r = got[rank]
@@ -106,7 +113,13 @@ def test_hp_as_sharded_equals_unsharded(built_lib, make_zk, world):
         assert r["instance"] == ref["instance"], rank          # same accumulator instance, bit for bit
         assert r["low"] == ref["low"], rank                    # same proof
         assert r["rand"] == ref["rand"], rank
-        assert r["a"] == ref["a"][lo:hi] and r["b"] == ref["b"][lo:hi], rank  # the witness is the slice
+        assert r["a"] == cut(ref["a"], lo, hi) and r["b"] == cut(ref["b"], lo, hi), rank  # the witness is the slice
         covered += hi - lo
     assert covered == N
     ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
+def test_hp_as_sharded_equals_unsharded(built_lib, make_zk, world):
+    run_sharded_vs_unsharded(make_zk, world)

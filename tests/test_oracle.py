@@ -184,3 +184,36 @@ def test_t_vecs_identity():
     # the uncommitted middle coefficient is sum_j mu_j (a_j o b_j)   (src/hp_as/mod.rs:373-375)
     mid = [sum(mu[j] * a[j][li] * b[j][li] for j in range(n_in)) % c.r for li in range(ln)]
     assert t[n_in - 1] == mid
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_c_t_vecs_and_spmv_match_python_oracle(c, cref):
+    """the C restatements the config-size GPU tests check against (2^22-element t-vectors, 2^18-row SpMV) equal the
+    big-int restatements of src/hp_as/mod.rs:288-349 and src/r1cs_nark_as/r1cs_nark/mod.rs:443-462 on ragged inputs"""
+    import random
+    for n in (1, 2, 3, 4):
+        for zk in (False, True):
+            ln = 19
+            a = [o.rng_scalars(100 + j, ln if j != 1 else ln - 5) for j in range(n)]
+            b = [o.rng_scalars(200 + j, ln if j != 0 else ln - 2) for j in range(n)]
+            mu = [1] + o.rng_scalars(300, n)
+            hid = (o.rng_scalars(400, ln), o.rng_scalars(401, ln - 2)) if zk else None
+            exp = o.compute_t_vecs(c, a, b, mu, ln, hid)
+            got = cref.fr_t_vecs(c.curve_id, [h.fr_mont_np(c, v) for v in a], [h.fr_mont_np(c, v) for v in b],
+                                 h.fr_mont_np(c, mu), ln,
+                                 None if not zk else (h.fr_mont_np(c, hid[0]), h.fr_mont_np(c, hid[1])))
+            assert len(got) == 2 * n - 1
+            for k in range(2 * n - 1):
+                assert h.fr_from_mont_np(c, got[k]) == exp[k], (n, zk, k)
+    rnd = random.Random(5)
+    rows = [[(rnd.randrange(c.r), rnd.randrange(7)) for _ in range(rnd.randrange(4))] for _ in range(11)]
+    inp, wit = o.rng_scalars(1, 3), o.rng_scalars(2, 4)
+    rp, col, co = [0], [], []
+    for r in rows:
+        for cf, i in r:
+            col.append(i)
+            co.append(cf)
+        rp.append(len(col))
+    got = cref.fr_spmv(c.curve_id, np.array(rp), np.array(col, dtype=np.uint64), h.fr_mont_np(c, co), h.fr_mont_np(c, inp),
+                       h.fr_mont_np(c, wit))
+    assert h.fr_from_mont_np(c, got) == o.matrix_vec_mul(c, rows, inp, wit)

@@ -67,7 +67,7 @@ static void report(const Opt& o, const char* scheme, int log_size, const char* s
          "\"serialize_roundtrip_decides\": %s, \"reps\": %d}\n",
          scheme, size_name, log_size, shape, zk ? "true" : "false", o.sponge.c_str(), r.index_ms, r.prove_ms, r.verify_ms,
          r.decide_ms, 1000.0 / r.prove_ms, r.acc_bytes, r.inst_bytes, r.wit_bytes, r.verified ? "true" : "false",
-         r.decided ? "true" : "false", r.roundtrip ? "true" : "false", o.reps);
+         r.decided ? "true" : "false", !o.roundtrip ? "null" : (r.roundtrip ? "true" : "false"), o.reps);
   fflush(stdout);
 }
 
