@@ -31,6 +31,7 @@ struct PallasFqU {
   static constexpr int B = 29;
   static constexpr bool UNSAT = true;
   static constexpr u32 NINV = 0x1fffffffu;  // -p^-1 mod 2^B
+  static constexpr bool CHAIN = true;       // u_opaque after every column (measured, tools/fp_bench.hip: mixed addition -1 %)
   // p, R' mod p, R'^2 / R mod p (ABI -> internal), R mod p (internal -> ABI); radix 2^29, checked in tests/test_oracle.py
   AMSM_TABLE(mod, 9, 0x00000001u, 0x09698768u, 0x133e46e6u, 0x0d31f812u, 0x00000224u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00400000u)
   AMSM_TABLE(one, 9, 0x1fffff81u, 0x14a5d367u, 0x141ad3c0u, 0x1435eec5u, 0x1ffeefefu, 0x1fffffffu, 0x1fffffffu, 0x1fffffffu, 0x003fffffu)
@@ -46,6 +47,7 @@ struct Bls12381FqU {  // 14 x 28 bits, R' = 2^392 ~ 2520 p: measured against the
   static constexpr int B = 28;
   static constexpr bool UNSAT = true;
   static constexpr u32 NINV = 0x0ffcfffdu;
+  static constexpr bool CHAIN = false;  // measured: the opaque carry costs the 14-limb mixed addition 4 % (register pressure)
   AMSM_TABLE(mod, 14, 0x0fffaaabu, 0x0fefffffu, 0x03ffffb9u, 0x0fffeb15u, 0x06241eabu, 0x0a0f6b0fu, 0x0f6730d2u, 0x0f38512bu, 0x04774b84u, 0x04bacd76u, 0x0ba7b643u, 0x0e69a4b1u, 0x01ea397fu, 0x0001a011u)
   AMSM_TABLE(one, 14, 0x0347fcb8u, 0x0d800000u, 0x0002b119u, 0x00cde6d2u, 0x0c7212e0u, 0x083a2090u, 0x0037669fu, 0x0da0f73eu, 0x09b09b42u, 0x01297bb0u, 0x0515d98fu, 0x0012ca7cu, 0x0659fcfau, 0x0000577au)
   AMSM_TABLE(k_import, 14, 0x080e6299u, 0x03500034u, 0x0eb12856u, 0x0deb2699u, 0x0c988670u, 0x04ef6697u, 0x070983e8u, 0x0a4e6fe9u, 0x03e8a053u, 0x0ecf271eu, 0x0c20d323u, 0x06eb6385u, 0x047f1286u, 0x000156dau)
@@ -55,6 +57,98 @@ struct Bls12381FqU {  // 14 x 28 bits, R' = 2^392 ~ 2520 p: measured against the
 template <class P>
 AMSM_HD constexpr u32 u_mask() {
   return (1u << P::B) - 1u;
+}
+
+// ---- reduction-step knobs (round 3; A/B with tools/fp_bench.hip: -DAMSM_UCHAIN=0 -DAMSM_UCONST=0 restore round 2) ----
+// The compiler's own schedule of a 9 x 29 product (round 2) kept one 64-bit accumulator chain PER COLUMN, started from zero,
+// and merged it with the carry of the column below by a 64-bit add (v_lshl_add_u64: half rate); the reduction step added
+// m * p_0 = m as a zero-extended 64-bit add (v_mov + v_lshl_add_u64) and m * 2^22 as a 64-bit shift + 64-bit add: 99 non-MAD
+// instructions per multiplication, 63 of them half rate, next to 117 MADs.  Round 3:
+//   AMSM_UCHAIN: an opaque (empty-asm) use of the accumulator after every column shift, so that the next column's MADs chain
+//                from the carry instead of from zero (no merge add);
+//   AMSM_UCONST: p_0 = 1 (Pallas: p = 1 mod 2^29): (acc + m) >> B == (acc + 2^B - 1) >> B, one 64-bit add of a constant and no
+//                m in the low column; a power-of-two limb of p (2^22 at limb 8) as a MAD by a constant held in an SGPR the
+//                compiler cannot see through (one half-rate instruction instead of shift + add).
+// Measured (MI355X, cycles per operation per SIMD at 2 / 4 waves per SIMD): Pallas multiplication 899 / 862 -> 877 / 822, squaring
+// 747 / 709 -> 715 / 685, mixed addition 8 640 / 8 288 -> 8 208 / 7 963 (-5 % / -4 %); 126 MADs + 81 full-rate + 40 half-rate
+// instructions per multiplication instead of 117 + 89 + 59.  BLS12-381 (p_0 != 1, no power-of-two limb) is unchanged.  A strictly
+// linear chain (an opaque use after EVERY product, AMSM_UCHAIN=2) removes the remaining merge adds but spills: 12 300.
+#ifndef AMSM_UCHAIN
+#define AMSM_UCHAIN 1
+#endif
+#ifndef AMSM_UCONST
+#define AMSM_UCONST 1
+#endif
+template <class P>
+AMSM_DEV void u_opaque(u64& acc) {
+#if AMSM_UCHAIN
+  if constexpr (P::CHAIN) asm("" : "+v"(acc));
+#endif
+}
+AMSM_DEV void u_opaque2(u64& acc) {  // AMSM_UCHAIN=2 (experiment): a strictly linear MAD chain, opaque after every product
+#if AMSM_UCHAIN >= 2
+  asm("" : "+v"(acc));
+#endif
+}
+template <u32 V>
+AMSM_DEV u32 u_sgpr_const() {  // V in an SGPR, opaque to the optimiser (hoisted out of loops like any pure expression)
+  u32 r;
+  asm("s_mov_b32 %0, %1" : "=s"(r) : "i"(V));
+  return r;
+}
+AMSM_HD constexpr bool u_is_pow2(u32 v) { return v != 0 && (v & (v - 1)) == 0; }
+
+// acc += m_i * p_j for the limbs j >= 1 of p that are not zero (column k of a product: i + j = k)
+template <class P, int I, int K>
+AMSM_DEV void u_red_term(u64& acc, const u32* m) {
+  constexpr int J = K - I;
+  if constexpr (I < K && J >= 1 && J < P::L) {
+    if constexpr (P::mod(J) != 0) {
+#if AMSM_UCONST
+      if constexpr (u_is_pow2(P::mod(J))) acc += (u64)m[I] * u_sgpr_const<P::mod(J)>();
+      else
+#endif
+        acc += (u64)m[I] * P::mod(J);
+      u_opaque2(acc);
+    }
+  }
+}
+template <class P, int K, int I = 0>
+AMSM_DEV void u_red_terms(u64& acc, const u32* m) {
+  if constexpr (I < P::L) {
+    u_red_term<P, I, K>(acc, m);
+    u_red_terms<P, K, I + 1>(acc, m);
+  }
+}
+// low column k < L: m_k = -acc * p^-1 mod 2^B, acc = (acc + m_k p_0) >> B
+template <class P>
+AMSM_DEV u32 u_red_low(u64& acc) {
+  constexpr u32 M = u_mask<P>();
+  const u32 lo = (u32)acc & M;
+  u32 mk;
+  if constexpr (P::NINV == M) {  // p_0 = 1
+    mk = (0u - lo) & M;
+#if AMSM_UCONST
+    acc = (acc + (u64)M) >> P::B;  // == (acc + mk) >> B: lo + mk is 0 or 2^B
+#else
+    acc += (u64)mk;
+    acc >>= P::B;
+#endif
+  } else {
+    mk = (lo * P::NINV) & M;
+    acc += (u64)mk * P::mod(0);
+    acc >>= P::B;
+  }
+  u_opaque<P>(acc);
+  return mk;
+}
+// high column k >= L: emit limb k - L
+template <class P>
+AMSM_DEV u32 u_red_high(u64& acc, bool top) {
+  const u32 r = top ? (u32)acc : ((u32)acc & u_mask<P>());
+  acc >>= P::B;
+  if (!top) u_opaque<P>(acc);
+  return r;
 }
 
 // K*p as tight limbs (compile-time)
@@ -106,36 +200,41 @@ AMSM_DEV void u_carry(Fe<P>& a) {
 // With ADD: returns a*b / 2^(B*L) + add, the addend's limbs (any u32, e.g. the unnormalised K*p - x) going straight
 // into the upper columns of the product, so "product minus value" costs L 64-bit adds instead of a subtraction and
 // a carry pass, and the result is tight.
+template <class P, int K, class F>
+AMSM_DEV void u_column(u64& acc, u32* m, Fe<P>& r, const Fe<P>* add, bool has_add, F&& products) {
+  products(acc);
+  u_red_terms<P, K>(acc, m);
+  if constexpr (K < P::L) {
+    m[K] = u_red_low<P>(acc);
+  } else {
+    if (has_add) acc += add->v[K - P::L];
+    r.v[K - P::L] = u_red_high<P>(acc, K == 2 * P::L - 1);
+  }
+}
+template <class P, int K, class F>
+AMSM_DEV void u_columns(u64& acc, u32* m, Fe<P>& r, const Fe<P>* add, bool has_add, F&& products) {
+  if constexpr (K < 2 * P::L) {
+    u_column<P, K>(acc, m, r, add, has_add, [&](u64& a) { products(a, K); });
+    u_columns<P, K + 1>(acc, m, r, add, has_add, products);
+  }
+}
+
 template <class P, bool ADD = false>
 AMSM_DEV Fe<P> u_mul(const Fe<P>& a, const Fe<P>& b, const Fe<P>* add = nullptr) {
   constexpr int L = P::L;
-  constexpr u32 M = u_mask<P>();
   u64 acc = 0;
   u32 m[L];
   Fe<P> r;
-#pragma unroll
-  for (int k = 0; k < 2 * L; k++) {
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-      int j = k - i;
-      if (j >= 0 && j < L) acc += (u64)a.v[i] * b.v[j];
-    }
+  u_columns<P, 0>(acc, m, r, add, ADD, [&](u64& ac, int k) {
 #pragma unroll
     for (int i = 0; i < L; i++) {
       int j = k - i;
-      if (i < k && j >= 1 && j < L && P::mod(j < 0 || j >= L ? 0 : j) != 0) acc += (u64)m[i] * P::mod(j < 0 || j >= L ? 0 : j);
+      if (j >= 0 && j < L) {
+        ac += (u64)a.v[i] * b.v[j];
+        u_opaque2(ac);
+      }
     }
-    if (k < L) {
-      u32 lo = (u32)acc & M;
-      m[k] = (P::NINV == M) ? ((0u - lo) & M) : ((lo * P::NINV) & M);
-      acc += (u64)m[k] * P::mod(0);
-      acc >>= P::B;
-    } else {
-      if (ADD) acc += add->v[k - L];
-      r.v[k - L] = (k == 2 * L - 1) ? (u32)acc : ((u32)acc & M);
-      acc >>= P::B;
-    }
-  }
+  });
   return r;
 }
 
@@ -145,35 +244,21 @@ AMSM_DEV Fe<P> u_mul(const Fe<P>& a, const Fe<P>& b, const Fe<P>* add = nullptr)
 template <class P>
 AMSM_DEV Fe<P> u_mul_add_mul(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
   constexpr int L = P::L;
-  constexpr u32 M = u_mask<P>();
   u64 acc = 0;
   u32 m[L];
   Fe<P> r;
-#pragma unroll
-  for (int k = 0; k < 2 * L; k++) {
+  u_columns<P, 0>(acc, m, r, nullptr, false, [&](u64& ac, int k) {
 #pragma unroll
     for (int i = 0; i < L; i++) {
       int j = k - i;
       if (j >= 0 && j < L) {
-        acc += (u64)a.v[i] * b.v[j];
-        acc += (u64)c.v[i] * d.v[j];
+        ac += (u64)a.v[i] * b.v[j];
+        u_opaque2(ac);
+        ac += (u64)c.v[i] * d.v[j];
+        u_opaque2(ac);
       }
     }
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-      int j = k - i;
-      if (i < k && j >= 1 && j < L && P::mod(j < 0 || j >= L ? 0 : j) != 0) acc += (u64)m[i] * P::mod(j < 0 || j >= L ? 0 : j);
-    }
-    if (k < L) {
-      u32 lo = (u32)acc & M;
-      m[k] = (P::NINV == M) ? ((0u - lo) & M) : ((lo * P::NINV) & M);
-      acc += (u64)m[k] * P::mod(0);
-      acc >>= P::B;
-    } else {
-      r.v[k - L] = (k == 2 * L - 1) ? (u32)acc : ((u32)acc & M);
-      acc >>= P::B;
-    }
-  }
+  });
   return r;
 }
 
@@ -193,39 +278,23 @@ AMSM_DEV Fe<P> u_kp_minus_lazy(const Fe<P>& y) {
 template <class P, bool ADD = false>
 AMSM_DEV Fe<P> u_sqr(const Fe<P>& a, const Fe<P>* add = nullptr) {
   constexpr int L = P::L;
-  constexpr u32 M = u_mask<P>();
   u32 a2[L];
 #pragma unroll
   for (int i = 0; i < L; i++) a2[i] = a.v[i] << 1;
   u64 acc = 0;
   u32 m[L];
   Fe<P> r;
-#pragma unroll
-  for (int k = 0; k < 2 * L; k++) {
+  u_columns<P, 0>(acc, m, r, add, ADD, [&](u64& ac, int k) {
 #pragma unroll
     for (int i = 0; i < L; i++) {
       int j = k - i;
       if (j >= 0 && j < L) {
-        if (i < j) acc += (u64)a2[i] * a.v[j];
-        else if (i == j) acc += (u64)a.v[i] * a.v[i];
+        if (i < j) ac += (u64)a2[i] * a.v[j];
+        else if (i == j) ac += (u64)a.v[i] * a.v[i];
+        if (i <= j) u_opaque2(ac);
       }
     }
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-      int j = k - i;
-      if (i < k && j >= 1 && j < L && P::mod(j < 0 || j >= L ? 0 : j) != 0) acc += (u64)m[i] * P::mod(j < 0 || j >= L ? 0 : j);
-    }
-    if (k < L) {
-      u32 lo = (u32)acc & M;
-      m[k] = (P::NINV == M) ? ((0u - lo) & M) : ((lo * P::NINV) & M);
-      acc += (u64)m[k] * P::mod(0);
-      acc >>= P::B;
-    } else {
-      if (ADD) acc += add->v[k - L];
-      r.v[k - L] = (k == 2 * L - 1) ? (u32)acc : ((u32)acc & M);
-      acc >>= P::B;
-    }
-  }
+  });
   return r;
 }
 

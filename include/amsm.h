@@ -375,7 +375,10 @@ int amsm_ipa_round(amsm_ctx* ctx, const amsm_bases* key, const uint64_t* xi_mont
  *  - h_prime_xy != NULL (affine, Montgomery, finite): out_lr = L_j + <c_r, z_l> h', R_j + <c_l, z_r> h' -- the two
  *    multiples are computed on the host while the MSM's tail runs, added in extended coordinates and L, R normalised
  *    with ONE inversion (amsm_ipa_round + two amsm_host_lincomb calls: three).
- * With both NULL it is amsm_ipa_round.  The driver's loop is one call per round plus the round's challenge. */
+ * With both NULL it is amsm_ipa_round.  The driver's loop is one call per round plus the round's challenge.
+ * Errors: argument errors and AMSM_E_OOM (every allocation of the round is made first) leave d_coeffs / d_z untouched, so the
+ * call can be retried; any later error (AMSM_E_SCALAR_RANGE, AMSM_E_HIP) returns with the fold ALREADY applied -- the
+ * vectors are consumed, do not retry with fold_x_mont set. */
 int amsm_ipa_round_fused(amsm_ctx* ctx, const amsm_bases* key, const uint64_t* xi_mont, size_t j, size_t log_key,
                          void* d_coeffs, void* d_z, const uint64_t* fold_x_mont, const uint64_t* h_prime_xy, void* d_u,
                          uint64_t* out_lr_xy, uint8_t* out_lr_inf, uint64_t* out_ip_mont);
