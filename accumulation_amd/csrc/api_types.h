@@ -29,6 +29,16 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   hipEvent_t done = nullptr;
   DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
       sort_tmp, scan_tmp, prep_small, heavy_scratch;
+  DevBuf bpl_grp, bpl_order;  // bucket-per-lane pipeline: group headers, bucket order (entries live in vals_a / vals_b)
+  // the MSM this slot carries, kept until it is collected: a bucket-per-lane MSM whose prep reports a skewed input is
+  // re-run from here through the chunked pipeline (msm_collect)
+  struct Job {
+    const amsm_bases* bases = nullptr;
+    size_t base_off = 0, n = 0;
+    const void* d_scalars = nullptr;
+    int mont = 0;
+    int (*rerun)(amsm_ctx*, Slot*) = nullptr;
+  } job;
   void* h_pinned = nullptr;
   size_t h_pinned_bytes = 0;
   MsmGeom geom = {};
@@ -158,6 +168,9 @@ struct amsm_ctx {
   int split_min_log2 = 22;  // generators (msm_multi_split_xyzz; AMSM_SPLIT_LOG2=0 disables, AMSM_SPLIT_MIN_LOG2)
   bool one_stream = true;  // a lone blocking MSM runs its whole chain on the caller's stream (AMSM_ONE_STREAM=0: per-stage streams, A/B)
   bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
+  bool bpl = true;  // keys of 2^20 generators and more are precomputed for 20-bit windows and their MSMs of (2^19, 2^20] pairs
+                    // take the bucket-per-lane pipeline (AMSM_BPL=0: 17-bit windows + the chunked pipeline, round 2's path)
+  unsigned long long n_bpl = 0, n_bpl_fallbacks = 0;  // MSMs that took it / that were re-run chunked (skewed digits)
   bool profiling = false;
   float stage_ms[ST_COUNT] = {};  // mean over the MSMs of the last call
   float stage_acc[ST_COUNT] = {};
@@ -204,6 +217,13 @@ struct amsm_bases {
   // recorded by amsm_bases_fold behind the kernel that writes d_table (it returns without synchronising): consumers that
   // are not ordered behind the folding context's stream (amsm_bases_device_ptr) wait for it
   hipEvent_t ready = nullptr;
+  // bpl: the table holds the multiples for 20-bit windows (13 levels) and MSMs of (2^19, 2^20] pairs over it run the
+  // bucket-per-lane pipeline.  Everything that pipeline does not take (shorter ranges, grouped MSMs, skewed scalars) runs
+  // over `alt`, the same generators precomputed for 17-bit windows, built on first use (under alt_mu: keys are shared)
+  int bpl = 0;
+  int top_shift = 0;  // MsmGeom::top_shift of the table (level W - 1 = 2^(c (W - 1) - top_shift) G)
+  mutable amsm_bases* alt = nullptr;
+  mutable std::mutex alt_mu;
   // sharded key of a multi-device context: shard g (a single-device key on shard_ctx[g]'s device) holds generators
   // [bound[g], bound[g + 1]); n is the total, d_table stays null
   std::vector<amsm_bases*> shards;

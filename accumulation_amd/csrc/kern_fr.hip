@@ -94,6 +94,60 @@ bool prep_supported(const MsmGeom& g) {
          prep_local_lds(pg) <= PREP_LDS_LIMIT && (pg.P + 256) * sizeof(u32) <= 64 * 1024;
 }
 
+// ---- bucket-per-lane prep (k_prep_local_t): partitions of exactly 1024 buckets, one 1024-lane workgroup each ----
+static PrepGeom prep_bpl_geom(const MsmGeom& g) {
+  PrepGeom pg;
+  pg.SH = 10;
+  pg.P = g.B >> pg.SH;
+  pg.SPB = 512;
+  unsigned long long max_idx = (unsigned long long)g.base_off + g.n - 1ull + (unsigned long long)(g.W - 1u) * g.table_stride;
+  if (g.idx_rel_bits) max_idx = ((unsigned long long)(g.W - 1u) << g.idx_rel_bits) | ((1ull << g.idx_rel_bits) - 1ull);
+  pg.IB = 1;
+  while ((max_idx >> pg.IB) != 0ull) pg.IB++;
+  const u32 nb = 1u << pg.SH;
+  const u32 budget_words = 37888u, fixed_words = 4u * nb + 1024u + BPL_BINS + 2u * (nb / BPL_GROUP) + 2u;
+  pg.CAP = budget_words - fixed_words;  // ~31.4 k entries: a partition of a 2^20-pair MSM holds ~26.6 k
+  pg.HEAVY = 0xffffffffu;
+  return pg;
+}
+static size_t prep_bpl_local_lds(const PrepGeom& pg) {
+  const u32 nb = 1u << pg.SH;
+  return (size_t)(4u * nb + 1024u + BPL_BINS + 2u * (nb / BPL_GROUP) + 2u + pg.CAP) * sizeof(u32);
+}
+static size_t prep_bpl_scatter_lds(const MsmGeom& g, const PrepGeom& pg) {
+  const size_t cap = (size_t)pg.SPB * g.S;
+  return (3 * (size_t)pg.P + 2 * cap) * sizeof(u32) + cap * sizeof(uint16_t);
+}
+u32 prep_bpl_partitions(const MsmGeom& g) { return g.B >> 10; }
+// transposed entries per partition: the expected partition size + 25 % (the padding to each group's largest bucket is ~6 %
+// on uniform digits) + a constant; anything that does not fit is a skewed input and takes the fallback
+u32 prep_bpl_stride(const MsmGeom& g) {
+  const u32 P = std::max(1u, prep_bpl_partitions(g));
+  const unsigned long long per = ((unsigned long long)g.E + P - 1) / P;
+  return (u32)((per + per / 4ull + 4096ull + 1023ull) & ~1023ull);
+}
+bool prep_bpl_supported(const MsmGeom& g) {
+  if (!g.precomp || g.groups != 1u || g.n_sets != 1u || g.S > 16u || g.n == 0) return false;
+  if (g.B < (1u << 16) || (g.B & 1023u) || (g.B >> 10) > PREP_MAX_P || ((g.B >> 10) & 1u)) return false;
+  PrepGeom pg = prep_bpl_geom(g);
+  if (pg.IB > 30u) return false;
+  // the expected partition must fit the LDS stage with room for the digits' spread
+  if ((unsigned long long)g.E / pg.P + 2048ull > pg.CAP) return false;
+  return prep_bpl_scatter_lds(g, pg) <= PREP_LDS_LIMIT && prep_bpl_local_lds(pg) <= PREP_LDS_LIMIT &&
+         (unsigned long long)pg.P * prep_bpl_stride(g) < (1ull << 31);
+}
+static std::atomic<unsigned long long> prep_bpl_attr_devices{0};
+template <class KS>
+static void prep_bpl_attr(KS scatter_kernel) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  const unsigned long long bit = 1ull << dev;
+  (void)hipFuncSetAttribute((const void*)scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_LDS_LIMIT);
+  if (dev != 63 && (prep_bpl_attr_devices.load(std::memory_order_acquire) & bit)) return;
+  (void)hipFuncSetAttribute((const void*)k_prep_local_t, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  prep_bpl_attr_devices.fetch_or(bit, std::memory_order_release);
+}
+
 void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
   hipLaunchKernelGGL(k_vec_fill, dim3(cdiv_(n, 256)), dim3(256), 0, st, out, make_uint4(v[0], v[1], v[2], v[3]),
                      make_uint4(v[4], v[5], v[6], v[7]), n);
@@ -156,6 +210,37 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
                          b.vals_sorted);                                                                             \
     hipLaunchKernelGGL(k_prep_offsets, dim3(cdiv_(g.B, 256)), dim3(256), (pg.P + 256) * sizeof(u32), st, part_start, \
                        part_items, pg, g, b.start, b.items, b.item_off, b.vals_sorted);                              \
+    return 0;                                                                                                        \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  int launch_prep_bpl<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBplBuffers& b) {        \
+    PrepGeom pg = prep_bpl_geom(g);                                                                                  \
+    u32* part_total = b.d_small;                                                                                     \
+    u32* part_start = b.d_small + (PREP_MAX_P + 1);                                                                  \
+    u32* part_cursor = b.d_small + 2 * (PREP_MAX_P + 1);                                                             \
+    PrepHeavy hv;                                                                                                    \
+    hv.n = b.d_small + 4 * (PREP_MAX_P + 1);                                                                         \
+    hv.cnt = hv.n + 1;                                                                                               \
+    hv.ids = hv.cnt + 64;                   /* never written: no partition exceeds HEAVY = 2^32 - 1 */               \
+    hv.cur = hv.end = hv.ids;                                                                                        \
+    {  /* one fill: the 16 flag words, the partition totals / starts / cursors and the heavy count */                \
+      size_t zero_bytes = (16 + 4 * (PREP_MAX_P + 1) + 1) * sizeof(u32);                                             \
+      zero_bytes = (zero_bytes + 255) & ~(size_t)255;                                                                \
+      if (b.err != b.d_small - 16) return -1;                                                                        \
+      if (hipMemsetAsync(b.err, 0, zero_bytes, st) != hipSuccess) return -1;                                         \
+    }                                                                                                                \
+    prep_bpl_attr(k_prep_scatter<FR, 16, 1, true>);                                                                  \
+    {                                                                                                                \
+      PrepGeom ph = pg;                                                                                              \
+      ph.SPB = 1024;                                                                                                 \
+      hipLaunchKernelGGL((k_prep_hist<FR>), dim3(cdiv_(g.n, 1024)), dim3(1024), pg.P * sizeof(u32), st, scalars,      \
+                         mont, g, ph, part_total, b.err);                                                            \
+    }                                                                                                                \
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P, pg.HEAVY, hv);         \
+    hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1, true>), dim3(cdiv_(g.n, pg.SPB)), dim3(512),                       \
+                       prep_bpl_scatter_lds(g, pg), st, scalars, mont, g, pg, part_start, part_cursor, b.part);      \
+    hipLaunchKernelGGL(k_prep_local_t, dim3(pg.P), dim3(1024), prep_bpl_local_lds(pg), st, part_start,               \
+                       (const u64*)b.part, g, pg, prep_bpl_stride(g), b.ents_t, (BplGroup*)b.grp, b.order, b.err);   \
     return 0;                                                                                                        \
   }                                                                                                                  \
   template <>                                                                                                        \

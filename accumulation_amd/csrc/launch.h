@@ -12,6 +12,10 @@ namespace amsm {
 template <class Fq>
 void launch_accum_l0(hipStream_t st, const u32* table, const u32* vals_sorted, const u32* start,
                      const u32* item_off, MsmGeom g, u32* partials, u32 lds_pad = 0);
+// bucket-per-lane accumulation (msm_kernels.h: k_accum_bpl) over the transposed layout k_prep_local_t wrote
+template <class Fq>
+void launch_accum_bpl(hipStream_t st, const u32* table, const u32* ents_t, const void* grp, const u32* order, u32 n_groups,
+                      const u32* flags, u32* buckets);
 // resident 256-lane workgroups of accumulate L0 per CU (occupancy query); lds_pad = unused dynamic LDS per workgroup,
 // which caps the residency (AMSM_L0_LDS_PAD: leaves wave slots / registers to the kernels of the other MSMs in flight)
 template <class Fq>
@@ -76,6 +80,20 @@ struct PrepBuffers {
   u32* err;           // == d_small - 16: the MSM's flag words, cleared by the same fill
 };
 bool prep_supported(const MsmGeom& g);
+// Bucket-per-lane prep (prep_kernels.h: hist, scan, wide scatter, k_prep_local_t): 4 dispatches + the fill
+struct PrepBplBuffers {
+  u32* d_small;   // as PrepBuffers
+  u32* part;      // 2 * E words: 64-bit interchange entries
+  u32* ents_t;    // P * stride words: the transposed entry blocks
+  void* grp;      // B / 64 group headers (8 bytes each)
+  u32* order;     // B words: buckets in accumulate order
+  u32* err;       // == d_small - 16; err[1] = overflow (the host falls back to the chunked pipeline)
+};
+bool prep_bpl_supported(const MsmGeom& g);
+u32 prep_bpl_stride(const MsmGeom& g);  // entries per partition block of ents_t
+u32 prep_bpl_partitions(const MsmGeom& g);
+template <class Fr>
+int launch_prep_bpl(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBplBuffers& b);
 template <class Fr>
 int launch_prep(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBuffers& b);
 

@@ -179,6 +179,84 @@ __global__ void __launch_bounds__(256) AMSM_L0_VGPR_ATTR
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before the LDS is released
 }
 
+// ---------------------------------------------------------------------------------------------
+// accumulate, bucket per lane (round 3; the layout is written by k_prep_local_t, prep_kernels.h): wave gw owns the group of
+// 64 buckets order[64 gw ..], lane l sums the WHOLE bucket order[64 gw + l]: its entry k sits at ents_t[base + 64 k + l]
+// (one coalesced 256-byte row per iteration), rows past a bucket's size hold BPL_PAD.  m = the group's largest bucket, so
+// all lanes run the same m iterations; buckets are ordered by size, so m exceeds the mean by a few entries only.  The
+// points arrive by the same cooperative LDS-DMA gather as in k_accum_l0, two iterations ahead.  Every lane stores its
+// finished bucket (empty buckets as the identity): the bucket table needs no clearing and there are no partial records.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 BPL_PAD = 0x40000000u;  // == BPL_ENTRY_PAD of prep_kernels.h
+struct BplGroupHdr {
+  u32 base, m;
+};
+template <class Fq>
+__global__ void __launch_bounds__(256)
+    k_accum_bpl(const u32* __restrict__ table, const u32* __restrict__ ents_t, const BplGroupHdr* __restrict__ grp,
+                const u32* __restrict__ order, u32 n_groups, u32 groups_per_part, const u32* __restrict__ flags,
+                u32* __restrict__ buckets) {
+  __shared__ __attribute__((aligned(16))) u32 lds[2 * 4 * GatherLds<Fq>::WAVE_BYTES / 4];
+  if (flags[1]) return;  // the prep overflowed (skewed digits): the host reruns this MSM through the chunked pipeline
+  const u32 lane = threadIdx.x & 63u;
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32* lds_wave0 = lds + wave * (2 * GatherLds<Fq>::WAVE_BYTES / 4);
+  u32* lds_wave1 = lds_wave0 + GatherLds<Fq>::WAVE_BYTES / 4;
+  // Which group a wave takes.  Group q of every partition is its q-th size class (q = 0: the largest buckets, several times
+  // the rows of the last).  Two things were measured with groups in memory order (workgroup w = classes 4 (w mod 4) .. + 3):
+  // workgroups go round-robin to the 8 XCDs, so XCDs 0 and 4 got ALL the largest classes (1.5x the balanced time), and with the
+  // classes interleaved the long workgroups that start late leave a tail (1.36 ms against 0.96 ms for equal-length waves).
+  // So: the four waves of a workgroup take the SAME class q of four different partitions (equal lengths: the workgroup's wave
+  // slots and LDS are released together), and the workgroups run through the classes in DESCENDING order -- all of class 0
+  // first, round-robin over the XCDs, the short classes last to fill the gaps (longest-processing-time-first).
+  u32 gw = blockIdx.x * 4u + wave;
+  const u32 n_parts = n_groups / groups_per_part;
+  if ((n_parts & 3u) == 0u) {
+    const u32 per_class = n_parts >> 2, q = blockIdx.x / per_class, j = blockIdx.x % per_class;
+    gw = (j * 4u + wave) * groups_per_part + q;
+  }
+  if (gw >= n_groups) return;
+#ifdef AMSM_BPL_FIXM  // (timing experiment: every wave the same length)
+  const u32 base = __builtin_amdgcn_readfirstlane(grp[gw].base), m = AMSM_BPL_FIXM;
+#else
+  const u32 base = __builtin_amdgcn_readfirstlane(grp[gw].base), m = __builtin_amdgcn_readfirstlane(grp[gw].m);
+#endif
+  const u32 b = order[gw * 64u + lane];
+  const u32* row = ents_t + base + lane;
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  if (m) {
+    u32 e0 = row[0];
+    u32 e1 = m > 1u ? row[64] : BPL_PAD;
+    u32 e2 = m > 2u ? row[128] : BPL_PAD;
+    gather_issue<Fq>(table, e0 & ENTRY_IDX & ~BPL_PAD, lds_wave0, lane);
+    gather_issue<Fq>(table, e1 & ENTRY_IDX & ~BPL_PAD, lds_wave1, lane);
+#pragma unroll 2
+    for (u32 k = 0; k < m; k++) {
+      const u32 e3 = k + 3u < m ? row[(size_t)(k + 3u) * 64u] : BPL_PAD;  // uniform condition: one row load per iteration
+      u32* region = (k & 1u) ? lds_wave1 : lds_wave0;
+      // outstanding, oldest first: gather(k) | gather(k + 1) | the row load just issued.  Memory operations retire in
+      // order, so "at most N_INSTR + 1 outstanding" means gather(k) -- and the row loaded one iteration ago -- have landed
+      if (GatherLds<Fq>::N_INSTR == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      Affine<Fq> pt = gather_read<Fq>(region, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef AMSM_BPL_NOGATHER  // (timing experiments only: the two halves of the loop on their own)
+      gather_issue<Fq>(table, e2 & ENTRY_IDX & ~BPL_PAD, region, lane);  // the points of iteration k + 2
+#endif
+#ifndef AMSM_BPL_NOMADD
+      if (!(e0 & BPL_PAD)) xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (e0 & ENTRY_NEG) != 0));
+#else
+      if (!(e0 & BPL_PAD)) acc.x.v[0] ^= pt.x.v[0] ^ pt.y.v[1];
+#endif
+      e0 = e1;
+      e1 = e2;
+      e2 = e3;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before the LDS is released
+  }
+  xyzz_store<Fq>(buckets, b, acc);
+}
+
 // Butterfly reduction of one XYZZ per lane over aligned groups of WIDTH lanes (WIDTH = 64: whole wave) with
 // __shfl_xor; every lane of a group ends with the group's sum.  All 64 lanes must be active.
 template <class Fq, int WIDTH>

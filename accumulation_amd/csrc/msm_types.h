@@ -37,6 +37,11 @@ struct MsmGeom {
   u32 n_chunks;      // work items of accumulate L0 (upper bound: sized for E entries)
   u32 l0_per_cu;     // host only: resident accumulate-L0 workgroups per CU to enforce for this launch (0 = natural occupancy)
   u32 K1;            // max partials folded by one L1 lane
+  u32 top_shift;     // s > 0 (bucket-per-lane keys): the TOP window holds only 255 - c (W - 1) scalar bits, so its digits would all
+                     // fall into the lowest 2^(that - 1) buckets -- a sixteenth of the partitions would receive a whole window.
+                     // Its table level is 2^(c (W - 1) - s) G instead and its digit is shifted left by s: the same product, spread
+                     // over every 2^s-th bucket of the whole range (raw digit <= 2^(c - 1 - s): never negative, no carry out)
+  u32 bpl;           // 1: bucket-per-lane pipeline (k_prep_local_t + k_accum_bpl; 20-bit windows), 0: chunked pipeline
   u32 red_s;         // buckets per reduce lane
   u32 red_threads;   // reduce lanes per set
 };

@@ -98,7 +98,13 @@ AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const Msm
     u32 neg = 0;
     carry = 0;
     u32 d = raw;
-    if (raw > half) {
+    if (g.top_shift && w == g.W - 1u) {
+      d = raw << g.top_shift;  // MsmGeom::top_shift: the short top window, spread over the bucket range
+      if (d > half) {          // only a non-canonical scalar gets here: reported, no entry
+        carry = 1;             // (makes `rest` non-zero below)
+        d = 0;
+      }
+    } else if (raw > half) {
       d = (1u << c) - raw;
       neg = 1;
       carry = 1;
@@ -135,7 +141,10 @@ AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont,
       u32 neg = 0;
       carry = 0;
       u32 d = raw;
-      if (raw > half) {
+      if (g.top_shift && (u32)w == g.W - 1u) {
+        d = raw << g.top_shift;  // MsmGeom::top_shift
+        if (d > half) d = 0;     // non-canonical scalar: k_prep_hist's walk reports it
+      } else if (raw > half) {
         d = (1u << c) - raw;
         neg = 1;
         carry = 1;
@@ -166,7 +175,10 @@ AMSM_DEV void scalar_entries_unrolled_reg(Fe<Fr> s, const MsmGeom& g, u32 i, F&&
       u32 neg = 0;
       carry = 0;
       u32 d = raw;
-      if (raw > half) {
+      if (g.top_shift && (u32)w == g.W - 1u) {
+        d = raw << g.top_shift;  // MsmGeom::top_shift
+        if (d > half) d = 0;     // non-canonical scalar: k_prep_hist's walk reports it
+      } else if (raw > half) {
         d = (1u << c) - raw;
         neg = 1;
         carry = 1;
@@ -245,7 +257,9 @@ __global__ void __launch_bounds__(1024)
 // SPT = scalars per lane (SPB = blockDim * SPT), MAXW >= S (entry slots per scalar); SPB * S <= 8192.
 // (Tried: 1024 partitions -> 32-byte runs, 162 us instead of 82; 1024 scalars per workgroup with 108 KiB of LDS to get
 // the 64-byte runs back, 110 us and a slower batch.  512 partitions x 512 scalars it is.)
-template <class Fr, int MAXW, int SPT>
+// WIDE (the bucket-per-lane pipeline, 20-bit windows): 64-bit interchange entries -- low word = negate | table index, high word
+// = the bucket id's low bits -- because 1 + 10 + 24 bits do not fit one word; `part` then holds E 8-byte entries (P even).
+template <class Fr, int MAXW, int SPT, bool WIDE = false>
 __global__ void __launch_bounds__(512)
     k_prep_scatter(const u32* __restrict__ scalars, int mont, MsmGeom g, PrepGeom pg, const u32* __restrict__ part_start,
                    u32* __restrict__ part_cursor, u32* __restrict__ part) {
@@ -255,7 +269,7 @@ __global__ void __launch_bounds__(512)
   u32* loff = prep_lds + pg.P;   // block-local exclusive prefix
   u32* gbase = prep_lds + 2 * pg.P;
   u32* staged = prep_lds + 3 * pg.P;
-  uint16_t* staged_p = reinterpret_cast<uint16_t*>(staged + cap);
+  uint16_t* staged_p = reinterpret_cast<uint16_t*>(staged + (WIDE ? 2u : 1u) * cap);
   const u32 t = threadIdx.x, T = blockDim.x;
   for (u32 p = t; p < pg.P; p += T) cnt[p] = 0;
   __syncthreads();
@@ -333,7 +347,8 @@ __global__ void __launch_bounds__(512)
         u32 p = key >> pg.SH;
         u32 rank = (rk[r][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
         u32 slot = loff[p] + rank;
-        staged[slot] = (val & 0x80000000u) | ((key & low) << pg.IB) | (val & 0x7fffffffu);
+        if (WIDE) reinterpret_cast<u64*>(staged)[slot] = ((u64)(key & low) << 32) | val;
+        else staged[slot] = (val & 0x80000000u) | ((key & low) << pg.IB) | (val & 0x7fffffffu);
         staged_p[slot] = (uint16_t)p;
       });
   }
@@ -345,7 +360,8 @@ __global__ void __launch_bounds__(512)
   u32 total = loff[pg.P - 1] + cnt[pg.P - 1];
   for (u32 j = t; j < total; j += T) {
     u32 p = staged_p[j];
-    part[gbase[p] + (j - loff[p])] = staged[j];
+    if (WIDE) reinterpret_cast<u64*>(part)[gbase[p] + (j - loff[p])] = reinterpret_cast<const u64*>(staged)[j];
+    else part[gbase[p] + (j - loff[p])] = staged[j];
   }
 }
 
@@ -586,6 +602,128 @@ __global__ void __launch_bounds__(256)
     unsigned long long reach = (unsigned long long)e_valid + span + 16ull;
     const u32 pad_end = (u32)min(reach, (unsigned long long)((g.E + 3u) & ~3u));
     for (u32 k = e_valid + t; k < pad_end; k += T) vals_sorted[k] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bucket-per-lane pipeline (round 3; 2^20-pair MSMs over a key precomputed for 20-bit windows: 13 entries per scalar
+// instead of 15, 2^19 buckets of ~26 entries).  One workgroup per partition (1024 buckets, ~26 k entries, assembled in
+// LDS) sorts its entries by bucket, orders its BUCKETS by size, and writes the entries of every group of 64 consecutive
+// buckets of that order TRANSPOSED: entry k of the group's lane l at  base + 64 k + l,  padded to the group's largest
+// bucket (sizes inside a group differ by a few entries once sorted: ~6 % padding).  k_accum_bpl then gives each lane ONE
+// WHOLE bucket: a wave reads its entries as 256-byte coalesced rows, runs max-size iterations with all lanes converged,
+// and stores finished bucket sums -- no partial records, no accumulate L1 / L2, no per-flush bucket search.
+// Skewed digit distributions (a partition above its LDS capacity, or a padded layout above the fixed per-partition
+// stride) raise the overflow flag: every later kernel of the chain returns at once and the host reruns the MSM over the
+// key's 17-bit-window table through the chunked pipeline above, which is built for exactly those inputs.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 BPL_GROUP = 64;            // buckets per accumulate wave
+constexpr u32 BPL_ENTRY_PAD = 0x40000000u;  // padding entry (bit 30; the last-of-bucket flag is not used in this pipeline)
+constexpr u32 BPL_BINS = 256;            // size classes of the bucket ordering (sizes >= 255 share the last one)
+struct BplGroup {
+  u32 base;  // first entry of the group's transposed block in ents_t
+  u32 m;     // rows = entries of its largest bucket
+};
+
+// dynamic LDS: (5 * NB + 1024 + BPL_BINS + 2 * (NB / 64) + 2 + CAP) words, NB = 2^SH <= 1024
+__global__ void __launch_bounds__(1024)
+    k_prep_local_t(const u32* __restrict__ part_start, const u64* __restrict__ part, MsmGeom g, PrepGeom pg, u32 stride,
+                   u32* __restrict__ ents_t, BplGroup* __restrict__ grp, u32* __restrict__ order, u32* __restrict__ err) {
+  extern __shared__ u32 prep_lds[];
+  const u32 NB = 1u << pg.SH, NG = NB / BPL_GROUP;
+  u32* cnt = prep_lds;            // entries per bucket
+  u32* cur = cnt + NB;            // placement cursor
+  u32* beg = cur + NB;            // first staged entry of the bucket
+  u32* ord = beg + NB;            // bucket at position i of the size order
+  u32* sl = ord + NB;             // 1024 scan words
+  u32* bins = sl + 1024;          // BPL_BINS size classes: count, then first position
+  u32* gm = bins + BPL_BINS;      // NG: rows per group
+  u32* gb = gm + NG;              // NG + 1: first entry of the group inside the partition's block
+  u32* stage = gb + NG + 2;       // CAP sorted entries
+  const u32 p = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  const u32 ps = part_start[p], pe = part_start[p + 1], n_p = pe - ps;
+  const u32 low = NB - 1u, idx_mask = (1u << pg.IB) - 1u, b0 = p << pg.SH;
+  const bool fits = n_p <= pg.CAP;
+  for (u32 k = t; k < NB; k += T) cnt[k] = 0;
+  for (u32 k = t; k < BPL_BINS; k += T) bins[k] = 0;
+  for (u32 k = t; k < NG; k += T) gm[k] = 0;
+  __syncthreads();
+  if (fits)
+    for (u32 j = ps + t; j < pe; j += T) atomicAdd(&cnt[(u32)(part[j] >> 32) & low], 1u);
+  __syncthreads();
+  // exclusive prefix of the bucket sizes: lane t owns bucket t (NB <= T)
+  const u32 c_t = t < NB ? cnt[t] : 0u;
+  sl[t] = c_t;
+  __syncthreads();
+  for (u32 d = 1; d < T; d <<= 1) {
+    u32 v = t >= d ? sl[t - d] : 0u;
+    __syncthreads();
+    sl[t] += v;
+    __syncthreads();
+  }
+  if (t < NB) {
+    beg[t] = sl[t] - c_t;
+    cur[t] = sl[t] - c_t;
+  }
+  // size class of my bucket and my rank inside it
+  const u32 bin = min(c_t, BPL_BINS - 1u);
+  u32 rank = 0;
+  if (t < NB) rank = atomicAdd(&bins[bin], 1u);
+  __syncthreads();
+  // entries to their bucket's run (order inside a bucket is arbitrary: the sum does not depend on it)
+  if (fits)
+    for (u32 j = ps + t; j < pe; j += T) {
+      const u64 e = part[j];
+      const u32 k = (u32)(e >> 32) & low, lo = (u32)e;
+      const u32 pos = atomicAdd(&cur[k], 1u);
+      stage[pos] = (lo & 0x80000000u) | entry_abs_index(g, lo & idx_mask);
+    }
+  // descending size order: first position of class b = buckets in larger classes
+  if (t < BPL_BINS) sl[t] = bins[BPL_BINS - 1u - t];  // reversed, so that an inclusive scan counts the larger classes
+  __syncthreads();
+  for (u32 d = 1; d < BPL_BINS; d <<= 1) {
+    u32 v = (t < BPL_BINS && t >= d) ? sl[t - d] : 0u;
+    __syncthreads();
+    if (t < BPL_BINS) sl[t] += v;
+    __syncthreads();
+  }
+  if (t < BPL_BINS) bins[BPL_BINS - 1u - t] = sl[t] - bins[BPL_BINS - 1u - t];  // exclusive
+  __syncthreads();
+  if (t < NB) {
+    const u32 pos = bins[bin] + rank;
+    ord[pos] = t;
+    atomicMax(&gm[pos / BPL_GROUP], c_t);  // the last class is not sorted inside: take the maximum, not the first
+  }
+  __syncthreads();
+  if (t == 0) {
+    u32 run = 0;
+    for (u32 q = 0; q < NG; q++) {
+      gb[q] = run;
+      run += gm[q] * BPL_GROUP;
+    }
+    gb[NG] = run;
+  }
+  __syncthreads();
+  const u32 total = gb[NG];
+  const bool ok = fits && total <= stride;
+  if (!ok && t == 0) atomicOr(err + 1, 1u);  // overflow: the host falls back to the chunked pipeline
+  if (t < NG) {
+    BplGroup h;
+    h.base = p * stride + gb[t];
+    h.m = ok ? gm[t] : 0u;
+    grp[p * NG + t] = h;
+  }
+  if (t < NB) order[b0 + t] = b0 + ord[t];
+  if (!ok) return;
+  for (u32 j = t; j < total; j += T) {
+    u32 q = 0;
+#pragma unroll 1
+    for (u32 s2 = NG >> 1; s2 >= 1; s2 >>= 1)  // largest q with gb[q] <= j (NG a power of two; empty groups share a base)
+      if (q + s2 < NG && gb[q + s2] <= j) q += s2;
+    while (q + 1 < NG && gb[q + 1] <= j) q++;
+    const u32 k = (j - gb[q]) / BPL_GROUP, l = j % BPL_GROUP;
+    const u32 kb = ord[q * BPL_GROUP + l];
+    ents_t[(size_t)p * stride + j] = k < cnt[kb] ? stage[beg[kb] + k] : BPL_ENTRY_PAD;
   }
 }
 

@@ -421,7 +421,13 @@ __global__ void __launch_bounds__(256)
     u32 neg = 0;
     carry = 0;
     u32 d = raw;
-    if (raw > half) {
+    if (g.top_shift && w == g.W - 1u) {
+      d = raw << g.top_shift;  // MsmGeom::top_shift
+      if (d > half) {          // non-canonical scalar: reported by the `rest` test below
+        carry = 1;
+        d = 0;
+      }
+    } else if (raw > half) {
       d = (1u << c) - raw;
       neg = 1;
       carry = 1;

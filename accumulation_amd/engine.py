@@ -90,6 +90,12 @@ class Context:
         ffi.check(self._lib.amsm_ctx_memory(self._h, C.byref(ws), C.byref(live), C.byref(pooled)), "amsm_ctx_memory")
         return {"workspace_bytes": ws.value, "vectors_live_bytes": live.value, "vectors_pooled_bytes": pooled.value}
 
+    def pipeline_stats(self) -> dict:
+        """MSMs that took the bucket-per-lane pipeline / that fell back to the chunked one (amsm_ctx_pipeline_stats)"""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        ffi.check(self._lib.amsm_ctx_pipeline_stats(self._h, C.byref(a), C.byref(b)), "amsm_ctx_pipeline_stats")
+        return {"bucket_per_lane": a.value, "fallbacks": b.value}
+
     def trim(self):
         """Release the MSM workspace and every cached buffer (amsm_ctx_trim); live vectors and keys stay."""
         self.empty_cache()

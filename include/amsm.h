@@ -104,6 +104,12 @@ const char* amsm_ctx_collective(const amsm_ctx* ctx);
  * exactly ONE per sharded MSM / commit call however many vectors the call carries, so a prover's exchange count is its
  * number of DEPENDENT commit rounds (tests/test_cpp_multi_device.py counts them).  0 for single-device contexts. */
 unsigned long long amsm_ctx_collectives(const amsm_ctx* ctx);
+/* Which accumulation pipeline the context's MSMs took so far: *n_bucket_per_lane = MSMs enqueued on the bucket-per-lane
+ * pipeline (keys of >= 2^20 generators, MSMs of (2^19, 2^20] pairs -- longer ones as windows of 2^20; 20-bit windows, 13
+ * gathered additions per pair), *n_fallbacks = those whose scalars turned out skewed (a digit value shared by a large part of
+ * a window: constant vectors) and were re-run through the chunked pipeline over the key's 17-bit-window twin,
+ * which is built on the first such call.  Results do not depend on the path.  Either pointer may be NULL. */
+int amsm_ctx_pipeline_stats(const amsm_ctx* ctx, unsigned long long* n_bucket_per_lane, unsigned long long* n_fallbacks);
 void amsm_ctx_destroy(amsm_ctx* ctx);
 int amsm_ctx_curve(const amsm_ctx* ctx);
 /* limbs (u64) of a base-field element: 4 (Pallas) or 6 (BLS12-381). */
