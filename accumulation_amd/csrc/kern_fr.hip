@@ -105,20 +105,21 @@ static PrepGeom prep_bpl_geom(const MsmGeom& g) {
   pg.IB = 1;
   while ((max_idx >> pg.IB) != 0ull) pg.IB++;
   const u32 nb = 1u << pg.SH;
-  const u32 budget_words = 37888u, fixed_words = 4u * nb + 1024u + BPL_BINS + 2u * (nb / BPL_GROUP) + 2u;
+  const u32 budget_words = 37888u, fixed_words = 4u * nb + 1024u + BPL_BINS + 2u * BPL_GROUPS + 2u;
   pg.CAP = budget_words - fixed_words;  // ~31.4 k entries: a partition of a 2^20-pair MSM holds ~26.6 k
   pg.HEAVY = 0xffffffffu;
   return pg;
 }
 static size_t prep_bpl_local_lds(const PrepGeom& pg) {
   const u32 nb = 1u << pg.SH;
-  return (size_t)(4u * nb + 1024u + BPL_BINS + 2u * (nb / BPL_GROUP) + 2u + pg.CAP) * sizeof(u32);
+  return (size_t)(4u * nb + 1024u + BPL_BINS + 2u * BPL_GROUPS + 2u + pg.CAP) * sizeof(u32);
 }
 static size_t prep_bpl_scatter_lds(const MsmGeom& g, const PrepGeom& pg) {
   const size_t cap = (size_t)pg.SPB * g.S;
   return (3 * (size_t)pg.P + 2 * cap) * sizeof(u32) + cap * sizeof(uint16_t);
 }
 u32 prep_bpl_partitions(const MsmGeom& g) { return g.B >> 10; }
+u32 prep_bpl_groups_per_partition() { return BPL_GROUPS; }  // 17 groups of 64 lane slots (prep_kernels.h: BPL_SPLIT)
 // transposed entries per partition: the expected partition size + 25 % (the padding to each group's largest bucket is ~6 %
 // on uniform digits) + a constant; anything that does not fit is a skewed input and takes the fallback
 u32 prep_bpl_stride(const MsmGeom& g) {

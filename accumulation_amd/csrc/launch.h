@@ -15,7 +15,7 @@ void launch_accum_l0(hipStream_t st, const u32* table, const u32* vals_sorted, c
 // bucket-per-lane accumulation (msm_kernels.h: k_accum_bpl) over the transposed layout k_prep_local_t wrote
 template <class Fq>
 void launch_accum_bpl(hipStream_t st, const u32* table, const u32* ents_t, const void* grp, const u32* order, u32 n_groups,
-                      const u32* flags, u32* buckets);
+                      u32 groups_per_part, const u32* flags, u32* buckets);
 // resident 256-lane workgroups of accumulate L0 per CU (occupancy query); lds_pad = unused dynamic LDS per workgroup,
 // which caps the residency (AMSM_L0_LDS_PAD: leaves wave slots / registers to the kernels of the other MSMs in flight)
 template <class Fq>
@@ -85,13 +85,14 @@ struct PrepBplBuffers {
   u32* d_small;   // as PrepBuffers
   u32* part;      // 2 * E words: 64-bit interchange entries
   u32* ents_t;    // P * stride words: the transposed entry blocks
-  void* grp;      // B / 64 group headers (8 bytes each)
-  u32* order;     // B words: buckets in accumulate order
+  void* grp;      // partitions x prep_bpl_groups_per_partition() group headers (8 bytes each)
+  u32* order;     // 64 words per group: the bucket every lane slot sums
   u32* err;       // == d_small - 16; err[1] = overflow (the host falls back to the chunked pipeline)
 };
 bool prep_bpl_supported(const MsmGeom& g);
 u32 prep_bpl_stride(const MsmGeom& g);  // entries per partition block of ents_t
 u32 prep_bpl_partitions(const MsmGeom& g);
+u32 prep_bpl_groups_per_partition();  // group headers (and 64-lane blocks of `order`) per partition
 template <class Fr>
 int launch_prep_bpl(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBplBuffers& b);
 template <class Fr>

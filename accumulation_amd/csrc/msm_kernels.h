@@ -188,6 +188,8 @@ __global__ void __launch_bounds__(256) AMSM_L0_VGPR_ATTR
 // finished bucket (empty buckets as the identity): the bucket table needs no clearing and there are no partial records.
 // ---------------------------------------------------------------------------------------------
 constexpr u32 BPL_PAD = 0x40000000u;  // == BPL_ENTRY_PAD of prep_kernels.h
+template <class Fq, int WIDTH>
+AMSM_DEV void group_reduce_xyzz(XYZZ<Fq>& acc);
 struct BplGroupHdr {
   u32 base, m;
 };
@@ -232,7 +234,9 @@ __global__ void __launch_bounds__(256)
     gather_issue<Fq>(table, e1 & ENTRY_IDX & ~BPL_PAD, lds_wave1, lane);
 #pragma unroll 2
     for (u32 k = 0; k < m; k++) {
-      const u32 e3 = k + 3u < m ? row[(size_t)(k + 3u) * 64u] : BPL_PAD;  // uniform condition: one row load per iteration
+      // one row load per iteration, ALWAYS issued (the clamped row is discarded): the s_waitcnt below counts it
+      const u32 e3_ld = row[(size_t)min(k + 3u, m - 1u) * 64u];
+      const u32 e3 = k + 3u < m ? e3_ld : BPL_PAD;
       u32* region = (k & 1u) ? lds_wave1 : lds_wave0;
       // outstanding, oldest first: gather(k) | gather(k + 1) | the row load just issued.  Memory operations retire in
       // order, so "at most N_INSTR + 1 outstanding" means gather(k) -- and the row loaded one iteration ago -- have landed
@@ -254,7 +258,12 @@ __global__ void __launch_bounds__(256)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before the LDS is released
   }
-  xyzz_store<Fq>(buckets, b, acc);
+  // the first and the last group of a partition hold the two halves of its 64 largest buckets on adjacent lanes
+  // (prep_kernels.h: BPL_SPLIT): one exchange, the even lane stores the bucket
+  const u32 q = gw % groups_per_part;
+  const bool pairs = q == 0u || q + 1u == groups_per_part;  // uniform per wave
+  if (pairs) group_reduce_xyzz<Fq, 2>(acc);
+  if (!pairs || !(lane & 1u)) xyzz_store<Fq>(buckets, b, acc);
 }
 
 // Butterfly reduction of one XYZZ per lane over aligned groups of WIDTH lanes (WIDTH = 64: whole wave) with

@@ -617,20 +617,43 @@ __global__ void __launch_bounds__(256)
 // stride) raise the overflow flag: every later kernel of the chain returns at once and the host reruns the MSM over the
 // key's 17-bit-window table through the chunked pipeline above, which is built for exactly those inputs.
 // ---------------------------------------------------------------------------------------------
-constexpr u32 BPL_GROUP = 64;            // buckets per accumulate wave
+constexpr u32 BPL_GROUP = 64;            // lanes per accumulate wave
 constexpr u32 BPL_ENTRY_PAD = 0x40000000u;  // padding entry (bit 30; the last-of-bucket flag is not used in this pipeline)
 constexpr u32 BPL_BINS = 256;            // size classes of the bucket ordering (sizes >= 255 share the last one)
+// The 64 LARGEST buckets of a partition are split in two halves, one lane each, whose sums the accumulate kernel adds with one
+// lane exchange.  On uniform scalars the largest are the buckets the spread top window feeds (MsmGeom::top_shift: every 32nd
+// bucket holds ~88 entries against ~24; Pallas has 32 of them per partition, BLS12-381 64): unsplit, the group holding them
+// ran 108 rows with half its lanes idle after 35 (rows per MSM 242 k -> 225 k, 88 % -> 94 % of the lane-iterations useful).
+// Lane slots of a partition: [0, 64) halves of the buckets at positions 0..31 of the size order | [64, 1024) the buckets at
+// positions 64..1023, one lane each | [1024, 1088) halves of positions 32..63 -- 17 groups of 64 lanes, rows nearly descending.
+constexpr u32 BPL_SPLIT = 64;
+constexpr u32 BPL_NB = 1024;                                   // buckets per partition
+constexpr u32 BPL_LANES = BPL_NB + BPL_SPLIT;                  // 1088 lane slots per partition
+constexpr u32 BPL_GROUPS = BPL_LANES / BPL_GROUP;              // 17
 struct BplGroup {
   u32 base;  // first entry of the group's transposed block in ents_t
-  u32 m;     // rows = entries of its largest bucket
+  u32 m;     // rows = entries of its largest lane
 };
+// lane slot -> position in the size order and which half (0: whole bucket, 1: first half, 2: second half)
+AMSM_DEV void bpl_slot(u32 s, u32& pos, u32& half) {
+  if (s < BPL_SPLIT) {
+    pos = s >> 1;
+    half = 1u + (s & 1u);
+  } else if (s >= BPL_NB) {
+    pos = BPL_SPLIT / 2u + ((s - BPL_NB) >> 1);
+    half = 1u + (s & 1u);
+  } else {
+    pos = s;
+    half = 0u;
+  }
+}
 
-// dynamic LDS: (5 * NB + 1024 + BPL_BINS + 2 * (NB / 64) + 2 + CAP) words, NB = 2^SH <= 1024
+// dynamic LDS: (4 * NB + 1024 + BPL_BINS + 2 * BPL_GROUPS + 2 + CAP) words, NB = 2^SH = 1024
 __global__ void __launch_bounds__(1024)
     k_prep_local_t(const u32* __restrict__ part_start, const u64* __restrict__ part, MsmGeom g, PrepGeom pg, u32 stride,
                    u32* __restrict__ ents_t, BplGroup* __restrict__ grp, u32* __restrict__ order, u32* __restrict__ err) {
   extern __shared__ u32 prep_lds[];
-  const u32 NB = 1u << pg.SH, NG = NB / BPL_GROUP;
+  const u32 NB = BPL_NB, NG = BPL_GROUPS;
   u32* cnt = prep_lds;            // entries per bucket
   u32* cur = cnt + NB;            // placement cursor
   u32* beg = cur + NB;            // first staged entry of the bucket
@@ -639,7 +662,7 @@ __global__ void __launch_bounds__(1024)
   u32* bins = sl + 1024;          // BPL_BINS size classes: count, then first position
   u32* gm = bins + BPL_BINS;      // NG: rows per group
   u32* gb = gm + NG;              // NG + 1: first entry of the group inside the partition's block
-  u32* stage = gb + NG + 2;       // CAP sorted entries
+  u32* stage = gb + NG + 1;       // CAP sorted entries
   const u32 p = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const u32 ps = part_start[p], pe = part_start[p + 1], n_p = pe - ps;
   const u32 low = NB - 1u, idx_mask = (1u << pg.IB) - 1u, b0 = p << pg.SH;
@@ -651,7 +674,7 @@ __global__ void __launch_bounds__(1024)
   if (fits)
     for (u32 j = ps + t; j < pe; j += T) atomicAdd(&cnt[(u32)(part[j] >> 32) & low], 1u);
   __syncthreads();
-  // exclusive prefix of the bucket sizes: lane t owns bucket t (NB <= T)
+  // exclusive prefix of the bucket sizes: lane t owns bucket t (NB == T)
   const u32 c_t = t < NB ? cnt[t] : 0u;
   sl[t] = c_t;
   __syncthreads();
@@ -689,10 +712,15 @@ __global__ void __launch_bounds__(1024)
   }
   if (t < BPL_BINS) bins[BPL_BINS - 1u - t] = sl[t] - bins[BPL_BINS - 1u - t];  // exclusive
   __syncthreads();
+  u32 my_pos = 0;
   if (t < NB) {
-    const u32 pos = bins[bin] + rank;
-    ord[pos] = t;
-    atomicMax(&gm[pos / BPL_GROUP], c_t);  // the last class is not sorted inside: take the maximum, not the first
+    my_pos = bins[bin] + rank;
+    ord[my_pos] = t;
+    // rows of the group(s) my bucket's lane(s) sit in (the last class is not sorted inside: maxima, not first elements)
+    const u32 h0 = (c_t + 1u) >> 1;
+    if (my_pos < BPL_SPLIT / 2u) atomicMax(&gm[0], h0);
+    else if (my_pos < BPL_SPLIT) atomicMax(&gm[NG - 1u], h0);
+    else atomicMax(&gm[my_pos / BPL_GROUP], c_t);
   }
   __syncthreads();
   if (t == 0) {
@@ -713,17 +741,22 @@ __global__ void __launch_bounds__(1024)
     h.m = ok ? gm[t] : 0u;
     grp[p * NG + t] = h;
   }
-  if (t < NB) order[b0 + t] = b0 + ord[t];
+  if (t < NB) {  // which bucket each lane slot sums (both halves of a split bucket name it; the odd lane does not store)
+    u32* o = order + (size_t)p * BPL_LANES;
+    if (my_pos < BPL_SPLIT / 2u) o[2u * my_pos] = o[2u * my_pos + 1u] = b0 + t;
+    else if (my_pos < BPL_SPLIT) o[BPL_NB + 2u * (my_pos - BPL_SPLIT / 2u)] = o[BPL_NB + 2u * (my_pos - BPL_SPLIT / 2u) + 1u] = b0 + t;
+    else o[my_pos] = b0 + t;
+  }
   if (!ok) return;
   for (u32 j = t; j < total; j += T) {
     u32 q = 0;
-#pragma unroll 1
-    for (u32 s2 = NG >> 1; s2 >= 1; s2 >>= 1)  // largest q with gb[q] <= j (NG a power of two; empty groups share a base)
-      if (q + s2 < NG && gb[q + s2] <= j) q += s2;
-    while (q + 1 < NG && gb[q + 1] <= j) q++;
+    while (q + 1u < NG && gb[q + 1u] <= j) q++;  // the group holding row element j (NG = 17 bases, ascending)
     const u32 k = (j - gb[q]) / BPL_GROUP, l = j % BPL_GROUP;
-    const u32 kb = ord[q * BPL_GROUP + l];
-    ents_t[(size_t)p * stride + j] = k < cnt[kb] ? stage[beg[kb] + k] : BPL_ENTRY_PAD;
+    u32 pos, half;
+    bpl_slot(q * BPL_GROUP + l, pos, half);
+    const u32 kb = ord[pos], c = cnt[kb], h0 = (c + 1u) >> 1;
+    const u32 off = half == 2u ? h0 : 0u, sz = half == 0u ? c : (half == 1u ? h0 : c - h0);
+    ents_t[(size_t)p * stride + j] = k < sz ? stage[beg[kb] + off + k] : BPL_ENTRY_PAD;
   }
 }
 
