@@ -179,6 +179,12 @@ struct amsm_ctx {
   hipEvent_t fork = nullptr;
   hipEvent_t ip_ready = nullptr;  // amsm_ipa_round_fused: the inner products have reached the host
   DevBuf scalars;
+  // host-slice batches (amsm_msm_batch, amsm_pedersen_commit_batch): a ring of device staging buffers, one more than the
+  // pipeline has slots, filled on a copy stream while the previous MSMs compute (created on first use)
+  static constexpr int STAGE_RING = N_SLOTS + 1;
+  DevBuf stage_ring[STAGE_RING];
+  hipEvent_t up_ev[STAGE_RING] = {};
+  hipStream_t s_copy = nullptr;
   DevBuf xyzz_scratch;  // unconverted sums of large key folds / precompute levels (launch.h: batch_affine_pays)
   // ---- multi-device (amsm_ctx_create_multi) ----
   // shard_ctx[0] == this (the primary); shard_ctx[g >= 1] are owned single-device contexts, each served by one host

@@ -432,6 +432,22 @@ class VariableBaseMSM:
 
 
     @staticmethod
+    def multi_scalar_mul_batch_host(bases: CommitterKey, vectors: Sequence[np.ndarray], mont: bool = False, base_off: int = 0):
+        """len(vectors) MSMs over HOST slices ((n, 4) uint64 each, equal n): amsm_msm_batch -- the upload of vector v + 1
+        overlaps MSM v (what back-to-back `commit` calls of a patched ark-poly-commit would go through)."""
+        ctx = bases.ctx
+        k = len(vectors)
+        arrs = [np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4) for v in vectors]
+        n = arrs[0].shape[0] if k else 0
+        assert all(a.shape[0] == n for a in arrs)
+        ptrs = (C.c_void_p * max(k, 1))(*[a.ctypes.data for a in arrs])
+        out = np.zeros((k, 2 * ctx.fq_limbs), dtype=np.uint64)
+        inf = np.zeros((k,), dtype=np.uint8)
+        ffi.check(ctx._lib.amsm_msm_batch(ctx._h, bases._h, base_off, ptrs, k, n, 1 if mont else 0, _ptr(out), _ptr(inf)),
+                  "amsm_msm_batch")
+        return out, inf
+
+    @staticmethod
     def multi_scalar_mul_multi(bases: CommitterKey, jobs: Sequence[Tuple[int, "FrVector"]], mont: bool = True):
         """Independent MSMs over windows of one key, pipelined on the device: job = (base_off, scalars); MSM j uses
         generators [base_off, base_off + len(scalars)).  Returns (k x 2L u64, k uint8)."""
@@ -497,6 +513,28 @@ class PedersenCommitment:
                       "amsm_host_lincomb")
             out.append((o, bool(oinf.value)))
         return out
+
+    @staticmethod
+    def commit_batch_host(ck: CommitterKey, elems: Sequence[np.ndarray], randomizers: Optional[Sequence[Optional[np.ndarray]]] = None):
+        """commit(ck, elems[v], randomizers[v]) for HOST vectors of Montgomery elements (lengths may differ) in one call:
+        amsm_pedersen_commit_batch.  Returns [(point, is_inf), ...]."""
+        ctx = ck.ctx
+        k = len(elems)
+        arrs = [np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4) for v in elems]
+        ptrs = (C.c_void_p * max(k, 1))(*[a.ctypes.data for a in arrs])
+        ns = (C.c_size_t * max(k, 1))(*[a.shape[0] for a in arrs])
+        rptrs, keep = None, []
+        if randomizers is not None and any(r is not None for r in randomizers):
+            if ck.hiding_generator is None:
+                raise ValueError("committer key has no hiding generator")
+            keep = [None if r is None else np.ascontiguousarray(r, dtype=np.uint64).reshape(4) for r in randomizers]
+            rptrs = (C.c_void_p * max(k, 1))(*[None if r is None else r.ctypes.data for r in keep])
+        out = np.zeros((k, 2 * ctx.fq_limbs), dtype=np.uint64)
+        inf = np.zeros((k,), dtype=np.uint8)
+        hg = None if rptrs is None else _ptr(np.ascontiguousarray(ck.hiding_generator, dtype=np.uint64))
+        ffi.check(ctx._lib.amsm_pedersen_commit_batch(ctx._h, ck._h, ptrs, ns, k, rptrs, hg, _ptr(out), _ptr(inf)),
+                  "amsm_pedersen_commit_batch")
+        return [(out[i], bool(inf[i])) for i in range(k)]
 
     @staticmethod
     def commit(ck: CommitterKey, elems, randomizer: Optional[np.ndarray] = None) -> Tuple[np.ndarray, bool]:

@@ -68,6 +68,8 @@ SIGNATURES = {
     "amsm_bases_free": (None, [_vp]),
     "amsm_msm": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_msm_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
+    "amsm_msm_batch": (C.c_int, [_vp, _vp, _sz, C.POINTER(_vp), _sz, _sz, C.c_int, _vp, _vp]),
+    "amsm_pedersen_commit_batch": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_sz), _sz, C.POINTER(_vp), _vp, _vp, _vp]),
     "amsm_msm_batch_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_vp), _sz, _sz, C.c_int, _vp, _vp]),
     "amsm_msm_batch_sharded_device": (C.c_int, [_vp, _vp, C.POINTER(_vp), _sz, C.c_int, _vp, _vp]),
     "amsm_msm_multi_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), C.c_int, _vp, _vp]),

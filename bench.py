@@ -61,6 +61,9 @@ def main() -> int:
                     help="gloo + --one-gpu: functional check of the N > 1 path with every rank on GPU 0 (numbers meaningless)")
     ap.add_argument("--one-gpu", action="store_true")
     ap.add_argument("--sync", action="store_true", help="one synchronous MSM call per step (no MSMs overlapped)")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: strong scaling -- ONE 2^log2n-pair MSM per step split over the ranks (2^log2n / N pairs each) "
+                         "instead of 2^log2n pairs per rank; `scaling` says which")
     ap.add_argument("--cpu-log2n", type=int, default=None, help="sample size of the CPU baseline (default: log2n)")
     ap.add_argument("--single-process", action="store_true",
                     help="drive all --gpus devices from this process through amsm_ctx_create_multi (no torchrun)")
@@ -97,6 +100,16 @@ def main() -> int:
 
     curve_id = ffi.AMSM_PALLAS if args.curve == "pallas" else ffi.AMSM_BLS12_381_G1
     n = 1 << args.log2n
+    if args.strong and world > 1:  # one 2^log2n-pair MSM per step, point-sharded: the first n % world ranks take one more
+        from accumulation_amd.dist import shard_bounds
+        lo_s, hi_s = shard_bounds(n, rank, world)
+        n = hi_s - lo_s
+    rank_info = None
+    if world > 1:  # who actually joined: the driver reads this to see that N ranks ran on N distinct devices over RCCL
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, {"rank": rank, "device": int(torch.cuda.current_device()),
+                                           "pci_bus_id": str(getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", "")),
+                                           "pairs": n})
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         ctx = Context(curve_id, device=local_rank, stream=stream.cuda_stream)
@@ -165,12 +178,38 @@ def main() -> int:
         for _ in range(5):
             ffi.check(ctx._lib.amsm_msm(ctx._h, ck._h, 0, _ptr(h_scalars), n, 0, _ptr(out), C.byref(inf)), "amsm_msm")
         ms_host = (time.perf_counter() - t1) / 5 * 1e3
+        # ... and the same host slices handed over back to back, the way the reference's provers call `commit`
+        # (src/hp_as/mod.rs:372-385): amsm_msm_batch overlaps the upload of vector v + 1 with MSM v
+        ms_host_batch = pipe = plain_rate = None
+        if world == 1:
+            h_vecs = [v.download() for v in vecs]
+            VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(3)])
+            reps = 12
+            t1 = time.perf_counter()
+            hb_pts, hb_inf = VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(reps)])
+            ms_host_batch = (time.perf_counter() - t1) / reps * 1e3
+            if "all" in last and not (np.array_equal(hb_pts[:n_distinct], last["all"][0][:n_distinct])):
+                raise SystemExit("host-slice batch differs from the device-resident batch")
+            del h_vecs
+            pipe = ctx.pipeline_stats()
+            # the TRUE variable-base rate: no precomputed multiples (what an ark-ec `[patch]` that passes its bases per
+            # call gets, or pays ~50 ms of table building per new base set to avoid)
+            if not args.no_precompute and args.log2n <= 21:
+                ck_plain = CommitterKey.generate(ctx, SEED_POINTS + rank, n, ffi.AMSM_BASES_NO_PRECOMPUTE)
+                VariableBaseMSM.multi_scalar_mul_batch(ck_plain, [vecs[0]], mont=False)
+                t1 = time.perf_counter()
+                pp, pi = VariableBaseMSM.multi_scalar_mul_batch(ck_plain, [vecs[i % n_distinct] for i in range(4)], mont=False)
+                plain_rate = 4 * n / (time.perf_counter() - t1)
+                if "all" in last and not np.array_equal(pp[:4], last["all"][0][:4]):
+                    raise SystemExit("plain-key MSM differs from the precomputed-key MSM")
+                ck_plain.free()
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_pairs = n * world * args.steps
+    pairs_per_step = sum(r["pairs"] for r in rank_info) if rank_info else n
+    total_pairs = pairs_per_step * args.steps
     value = total_pairs / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
@@ -189,12 +228,14 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (args.strong and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"2^{args.log2n}-pair {args.curve} MSM per GPU (north_star size; uniform 254-bit scalars, "
+                "workload": (f"ONE 2^{args.log2n}-pair {args.curve} MSM per step, point-sharded over {world} GPUs"
+                             if (args.strong and world > 1) else f"2^{args.log2n}-pair {args.curve} MSM per GPU") +
+                            f" (north_star size; uniform 254-bit scalars, "
                             f"G_i = k_i*G), key resident{'' if args.no_precompute else ' + precomputed window multiples'}",
                 "pairs_per_gpu": n,
                 "curve": args.curve,
@@ -204,12 +245,24 @@ def main() -> int:
                 "ms_per_msm_synchronous_call": round(ms_sync, 4),
                 "ms_per_msm_host_scalars": round(ms_host, 4),
                 "pairs_per_s_host_scalars": round(n / (ms_host * 1e-3), 1),
+                # host slices, 12 per call (amsm_msm_batch): PCIe-inclusive like the line above, uploads overlapped
+                "ms_per_msm_host_scalars_batch": None if ms_host_batch is None else round(ms_host_batch, 4),
+                "pairs_per_s_host_scalars_batch": None if ms_host_batch is None else round(n / (ms_host_batch * 1e-3), 1),
+                # no precomputed multiples (one copy of the key, a bucket set per window): the variable-base rate
+                "pairs_per_s_plain_key": None if plain_rate is None else round(plain_rate, 1),
+                "key_bytes": key_bytes(ck, ctx, n),
+                "window_bits": int(ck.window_bits),
+                "pipeline": ("bucket-per-lane (k_prep_local_t + k_accum_bpl; skewed scalars re-run chunked)"
+                             if ck.window_bits == 20 else "chunked (k_accum_l0 + k_accum_l1)"),
+                "pipeline_stats": pipe,
+                "rccl_ranks": None if rank_info is None else (len(rank_info) if args.backend == "nccl" else 0),
+                "ranks": rank_info,
                 "msms_in_flight": 1 if args.sync else 3,
                 "seeds": {"scalars": SEED_SCALARS, "points": SEED_POINTS},
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_accum_l0 (bucket accumulation)",
+                "kernel": ("k_accum_bpl" if ck.window_bits == 20 else "k_accum_l0") + " (bucket accumulation)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -221,6 +274,9 @@ def main() -> int:
                 # the kernel is integer-VALU bound, not HBM bound: the ceiling that binds is
                 # the issue rate of the 10-multiplication mixed addition measured in isolation (tools/fp_bench.hip)
                 "alu": alu_roofline(args, ck, n, dom_ms),
+                # a ceiling that does not come from this repo's own micro-benchmark: the multiplier's issue rate alone --
+                # 1024 SIMDs x 2.4 GHz / 5.2 cycles per wave64 v_mad_u64_u32 x 64 lanes / MADs per mixed addition
+                "alu_hw": alu_hw_roofline(args, ck, n, dom_ms),
                 # the same kernel with the GPU to itself (one blocking MSM call after the timed region)
                 "kernel_ms_unshared": stage_ms_alone.get(dom, 0.0),
                 "alu_unshared": alu_roofline(args, ck, n, stage_ms_alone.get(dom, 0.0)),
@@ -374,6 +430,42 @@ def alu_roofline(args, ck, n, kernel_ms):
             "madds_per_launch": madds, "window_bits": c}
 
 
+MADS_PER_MADD = {"pallas": 7 * 126 + 2 * 90 + 207, "bls12_381_g1": 7 * 392 + 2 * 301 + 588}  # fpu.h: mul / sqr / fused pair
+
+
+def alu_hw_roofline(args, ck, n, kernel_ms):
+    a = alu_roofline(args, ck, n, kernel_ms)
+    if a is None:
+        return None
+    peak = 1024 * 2.4e9 / 5.2 * 64 / MADS_PER_MADD[args.curve] / 1e9
+    return {"unit": "G mixed-additions/s", "achieved": a["achieved"], "peak": round(peak, 2), "frac": a["achieved"] / peak,
+            "mads_per_mixed_addition": MADS_PER_MADD[args.curve],
+            "basis": "v_mad_u64_u32 issue only: 5.2 cycles per wave64 per SIMD (tools/ubench_valu.hip), 1024 SIMDs, 2.4 GHz nominal"}
+
+
+def key_bytes(ck, ctx, n):
+    """HBM held by the committer key: W table levels of affine points (the 17-bit twin of a bucket-per-lane key is built
+    only when a skewed vector or a short / grouped MSM needs it)"""
+    c = int(ck.window_bits)
+    levels = (255 // c + 1) if (ck.precomputed and c) else 1
+    out = {"table": n * levels * 16 * ctx.fq_limbs, "levels": levels}
+    if c == 20:
+        out["twin_17_bit_table_if_built"] = n * 16 * 16 * ctx.fq_limbs
+    return out
+
+
+def source_hash():
+    """SHA-256 over the kernel sources the library is built from (the PMC summaries carry it: a stale one is flagged)"""
+    import glob
+    import hashlib
+    hh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "accumulation_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            hh.update(os.path.basename(f).encode())
+            hh.update(open(f, "rb").read())
+    return hh.hexdigest()[:16]
+
+
 def pmc_traffic(args):
     """(HBM bytes per launch, provenance) of the dominant kernel from the committed rocprofv3 PMC passes
     (tools/profile_round.sh -> profiles/*_pmc_accum_l0.json; FETCH_SIZE doubled as MI355X_MICROARCH.md
@@ -385,8 +477,11 @@ def pmc_traffic(args):
     if not files:
         return None, None
     try:
-        return json.load(open(files[-1]))["hbm_traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT) + \
-            " (committed rocprofv3 --pmc passes of this workload; not re-measured in this run)"
+        d = json.load(open(files[-1]))
+        same = d.get("source_hash") == source_hash()
+        return d["hbm_traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT) + \
+            " (committed rocprofv3 --pmc passes of this workload; not re-measured in this run; kernel sources " + \
+            ("UNCHANGED since it was collected)" if same else "CHANGED since it was collected: stale)")
     except Exception:
         return None, None
 

@@ -216,6 +216,14 @@ int amsm_msm_partial_batch_device(amsm_ctx* ctx, const amsm_bases* bases, size_t
 int amsm_partials_combine_batch(amsm_ctx* ctx, const void* d_partials, size_t n_groups, size_t count,
                                 uint64_t* out_xy_mont, uint8_t* out_is_inf);
 
+/* n_vecs MSMs over the same generators whose scalar vectors are HOST slices (scalars[v]: n * 4 u64) -- the form the
+ * reference's provers hand their commitments over in, back to back: src/hp_as/mod.rs:372-385 (the t-vectors), :196-214 (the
+ * hiding commitments), src/r1cs_nark_as/r1cs_nark/mod.rs:216-218 (comm_a, comm_b, comm_c).  The upload of vector v + 1 runs on
+ * a copy stream while MSM v computes, so a batch pays PCIe once per vector only where it is longer than the MSM (32 MiB at
+ * 2^20: ~0.6 ms against ~1.1 ms); results as amsm_msm_batch_device.  The slices need not be pinned. */
+int amsm_msm_batch(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const uint64_t* const* scalars, size_t n_vecs,
+                   size_t n, int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+
 /* Replaces `PedersenCommitment::commit(ck, elems, Some(r))` (ext): MSM over ck.generators[..n] plus
  * r * hiding_generator (single scalar-mul, done on the host like SURVEY.md section 8(a) row a11).
  * elems_mont: raw `&[Fr]` memory (Montgomery).  randomizer_mont / hiding_xy_mont may be NULL (no
@@ -223,6 +231,14 @@ int amsm_partials_combine_batch(amsm_ctx* ctx, const void* d_partials, size_t n_
 int amsm_pedersen_commit(amsm_ctx* ctx, const amsm_bases* ck, const uint64_t* elems_mont, size_t n,
                          const uint64_t* randomizer_mont, const uint64_t* hiding_xy_mont, uint64_t* out_xy_mont,
                          uint8_t* out_is_inf);
+
+/* n_vecs commitments over one key in one call: elems_mont[v] = ns[v] Montgomery elements on the HOST (raw `&[Fr]` memory,
+ * lengths may differ), randomizers_mont = NULL or n_vecs pointers of which any may be NULL (`commit(.., None)`); uploads
+ * overlapped with the previous commitment's MSM as in amsm_msm_batch, the r_v * hiding_generator terms on host threads, ONE
+ * batched normalisation.  What a `[patch]`ed `PedersenCommitment::commit` loop calls. */
+int amsm_pedersen_commit_batch(amsm_ctx* ctx, const amsm_bases* ck, const uint64_t* const* elems_mont, const size_t* ns,
+                               size_t n_vecs, const uint64_t* const* randomizers_mont, const uint64_t* hiding_xy_mont,
+                               uint64_t* out_xy_mont, uint8_t* out_is_inf);
 
 /* Same with the committed vector already resident in HBM (Montgomery form). */
 int amsm_pedersen_commit_device(amsm_ctx* ctx, const amsm_bases* ck, const void* d_elems_mont, size_t n,

@@ -164,6 +164,19 @@ struct VariableBaseMSM {
 
 // Several MSMs in one call (pipelined on the device).  All take device-resident Montgomery scalars.
 struct MsmBatch {
+  // k MSMs over host slices of canonical scalars (`&[BigInt]`), uploads overlapped with the MSMs: amsm_msm_batch
+  static std::vector<Affine> same_bases_host(const CommitterKey& bases, const std::vector<const std::vector<Fr>*>& vecs,
+                                             bool mont = false) {
+    const size_t k = vecs.size(), n = k ? vecs[0]->size() : 0;
+    std::vector<const uint64_t*> ptrs(k);
+    for (size_t v = 0; v < k; v++) {
+      if (vecs[v]->size() != n) throw Error(AMSM_E_INVALID_ARG, "same_bases_host: vectors of one length");
+      ptrs[v] = reinterpret_cast<const uint64_t*>(vecs[v]->data());
+    }
+    return run(bases, k, [&](uint64_t* xy, uint8_t* inf) {
+      return amsm_msm_batch(bases.ctx().get(), bases.get(), 0, ptrs.data(), k, n, mont ? 1 : 0, xy, inf);
+    }, "amsm_msm_batch");
+  }
   // the same generators, several scalar vectors (the prover's back-to-back commits, src/hp_as/mod.rs:354-388)
   static std::vector<Affine> same_bases(const CommitterKey& bases, const std::vector<const FrVector*>& vecs) {
     std::vector<const void*> ptrs;
@@ -242,6 +255,37 @@ struct PedersenCommitment {
                                       randomizer ? ck.hiding_generator.data() : nullptr, out.xy.data(), &inf),
           "amsm_pedersen_commit_device");
     out.infinity = inf != 0;
+    return out;
+  }
+  // commit(ck, elems[v], randomizers[v]) for HOST vectors (`&[Fr]` memory, lengths may differ) in one call: the upload of
+  // vector v + 1 overlaps the MSM of vector v (amsm_pedersen_commit_batch) -- what the reference's back-to-back commits map
+  // to behind a patched PedersenCommitment (src/hp_as/mod.rs:372-385, src/r1cs_nark_as/r1cs_nark/mod.rs:216-218).
+  static std::vector<Affine> commit_batch_host(const CommitterKey& ck, const std::vector<const std::vector<Fr>*>& elems,
+                                               const std::vector<const Fr*>& randomizers = {}) {
+    Context& ctx = ck.ctx();
+    const size_t k = elems.size(), w = 2 * (size_t)ctx.fq_limbs();
+    std::vector<const uint64_t*> ptrs(k), rptrs(k, nullptr);
+    std::vector<size_t> ns(k);
+    bool any = false;
+    for (size_t v = 0; v < k; v++) {
+      ptrs[v] = reinterpret_cast<const uint64_t*>(elems[v]->data());
+      ns[v] = elems[v]->size();
+      if (v < randomizers.size() && randomizers[v]) {
+        rptrs[v] = randomizers[v]->data();
+        any = true;
+      }
+    }
+    if (any && ck.hiding_generator.empty()) throw Error(AMSM_E_INVALID_ARG, "commit_batch_host: key has no hiding generator");
+    std::vector<uint64_t> xy(k * w, 0);
+    std::vector<uint8_t> inf(k, 0);
+    check(amsm_pedersen_commit_batch(ctx.get(), ck.get(), ptrs.data(), ns.data(), k, any ? rptrs.data() : nullptr,
+                                     any ? ck.hiding_generator.data() : nullptr, xy.data(), inf.data()),
+          "amsm_pedersen_commit_batch");
+    std::vector<Affine> out(k);
+    for (size_t v = 0; v < k; v++) {
+      out[v].xy.assign(xy.begin() + (long)(v * w), xy.begin() + (long)((v + 1) * w));
+      out[v].infinity = inf[v] != 0;
+    }
     return out;
   }
   // Several independent commitments to vectors of one length as ONE pipelined MSM batch; the hiding terms

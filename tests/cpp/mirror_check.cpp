@@ -61,6 +61,22 @@ int main() {
       print_point("win_lo", win.at(0));
       print_point("win_hi", win.at(1));
     }
+    // host slices, several per call (amsm_msm_batch / amsm_pedersen_commit_batch): the same points as the device forms
+    {
+      std::vector<Fr> ha = a_canon.to_host(), hb = FrVector::random(ctx, 12, n, false).to_host();
+      auto hb2 = MsmBatch::same_bases_host(ck, {&ha, &hb, &ha});
+      print_point("hostbatch_a", hb2.at(0));
+      print_point("hostbatch_b", hb2.at(1));
+      print_point("hostbatch_a2", hb2.at(2));
+      std::vector<Fr> ma = a.to_host(), mb = b.to_host();
+      mb.resize(777);  // lengths may differ
+      auto cb = PedersenCommitment::commit_batch_host(ck, {&ma, &mb, &ma}, {nullptr, nullptr, &rnd});
+      print_point("hostcommit_a", cb.at(0));
+      print_point("hostcommit_b777", cb.at(1));
+      print_point("hostcommit_a_hiding_3", cb.at(2));
+      FrVector b777(ctx, mb);
+      print_point("commit_b777", PedersenCommitment::commit(ck, b777));
+    }
     // error behaviour: a key without hiding generator cannot take a randomizer
     std::vector<uint64_t> xy = ck.read(0, 4);
     CommitterKey bare = CommitterKey::load(ctx, xy, nullptr);

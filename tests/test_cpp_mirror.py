@@ -71,4 +71,9 @@ def test_cpp_mirror_matches_oracle(built_lib, cref):
     hi = msm([0] * 500 + ai[:500])
     assert pt("win_lo") == lo and pt("win_hi") == hi
     assert pt("fold_commit") == o.add(c, lo, o.mul(c, 3, hi))  # <a, key_l + 3 key_r> = <a, key_l> + 3 <a, key_r>
+    # host slices, several per call (amsm_msm_batch / amsm_pedersen_commit_batch)
+    assert pt("hostbatch_a") == Pa and pt("hostbatch_b") == Pb and pt("hostbatch_a2") == Pa
+    Pb777 = msm(bi[:777] + [0] * (n - 777))
+    assert pt("hostcommit_a") == Pa and pt("hostcommit_b777") == Pb777 and pt("commit_b777") == Pb777
+    assert pt("hostcommit_a_hiding_3") == o.add(c, Pa, o.mul(c, 3, H))
     assert vals["error_check"] == ["-1"]

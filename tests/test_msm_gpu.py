@@ -208,18 +208,25 @@ def test_north_star_size_pallas_2_20(ctxs, cref):
     ck.free()
 
 
-def test_carry_window_at_north_star_size(ctxs, cref):
-    """Keys of 2^20 generators and more use 17-bit windows: 15 of them cover the 255-bit scalars and the 16th holds only
-    the signed recoding's carry (amsm_bases_window_bits).  For Pallas that carry needs a scalar
-    above 2^254 -- one in 2^128 at random -- so the batch path would never see it in the other tests: here every 997th
-    scalar sits at the top of the field (r - 1, r - 2, 2^254 + k), and one vector is ALL r - 1 (every entry of the carry
-    window in ONE bucket).  Bit-exact against the CPU restatement, blocking and in a batch."""
-    from accumulation_amd import CommitterKey, VariableBaseMSM, ffi
+@pytest.mark.parametrize("bpl", ["1", "0"], ids=["bucket_per_lane_key", "chunked_17_bit_key"])
+def test_carry_window_at_north_star_size(cref, bpl):
+    """Round 2's keys of 2^20 generators use 17-bit windows (AMSM_BPL=0; since round 3 the twin key behind the fallback): 15
+    of them cover the 255-bit scalars and the 16th holds only the signed recoding's carry.  For Pallas that carry needs a
+    scalar above 2^254 -- one in 2^128 at random -- so the batch path would never see it in the other tests: here every
+    997th scalar sits at the top of the field (r - 1, r - 2, 2^254 + k), and one vector is ALL r - 1 (every entry of the carry
+    window in ONE bucket).  The same vectors go through round 3's 20-bit-window key (the top window's spread digit at its
+    maximum, the constant vector through the fallback).  Bit-exact against the CPU restatement, blocking and in a batch."""
+    import os
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM, ffi
     c = o.PALLAS
-    ctx = ctxs[c.name]
+    os.environ["AMSM_BPL"] = bpl
+    try:
+        ctx = Context(c.curve_id)
+    finally:
+        del os.environ["AMSM_BPL"]
     n = 1 << 20
     ck = CommitterKey.generate(ctx, 0x5EED1011, n)
-    assert ck.precomputed and ck.window_bits == 17
+    assert ck.precomputed and ck.window_bits == (20 if bpl == "1" else 17)
     small = CommitterKey.generate(ctx, 0x5EED1012, 1 << 18)
     plain = CommitterKey.generate(ctx, 0x5EED1013, 1 << 10, ffi.AMSM_BASES_NO_PRECOMPUTE)
     assert small.window_bits == 16 and plain.window_bits == 0
@@ -239,6 +246,7 @@ def test_carry_window_at_north_star_size(ctxs, cref):
         outs, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [vec, dv, vec], mont=False)
         assert np.array_equal(outs[0], ref) and np.array_equal(outs[2], ref) and not infs.any()
     ck.free()
+    ctx.close()
 
 
 def test_config5_size_pallas_2_22(ctxs, cref):

@@ -20,19 +20,23 @@ src, dst = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(list)
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_accum_l0" in r["Kernel_Name"]:
+        if "k_accum_l0" in r["Kernel_Name"] or "k_accum_bpl" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = {k: sum(v) / len(v) for k, v in sorted(acc.items())}
 # windows that hold digits: 15 at c = 17 (the default for 2^20 since round 2), 16 at c = 16 (AMSM_WINDOW=16); argv[3] overrides
-n, windows = 1 << 20, (int(sys.argv[3]) if len(sys.argv) > 3 else 15)
+n, windows = 1 << 20, (int(sys.argv[3]) if len(sys.argv) > 3 else 13)
 entries = n * windows
 stream_bytes = entries * 4  # entry words, read once (dwordx4 per 4 entries)
 fetch = mean.get("FETCH_SIZE", 0.0) * 1024.0
 write = mean.get("WRITE_SIZE", 0.0) * 1024.0
 # fetch = gather/1.0 + stream/2.0  ->  true bytes = (fetch - stream/2) * 1.0 + stream
 true_fetch = (fetch - stream_bytes / 2.0) + stream_bytes if fetch else 0.0
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402
+
 out = {
-    "kernel": "k_accum_l0",
+    "kernel": "k_accum_bpl" if windows == 13 else "k_accum_l0",
+    "source_hash": source_hash(),
     "workload": f"2^20 Pallas, precomputed key ({windows} entries per scalar), bench.py --sync",
     "launches_averaged": {k: len(v) for k, v in sorted(acc.items())},
     "counters_mean_per_launch": mean,

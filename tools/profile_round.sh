@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sync -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-schemes --sync > $OUT/trace_sync.log 2>&1
 for p in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   n=$(echo $p | cut -c1-10 | tr " " "_")
-  rocprofv3 --pmc $p --kernel-include-regex "k_accum_l0" --output-format csv -d $OUT/pmc_$n -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-schemes --sync > $OUT/pmc_$n.log 2>&1
+  rocprofv3 --pmc $p --kernel-include-regex "k_accum_(l0|bpl)" --output-format csv -d $OUT/pmc_$n -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-schemes --sync > $OUT/pmc_$n.log 2>&1
 done
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 # summaries to copy into profiles/ (tracked)
