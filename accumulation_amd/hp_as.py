@@ -370,8 +370,6 @@ class ASForHadamardProducts:
         instances = [x.instance for x in inputs] + [x.instance for x in old_accumulators]
         witnesses = [cls._check_input_witness_structure(x.witness, prover_key, hp_vec_len, False) for x in inputs] + \
                     [cls._check_input_witness_structure(x.witness, prover_key, hp_vec_len, True) for x in old_accumulators]
-        if num_all > 8:
-            raise ASError("more than 8 inputs+accumulators per accumulation are not supported by the t-vector kernel")
         hiding_vecs = hiding_rands = hiding_comms = None
         if make_zk:  # step 3
             hiding_vecs, hiding_rands, hiding_comms = cls._generate_prover_randomness(prover_key, fr, hp_vec_len,

@@ -473,7 +473,7 @@ def pmc_traffic(args):
     if args.log2n != 20 or args.curve != "pallas" or args.no_precompute:
         return None, None
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_accum_l0.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_accum_*.json")))
     if not files:
         return None, None
     try:

@@ -351,7 +351,6 @@ class ASForHadamardProducts {
       instances.push_back(&x.instance);
       witnesses.push_back(&check_witness(x.witness, pk, hp_vec_len, true));
     }
-    if (num_all > 8) throw ASError("more than 8 inputs+accumulators per accumulation are not supported by the t-vector kernel");
     // step 3: prover randomness (:179-230) -- the hiding vectors are CONSTANT vectors (`vec![rand; len]`)
     std::shared_ptr<FrVector> hid_a, hid_b;
     InputWitnessRandomness hid_r{};

@@ -149,8 +149,11 @@ def hp_case(ctx, ck, gens, H, n, make_zk, shape, seed=100):
 
 
 @pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
-@pytest.mark.parametrize("shape", [(1, 0), (3, 0), (2, 1), (0, 2), (0, 0)], ids=lambda s: f"in{s[0]}_acc{s[1]}")
+@pytest.mark.parametrize("shape", [(1, 0), (3, 0), (2, 1), (0, 2), (0, 0), (7, 2), (9, 8), (16, 0), (3, 20)],
+                         ids=lambda s: f"in{s[0]}_acc{s[1]}")
 def test_hp_as_prove_vs_oracle(hp_env, make_zk, shape):
+    """the reference has no limit on inputs + accumulators (src/hp_as/mod.rs:288-349): beyond the fused kernel's eight the
+    t-vectors come from block products (api_schemes.inc: t_vecs_blocked) -- 9, 16, 17 and 23 here, zk and not"""
     ctx, ck, gens, H, n = hp_env
     hp_case(ctx, ck, gens, H, n, make_zk, shape)
 

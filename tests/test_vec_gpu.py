@@ -74,7 +74,7 @@ def test_combine_vectors_any_count_and_unit_coefficients(ctxs, cref, c, k):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-@pytest.mark.parametrize("n_in", [1, 2, 3, 4])
+@pytest.mark.parametrize("n_in", [1, 2, 3, 4, 8, 9, 13, 16, 17])
 @pytest.mark.parametrize("zk", [False, True])
 def test_compute_t_vecs(ctxs, c, n_in, zk):
     from accumulation_amd.hp_as import compute_t_vecs
