@@ -170,6 +170,8 @@ struct amsm_ctx {
   bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
   bool bpl = true;  // keys of 2^20 generators and more are precomputed for 20-bit windows and their MSMs of (2^19, 2^20] pairs
                     // take the bucket-per-lane pipeline (AMSM_BPL=0: 17-bit windows + the chunked pipeline, round 2's path)
+  bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline
+                          // (AMSM_BPL_PROBE=0: find out from the prep's overflow flag only -- the safety net either way)
   unsigned long long n_bpl = 0, n_bpl_fallbacks = 0;  // MSMs that took it / that were re-run chunked (skewed digits)
   bool profiling = false;
   float stage_ms[ST_COUNT] = {};  // mean over the MSMs of the last call
@@ -179,6 +181,7 @@ struct amsm_ctx {
   hipEvent_t fork = nullptr;
   hipEvent_t ip_ready = nullptr;  // amsm_ipa_round_fused: the inner products have reached the host
   DevBuf scalars;
+  DevBuf probe_flags;  // one word per vector probed for skew (api_pipeline.inc: bpl_probe_device)
   // host-slice batches (amsm_msm_batch, amsm_pedersen_commit_batch): a ring of device staging buffers, one more than the
   // pipeline has slots, filled on a copy stream while the previous MSMs compute (created on first use)
   static constexpr int STAGE_RING = N_SLOTS + 1;

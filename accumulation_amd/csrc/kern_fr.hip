@@ -255,6 +255,10 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
                          vals, err);                                                                                 \
   }                                                                                                                  \
   template <>                                                                                                        \
+  void launch_skew_probe<FR>(hipStream_t st, const u32* scalars, int mont, u32 n, u32 c, u32 W, u32* d_flag) {        \
+    hipLaunchKernelGGL((k_skew_probe<FR>), dim3(1), dim3(1024), 0, st, scalars, mont, n, c, W, d_flag);              \
+  }                                                                                                                  \
+  template <>                                                                                                        \
   void launch_vec_random<FR>(hipStream_t st, u32* out, u64 seed, u32 n, int mont) {                                  \
     hipLaunchKernelGGL((k_vec_random<FR>), dim3(cdiv_(n, 256)), dim3(256), 0, st, out, seed, n, mont);               \
   }                                                                                                                  \

@@ -393,6 +393,48 @@ __global__ void __launch_bounds__(256) k_vec_random(u32* __restrict__ out, u64 s
 }
 
 // ---------------------------------------------------------------------------------------------
+// Skew probe (round 3): would this scalar vector overflow the bucket-per-lane prep?  1024 evenly spaced samples, signed
+// c-bit digits as the prep computes them; per window a 2048-bin histogram of the non-zero digits (hashed) in LDS.  Uniform
+// digits put at most ~6 samples into a bin; a constant vector (`vec![x; len]`), a vector with a large share of
+// equal or of few distinct values puts hundreds.  *flag = 1 when any bin reaches PROBE_LIMIT.  An optimisation only: the
+// host then sends the vector straight to the chunked pipeline instead of finding out from the prep's overflow flag (which
+// stays the safety net for what 1024 samples miss).  One 1024-lane workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 PROBE_SAMPLES = 1024, PROBE_BINS = 2048, PROBE_LIMIT = 24;
+template <class Fr>
+__global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ scalars, int mont, u32 n, u32 c, u32 W,
+                                                      u32* __restrict__ flag) {
+  __shared__ u32 bins[PROBE_BINS];
+  __shared__ u32 worst;
+  const u32 t = threadIdx.x;
+  if (t == 0) worst = 0;
+  const u32 i = (u32)(((u64)t * n) / PROBE_SAMPLES);
+  Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
+  if (mont) s = fe_from_mont<Fr>(s);
+  const u32 mask = (1u << c) - 1u, half = 1u << (c - 1);
+  u32 carry = 0;
+  for (u32 w = 0; w < W; w++) {
+    for (u32 k = t; k < PROBE_BINS; k += blockDim.x) bins[k] = 0;
+    __syncthreads();
+    u32 raw = (s.v[0] & mask) + carry;
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
+    s.v[7] >>= c;
+    carry = 0;
+    u32 d = raw;
+    if (raw > half && w + 1 < W) {
+      d = (1u << c) - raw;
+      carry = 1;
+    }
+    u32 seen = 0;
+    if (d != 0 && t < n) seen = atomicAdd(&bins[(d * 2654435761u) >> 21], 1u) + 1u;
+    if (seen >= PROBE_LIMIT) atomicMax(&worst, seen);
+    __syncthreads();
+  }
+  if (t == 0 && worst) *flag = 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
 // digits: scalar -> W signed digits -> (key, value) entries, window-major (entry w*n + i).
 // Reads are 2 x dwordx4 per lane, coalesced; writes are coalesced per window.
 // ---------------------------------------------------------------------------------------------

@@ -18,10 +18,18 @@ C = o.PALLAS
 N = 1 << 20
 
 
-@pytest.fixture(scope="module")
-def env(cref):
+@pytest.fixture(scope="module", params=["probe", "no_probe"])
+def env(cref, request):
+    """probe: a 1024-sample look at every candidate vector's digits sends skewed vectors straight to the chunked pipeline;
+    no_probe (AMSM_BPL_PROBE=0): every candidate is attempted and the prep's overflow flag triggers the re-run -- the safety
+    net under the probe, exercised on its own here"""
     from accumulation_amd import CommitterKey, Context
-    ctx = Context(C.curve_id)
+    os.environ["AMSM_BPL_PROBE"] = "1" if request.param == "probe" else "0"
+    try:
+        ctx = Context(C.curve_id)
+    finally:
+        del os.environ["AMSM_BPL_PROBE"]
+    ctx.probe = request.param == "probe"
     ck = CommitterKey.generate(ctx, 0x5EED1001, N)
     xy, _ = ck.read()
     yield ctx, ck, xy
@@ -29,7 +37,9 @@ def env(cref):
     ctx.close()
 
 
-def check(ctx, ck, xy, sc, cref, off=0, expect_fallback=None, threads=17):
+def check(ctx, ck, xy, sc, cref, off=0, expect_fallback=None, threads=17, probe_sees_it=True):
+    """expect_fallback False: the MSM must stay on the bucket-per-lane pipeline; True: it must end up chunked -- re-run after
+    the prep's overflow flag, or (probe on, and the skew is one 1024 samples show) sent there without an attempt"""
     from accumulation_amd import VariableBaseMSM
     before = ctx.pipeline_stats()
     got, inf = VariableBaseMSM.multi_scalar_mul(ck, sc, base_off=off)
@@ -39,8 +49,13 @@ def check(ctx, ck, xy, sc, cref, off=0, expect_fallback=None, threads=17):
     assert bool(inf) == bool(rinf) and np.array_equal(got, ref)
     took = after["bucket_per_lane"] - before["bucket_per_lane"]
     fell = after["fallbacks"] - before["fallbacks"]
-    if expect_fallback is not None:
-        assert took >= 1 and (fell >= 1) == expect_fallback, (took, fell)
+    if expect_fallback is False:
+        assert took >= 1 and fell == 0, (took, fell)
+    elif expect_fallback is True:
+        if getattr(ctx, "probe", True) and probe_sees_it:
+            assert took == 0 and fell == 0, (took, fell)
+        else:
+            assert took >= 1 and fell >= 1, (took, fell)
     return took, fell
 
 
@@ -132,7 +147,8 @@ def test_batch_mixes_uniform_and_skewed_vectors(env, cref):
     before = ctx.pipeline_stats()
     pts, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, dv, mont=False)
     after = ctx.pipeline_stats()
-    assert after["bucket_per_lane"] - before["bucket_per_lane"] == 5 and after["fallbacks"] - before["fallbacks"] == 2
+    took, fell = after["bucket_per_lane"] - before["bucket_per_lane"], after["fallbacks"] - before["fallbacks"]
+    assert (took, fell) == ((3, 0) if ctx.probe else (5, 2))
     for j, v in enumerate(vecs):
         ref, rinf = cref.msm(C.curve_id, xy, v, threads=17)
         assert bool(infs[j]) == bool(rinf) and np.array_equal(pts[j], ref), j
@@ -198,7 +214,8 @@ def test_bls12_381_at_2p20(cref):
         assert bool(inf) == bool(rinf) and np.array_equal(got, ref)
         top = np.tile(np.array(o.int_to_limbs(c.r - 2, 4), dtype=np.uint64), (N, 1))
         got, inf = VariableBaseMSM.multi_scalar_mul(ck, top)
-        assert ctx.pipeline_stats()["fallbacks"] == 1
+        st = ctx.pipeline_stats()
+        assert st["bucket_per_lane"] == 1 and st["fallbacks"] == 0  # the probe sent the constant vector to the chunked pipeline
         ref, rinf = cref.msm(c.curve_id, xy, top, threads=17)
         assert bool(inf) == bool(rinf) and np.array_equal(got, ref)
         ck.free()

@@ -60,13 +60,20 @@ def test_pedersen_commit_batch_ragged_with_and_without_randomizers(cref, c):
         ctx.close()
 
 
-def test_batch_at_2p20_with_a_constant_vector_in_the_middle(cref):
-    """five host vectors of 2^20 Pallas scalars, the third constant: the bucket-per-lane MSMs overlap the uploads, the constant
-    one is re-run chunked FROM THE STAGING RING after its successors were uploaded"""
+@pytest.mark.parametrize("probe", ["1", "0"], ids=["probe", "no_probe"])
+def test_batch_at_2p20_with_a_constant_vector_in_the_middle(cref, probe):
+    """five host vectors of 2^20 Pallas scalars, the third constant: the bucket-per-lane MSMs overlap the uploads; the constant
+    one goes chunked -- picked out by the host-side digit probe, or (AMSM_BPL_PROBE=0) attempted and re-run FROM THE STAGING
+    RING after its successors were uploaded"""
+    import os
     from accumulation_amd import CommitterKey, Context, VariableBaseMSM
     c = o.PALLAS
     n = 1 << 20
-    ctx = Context(c.curve_id)
+    os.environ["AMSM_BPL_PROBE"] = probe
+    try:
+        ctx = Context(c.curve_id)
+    finally:
+        del os.environ["AMSM_BPL_PROBE"]
     try:
         ck = CommitterKey.generate(ctx, 0x5EED1001, n)
         xy, _ = ck.read()
@@ -75,7 +82,8 @@ def test_batch_at_2p20_with_a_constant_vector_in_the_middle(cref):
         before = ctx.pipeline_stats()
         pts, infs = VariableBaseMSM.multi_scalar_mul_batch_host(ck, vecs)
         after = ctx.pipeline_stats()
-        assert after["bucket_per_lane"] - before["bucket_per_lane"] == 5 and after["fallbacks"] - before["fallbacks"] == 1
+        took, fell = after["bucket_per_lane"] - before["bucket_per_lane"], after["fallbacks"] - before["fallbacks"]
+        assert (took, fell) == ((4, 0) if probe == "1" else (5, 1))
         for j, v in enumerate(vecs):
             ref, rinf = cref.msm(c.curve_id, xy, v, threads=17)
             assert bool(infs[j]) == bool(rinf) and np.array_equal(pts[j], ref), j
