@@ -724,3 +724,23 @@ def test_large_msm_as_windows_of_the_key_equals_the_whole(ctxs):
         ctx.close()
     for r in results[1:]:
         assert np.array_equal(r[0], results[0][0]) and np.array_equal(r[1], results[0][1])
+
+
+def test_published_bls12_381_multiples_through_the_device_msm(ctxs):
+    """third-party vectors (tests/test_third_party_kats_cpu.py: the zkcrypto / consensus-spec encodings of 1 G, 2 G, 3 G): MSMs over
+    copies of the generator with unit scalars and over [G] with the scalar k, plain and precomputed keys"""
+    from accumulation_amd import CommitterKey, VariableBaseMSM
+    from tests.test_third_party_kats_cpu import KATS, decode
+    c = o.BLS12_381_G1
+    ctx = ctxs[c.name]
+    g = o.generator(c)
+    assert decode(KATS[1]) == g
+    for flags in (1, 2):
+        xy, _ = h.points_to_np(c, [g] * 300)
+        ck = CommitterKey.load(ctx, xy, None, flags)
+        for k in (2, 3):
+            out, inf = VariableBaseMSM.multi_scalar_mul(ck, h.scalars_to_np([1] * k + [0] * (300 - k)))
+            assert h.np_to_point(c, out, inf) == decode(KATS[k]), (flags, k)
+            out, inf = VariableBaseMSM.multi_scalar_mul(ck, h.scalars_to_np([k]))
+            assert h.np_to_point(c, out, inf) == decode(KATS[k]), (flags, k)
+        ck.free()

@@ -42,7 +42,7 @@ def run(*args):
 @pytest.mark.parametrize("sponge", ["sha256", "poseidon"])
 def test_all_schemes_both_shapes(built_lib, sponge):
     rows, text = run("all", "6", "6", "--sponge", sponge, "--reps", "1")
-    assert len(rows) == 8  # 4 schemes x 2 shapes
+    assert len(rows) == 10  # 4 accumulation schemes x 2 shapes + the NARK on its own (examples/scaling-nark.rs), zk off / on
     assert "Indexer:" in text and "Prover:" in text and "Accumulator witness size:" in text
     c = o.PALLAS
     P, F = ser.point_size(c), 32
@@ -65,6 +65,10 @@ def test_all_schemes_both_shapes(built_lib, sponge):
             # LabeledCommitment{label "", comm, shifted None, degree_bound None} + point + eval + Proof{l, r (6 each), key, c, 2 Options}
             proof = 2 * (8 + 6 * P) + P + F + 1 + (P if zk else 0) + 1 + (F if zk else 0)
             assert r["accumulator_bytes"] == (8 + P + 1 + 1) + 2 * F + proof
+        elif r["scheme"] == "r1cs_nark":
+            # Proof{first_msg: 3 points + Option<5 points>, second_msg: Vec<F>(num_constraints - 5 + 1) + Option<4 F>}
+            n_wit = n - 5 + 1
+            assert r["accumulator_bytes"] == 3 * P + 1 + (5 * P if zk else 0) + (8 + F * n_wit) + 1 + (4 * F if zk else 0)
         elif r["scheme"] == "trivial_pc_as":
             assert r["instance_bytes"] == (8 + P + 1) + 2 * F
             assert r["witness_bytes"] == 8 + (8 + F * n) + 1 + 1

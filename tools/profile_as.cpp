@@ -214,6 +214,58 @@ static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
          harness_shape ? "harness: 1 input + 2x the same accumulator" : "n2: 1 input + 1 accumulator", harness_shape, r);
 }
 
+// ---- the R1CS NARK on its own: examples/scaling-nark.rs:58-110 (profile_nark: index / prove / verify, proof size; main runs it
+// with zk off, then on).  DummyCircuit as at :21-56: witness = [a, b, a, ..., a] (num_constraints - 5 + 1 variables), instance
+// = [1, a b, a, a, a, a], num_constraints - 1 copies of a * b = c and one empty constraint.  `harness_shape` = make_zk.
+template <class Sponge>
+static void profile_nark(const Opt& o, int lg, bool make_zk) {
+  using Nark = r1cs_nark::R1CSNark<Sponge>;
+  Context ctx(o.curve, 0);
+  hp_as::FrOps fr{o.curve};
+  const size_t n_con = (size_t)1 << lg, n_inputs = 5, n_inst = n_inputs + 1;
+  const size_t n_wit = (n_con > 5 ? n_con - 5 : 1) + 1;  // a, b, then num_witness_variables - 1 copies of a
+  const Fr one = {1, 0, 0, 0};
+  HarnessRng hr(0xB0B);
+  hp_as::Rng zk_rng = make_zk ? hp_as::Rng([&hr]() { return hr.field(); }) : hp_as::Rng();
+  Result r;
+  Fr a = hr.field(), b = hr.field();
+  Fr am = fr.to_mont(a), bm = fr.to_mont(b), abm = fr.mul(am, bm), ab;
+  check(amsm_fr_from_mont(o.curve, abm.data(), 1, ab.data()), "from_mont");
+  auto t0 = Clock::now();
+  std::vector<r1cs_nark::Matrix::Row> A, B, C;
+  for (size_t k = 0; k + 1 < n_con; k++) {
+    A.push_back({{one, n_inst + 0}});
+    B.push_back({{one, n_inst + 1}});
+    C.push_back({{one, 1}});
+  }
+  A.push_back({});
+  B.push_back({});
+  C.push_back({});
+  r1cs_nark::IndexProverKey ipk = Nark::index(ctx, A, B, C, n_inst, n_inst + n_wit, 31337);
+  r.index_ms = ms_since(t0);
+  std::vector<Fr> inst{one, ab};
+  for (size_t k = 1; k < n_inputs; k++) inst.push_back(a);
+  std::vector<Fr> w(n_wit, am);
+  w[1] = bm;
+  auto wit = std::make_shared<FrVector>(ctx, w);
+  r1cs_nark::Proof proof = Nark::prove(ipk, inst, wit, zk_rng, Sponge());
+  r.prove_ms = median_ms(o.reps, [&] { proof = Nark::prove(ipk, inst, wit, zk_rng, Sponge()); });
+  t0 = Clock::now();
+  r.verified = Nark::verify(ipk, inst, proof, Sponge());
+  r.verify_ms = ms_since(t0);
+  std::vector<Fr> bad = inst;
+  bad[1] = a;
+  r.decided = !Nark::verify(ipk, bad, proof, Sponge());  // (no decider in a NARK: the slot reports that a wrong input is rejected)
+  r.acc_bytes = ser::serialized_size(ctx, proof);
+  if (o.roundtrip) {
+    auto pb = ser::serialize(ctx, proof);
+    r.roundtrip = pb.size() == r.acc_bytes && ser::serialize(ctx, ser::deserialize<r1cs_nark::Proof>(ctx, pb)) == pb;
+  }
+  printf("(num_constraints, index_time, prover_time, verifier_time):\n(%zu, %.0f, %.0f, %.0f)\nProof size: %zu\n", n_con, r.index_ms,
+         r.prove_ms, r.verify_ms, r.acc_bytes);
+  report(o, "r1cs_nark", lg, "log2_constraints", make_zk ? "harness: scaling-nark.rs, make_zk" : "n2: scaling-nark.rs, no zk", make_zk, r);
+}
+
 // ---- ipa_pc_as (examples/scaling-as.rs:199-280 dl_param_gen / dl_input_gen) -------------------------------------------------
 template <class Sponge>
 static void profile_ipa(const Opt& o, int lg, bool harness_shape) {
@@ -323,7 +375,8 @@ static void run_all(const Opt& o) {
   } schemes[] = {{"trivial_pc_as", profile_trivial<Sponge>},
                  {"ipa_pc_as", profile_ipa<Sponge>},
                  {"hp_as", profile_hp<Sponge>},
-                 {"r1cs_nark_as", profile_nark_as<Sponge>}};
+                 {"r1cs_nark_as", profile_nark_as<Sponge>},
+                 {"r1cs_nark", profile_nark<Sponge>}};
   for (auto& s : schemes) {
     if (o.scheme != "all" && o.scheme != s.name) continue;
     printf("\n\n\n================ Benchmarking %s ================\n", s.name);
