@@ -70,3 +70,58 @@ def test_schemes_run_unchanged_on_a_multi_device_context():
         finally:
             ctx.close()
     assert accs[0] == accs[1]
+
+
+def test_one_exchange_per_dependent_commit_round():
+    """Multi-device contexts exchange partial records ONCE per sharded MSM / commit call (amsm_ctx_collectives), and the
+    scheme drivers batch every group of commitments that does not depend on a Fiat-Shamir challenge in between -- so a
+    prover's number of exchanges is its number of dependent commit rounds, whatever the number of vectors:
+      hp_as prove, no zk: 1 (the product-polynomial commitments, src/hp_as/mod.rs:354-388); zk: 2 (+ the three hiding
+      commitments, :196-214, absorbed before mu is squeezed); decide: 1 (:906-922);
+      r1cs_nark prove: 1 (:216-261, all eight commitments of the zk prover in one batch);
+      r1cs_nark_as prove, no zk: 1 (the nested hp_as round); zk: 3 (the prover's randomness commitments
+      src/r1cs_nark_as/mod.rs:394-410, then the nested scheme's two)."""
+    from accumulation_amd import MultiContext, PedersenCommitment, ffi
+    from accumulation_amd import r1cs_nark as nark
+    from accumulation_amd.hp_as import ASForHadamardProducts as HP
+    from accumulation_amd.r1cs_nark_as import ASForR1CSNark as NAS, Input, InputInstance
+    from accumulation_amd.scalar_field import MODULI, Fr
+    from accumulation_amd.sponge import Sha256Sponge
+    from tests.test_as_layers_vs_oracle_gpu import hp_inputs
+    from tests.test_hp_as_scheme_gpu import SchemeRng
+    from tests.test_r1cs_nark_gpu import dummy_circuit
+    ctx = MultiContext(ffi.AMSM_PALLAS, (0, 0, 0))
+    try:
+        def delta(f):
+            before = ctx.collectives
+            out = f()
+            return ctx.collectives - before, out
+        n = 500
+        ck = PedersenCommitment.setup(ctx, n, seed=5)
+        for zk, expect in ((False, 1), (True, 2)):
+            ins = hp_inputs(ctx, ck, n, 3, zk, 100)
+            rng = SchemeRng(7) if zk else None
+            d, (acc, proof) = delta(lambda: HP.prove(ck, ins, [], rng, None))
+            assert d == expect, (zk, d)
+            d, ok = delta(lambda: HP.decide(ck, acc, None))
+            assert ok and d == 1, d
+        r = MODULI[ctx.curve]
+        fr = Fr(ctx.curve)
+        A, B, C_, _, _ = dummy_circuit(5, 300, 2, 3, r)
+        ipk = nark.index(ctx, A, B, C_, 6, 8, key_seed=9)
+        pk, vk, dk = NAS.index(ipk)
+        for zk, expect_nark, expect_as in ((False, 1, 1), (True, 1, 3)):
+            rng = SchemeRng(11)
+            ins = []
+            for _ in range(2):
+                a, b = rng.field() % r, rng.field() % r
+                _, _, _, inst, w = dummy_circuit(5, 300, a, b, r)
+                d, proof = delta(lambda: nark.prove(ipk, inst, ctx.upload(fr.to_limbs_many(w)), zk, NAS._sponges(Sha256Sponge())[0],
+                                                    rng if zk else None))
+                assert d == expect_nark, (zk, d)
+                ins.append(Input(InputInstance(inst, proof.first_msg), proof.second_msg))
+            d, (acc, _) = delta(lambda: NAS.prove(pk, ins, [], rng if zk else None, None))
+            assert d == expect_as, (zk, d)
+            assert NAS.decide(dk, acc, None)
+    finally:
+        ctx.close()
