@@ -37,6 +37,8 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
     size_t base_off = 0, n = 0;
     const void* d_scalars = nullptr;
     int mont = 0;
+    int group_shift = -1;
+    bool force_chunked = false;  // a bucket-split MSM whose prep overflowed: the re-run must not choose that pipeline again
     int (*rerun)(amsm_ctx*, Slot*) = nullptr;
   } job;
   void* h_pinned = nullptr;
@@ -170,6 +172,15 @@ struct amsm_ctx {
   bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
   bool bpl = true;  // keys of 2^20 generators and more are precomputed for 20-bit windows and their MSMs of (2^19, 2^20] pairs
                     // take the bucket-per-lane pipeline (AMSM_BPL=0: 17-bit windows + the chunked pipeline, round 2's path)
+  bool bpl_mid = false;  // (experiment, off: measured no better than the other pipelines) Pallas keys of 2^16 .. 2^19 generators: 17-bit windows and the bucket-per-lane pipeline for MSMs of
+                        // 2^15 .. 2^19 pairs over them (AMSM_BPL_MID=0: round 2's widths and the other pipelines)
+  // Bucket-split pipeline for precomputed-key MSMs of 2^16 .. 2^17 pairs (AMSM_BPS): 0 never; 1 (default) the grouped MSMs of
+  // the IPA opening rounds only -- their scalars are challenge products, uniform by construction, and the call is one blocking
+  // MSM (ipa_pc_as 2^16 prove 8.17 -> 7.69 ms); 2 every candidate, behind the skew probe -- pays on uniform vectors (hp_as 2^16
+  // prove 1.03 -> 0.85 ms, batches 216 -> 250 M pairs/s) but the probe's synchronisation and the constant vectors of the
+  // reference's DummyCircuit cost r1cs_nark_as at 2^16 more than that (5.2 -> 5.9 ms): not the default
+  int bps = 1;
+  unsigned long long n_bps = 0, n_bps_fallbacks = 0;
   bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline
                           // (AMSM_BPL_PROBE=0: find out from the prep's overflow flag only -- the safety net either way)
   unsigned long long n_bpl = 0, n_bpl_fallbacks = 0;  // MSMs that took it / that were re-run chunked (skewed digits)

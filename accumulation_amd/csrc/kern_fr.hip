@@ -128,12 +128,12 @@ u32 prep_bpl_stride(const MsmGeom& g) {
   return (u32)((per + per / 4ull + 4096ull + 1023ull) & ~1023ull);
 }
 bool prep_bpl_supported(const MsmGeom& g) {
-  if (!g.precomp || g.groups != 1u || g.n_sets != 1u || g.S > 16u || g.n == 0) return false;
-  if (g.B < (1u << 16) || (g.B & 1023u) || (g.B >> 10) > PREP_MAX_P || ((g.B >> 10) & 1u)) return false;
+  if (!g.precomp || g.n_sets != g.groups || g.S > 16u || g.n == 0) return false;  // one bucket set per group (precomputed key)
+  if (g.B < (1u << 16) || (g.B & 1023u) || (g.B >> 10) > PREP_MAX_P || ((g.B >> 10) & 3u)) return false;
   PrepGeom pg = prep_bpl_geom(g);
   if (pg.IB > 30u) return false;
-  // the expected partition must fit the LDS stage with room for the digits' spread
-  if ((unsigned long long)g.E / pg.P + 2048ull > pg.CAP) return false;
+  // the expected partition must fit the LDS stage with room for the digits' spread (sigma ~ 180 entries at 30 k)
+  if ((unsigned long long)g.E / pg.P + 1024ull > pg.CAP) return false;
   return prep_bpl_scatter_lds(g, pg) <= PREP_LDS_LIMIT && prep_bpl_local_lds(pg) <= PREP_LDS_LIMIT &&
          (unsigned long long)pg.P * prep_bpl_stride(g) < (1ull << 31);
 }
@@ -147,6 +147,63 @@ static void prep_bpl_attr(KS scatter_kernel) {
   if (dev != 63 && (prep_bpl_attr_devices.load(std::memory_order_acquire) & bit)) return;
   (void)hipFuncSetAttribute((const void*)k_prep_local_t, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
   prep_bpl_attr_devices.fetch_or(bit, std::memory_order_release);
+}
+
+// ---- bucket-split prep (k_prep_local_s): partitions of 1024 / L buckets = 1024 lanes, 32-bit interchange entries ----
+static PrepGeom prep_bps_geom(const MsmGeom& g, u32 log2_l) {
+  PrepGeom pg;
+  pg.SH = 10u - log2_l;
+  pg.P = g.B >> pg.SH;
+  pg.SPB = g.S <= 16u ? 512u : 256u;
+  unsigned long long max_idx = (unsigned long long)g.base_off + g.n - 1ull +
+                               (g.precomp ? (unsigned long long)(g.W - 1u) * g.table_stride : 0ull);
+  if (g.idx_rel_bits) max_idx = ((unsigned long long)(g.W - 1u) << g.idx_rel_bits) | ((1ull << g.idx_rel_bits) - 1ull);
+  pg.IB = 1;
+  while ((max_idx >> pg.IB) != 0ull) pg.IB++;
+  const u32 nbp = 1u << pg.SH;
+  const u32 budget_words = 37888u, fixed_words = 3u * nbp + 1024u + 2u * BPS_GROUPS + 2u;
+  pg.CAP = budget_words - fixed_words;
+  pg.HEAVY = 0xffffffffu;
+  return pg;
+}
+static size_t prep_bps_local_lds(const PrepGeom& pg) {
+  return (size_t)(3u * (1u << pg.SH) + 1024u + 2u * BPS_GROUPS + 2u + pg.CAP) * sizeof(u32);
+}
+u32 prep_bps_partitions(const MsmGeom& g, u32 log2_l) { return g.B >> (10u - log2_l); }
+u32 prep_bps_stride(const MsmGeom& g, u32 log2_l) {
+  const u32 P = std::max(1u, prep_bps_partitions(g, log2_l));
+  const unsigned long long per = ((unsigned long long)g.E + P - 1) / P;
+  return (u32)((per + per / 2ull + 4096ull + 1023ull) & ~1023ull);
+}
+// lanes per bucket (log2): enough partitions that one fits the LDS stage and that the chip is filled (>= 128 partitions =
+// 131 072 lanes), at most a wave per bucket.  -1: this geometry does not take the bucket-split pipeline.
+int prep_bps_choose(const MsmGeom& g) {
+  if (!g.precomp || g.n == 0 || g.S > 32u || g.B < 64u || (g.B & (g.B - 1u))) return -1;
+  unsigned long long want = 128;
+  while (want * 24576ull < g.E) want <<= 1;
+  for (int l = 0; l <= 6; l++) {
+    if ((10 - l) < 0 || (g.B >> (10 - l)) == 0) continue;
+    const unsigned long long P = g.B >> (10 - l);
+    if (P < want && l < 6) continue;
+    if (P > PREP_MAX_P || (P & 1ull)) return -1;
+    MsmGeom g2 = g;
+    PrepGeom pg = prep_bps_geom(g2, (u32)l);
+    if (pg.IB + pg.SH > 31u) return -1;
+    if ((unsigned long long)g.E / P + 1024ull > pg.CAP) return -1;
+    if (prep_scatter_lds(g, pg) > PREP_LDS_LIMIT || prep_bps_local_lds(pg) > PREP_LDS_LIMIT) return -1;
+    if (P * (unsigned long long)prep_bps_stride(g, (u32)l) >= (1ull << 31)) return -1;
+    return l;
+  }
+  return -1;
+}
+static std::atomic<unsigned long long> prep_bps_attr_devices{0};
+static void prep_bps_attr() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  const unsigned long long bit = 1ull << dev;
+  if (dev != 63 && (prep_bps_attr_devices.load(std::memory_order_acquire) & bit)) return;
+  (void)hipFuncSetAttribute((const void*)k_prep_local_s, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  prep_bps_attr_devices.fetch_or(bit, std::memory_order_release);
 }
 
 void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
@@ -211,6 +268,49 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
                          b.vals_sorted);                                                                             \
     hipLaunchKernelGGL(k_prep_offsets, dim3(cdiv_(g.B, 256)), dim3(256), (pg.P + 256) * sizeof(u32), st, part_start, \
                        part_items, pg, g, b.start, b.items, b.item_off, b.vals_sorted);                              \
+    return 0;                                                                                                        \
+  }                                                                                                                  \
+  template <>                                                                                                        \
+  int launch_prep_bps<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, u32 log2_l, const PrepBplBuffers& b) { \
+    PrepGeom pg = prep_bps_geom(g, log2_l);                                                                          \
+    u32* part_total = b.d_small;                                                                                     \
+    u32* part_start = b.d_small + (PREP_MAX_P + 1);                                                                  \
+    u32* part_cursor = b.d_small + 2 * (PREP_MAX_P + 1);                                                             \
+    PrepHeavy hv;                                                                                                    \
+    hv.n = b.d_small + 4 * (PREP_MAX_P + 1);                                                                         \
+    hv.cnt = hv.n + 1;                                                                                               \
+    hv.ids = hv.cnt + 64;                                                                                            \
+    hv.cur = hv.end = hv.ids;                                                                                        \
+    {                                                                                                                \
+      size_t zero_bytes = (16 + 4 * (PREP_MAX_P + 1) + 1) * sizeof(u32);                                             \
+      zero_bytes = (zero_bytes + 255) & ~(size_t)255;                                                                \
+      if (b.err != b.d_small - 16) return -1;                                                                        \
+      if (hipMemsetAsync(b.err, 0, zero_bytes, st) != hipSuccess) return -1;                                         \
+    }                                                                                                                \
+    prep_bps_attr();                                                                                                 \
+    {                                                                                                                \
+      PrepGeom ph = pg;                                                                                              \
+      ph.SPB = 1024;                                                                                                 \
+      hipLaunchKernelGGL((k_prep_hist<FR>), dim3(cdiv_(g.n, 1024)), dim3(1024), pg.P * sizeof(u32), st, scalars,      \
+                         mont, g, ph, part_total, b.err);                                                            \
+    }                                                                                                                \
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P, pg.HEAVY, hv);         \
+    const size_t lds_scatter = prep_scatter_lds(g, pg);                                                              \
+    if (g.S <= 16u) {                                                                                                \
+      if (lds_scatter > 64 * 1024)                                                                                   \
+        (void)hipFuncSetAttribute((const void*)k_prep_scatter<FR, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)PREP_LDS_LIMIT);                                                              \
+      hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1>), dim3(cdiv_(g.n, pg.SPB)), dim3(512), lds_scatter, st, scalars, \
+                         mont, g, pg, part_start, part_cursor, b.part);                                              \
+    } else {                                                                                                         \
+      if (lds_scatter > 64 * 1024)                                                                                   \
+        (void)hipFuncSetAttribute((const void*)k_prep_scatter<FR, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)PREP_LDS_LIMIT);                                                              \
+      hipLaunchKernelGGL((k_prep_scatter<FR, 32, 1>), dim3(cdiv_(g.n, pg.SPB)), dim3(256), lds_scatter, st, scalars, \
+                         mont, g, pg, part_start, part_cursor, b.part);                                              \
+    }                                                                                                                \
+    hipLaunchKernelGGL(k_prep_local_s, dim3(pg.P), dim3(1024), prep_bps_local_lds(pg), st, part_start, b.part, g, pg, \
+                       prep_bps_stride(g, log2_l), log2_l, b.ents_t, (BplGroup*)b.grp, b.err);                       \
     return 0;                                                                                                        \
   }                                                                                                                  \
   template <>                                                                                                        \

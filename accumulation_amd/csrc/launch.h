@@ -95,6 +95,16 @@ u32 prep_bpl_partitions(const MsmGeom& g);
 u32 prep_bpl_groups_per_partition();  // group headers (and 64-lane blocks of `order`) per partition
 template <class Fr>
 int launch_prep_bpl(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBplBuffers& b);
+// Bucket-split prep for small / medium MSMs (prep_kernels.h: k_prep_local_s): every bucket on 2^log2_l adjacent lanes.
+// prep_bps_choose: log2 of the lanes per bucket for this geometry, or -1 when it does not take this pipeline.
+int prep_bps_choose(const MsmGeom& g);
+u32 prep_bps_partitions(const MsmGeom& g, u32 log2_l);
+u32 prep_bps_stride(const MsmGeom& g, u32 log2_l);
+template <class Fr>
+int launch_prep_bps(hipStream_t st, const u32* scalars, int mont, MsmGeom g, u32 log2_l, const PrepBplBuffers& b);
+template <class Fq>
+void launch_accum_bps(hipStream_t st, const u32* table, const u32* ents_t, const void* grp, u32 n_groups, u32 log2_l,
+                      const u32* flags, u32* buckets);
 template <class Fr>
 int launch_prep(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBuffers& b);
 

@@ -266,6 +266,66 @@ __global__ void __launch_bounds__(256)
   if (!pairs || !(lane & 1u)) xyzz_store<Fq>(buckets, b, acc);
 }
 
+// accumulate, bucket-split (k_prep_local_s): lane l of group gw sums part (l mod L) of bucket (64 gw + l) / L; after the
+// rows, log2 L exchanges add the parts and the first lane of every bucket stores it.  Same loop as k_accum_bpl.
+template <class Fq>
+__global__ void __launch_bounds__(256)
+    k_accum_bps(const u32* __restrict__ table, const u32* __restrict__ ents_t, const BplGroupHdr* __restrict__ grp, u32 n_groups,
+                u32 log2_l, const u32* __restrict__ flags, u32* __restrict__ buckets) {
+  __shared__ __attribute__((aligned(16))) u32 lds[2 * 4 * GatherLds<Fq>::WAVE_BYTES / 4];
+  if (flags[1]) return;  // the prep overflowed: the host reruns this MSM through the chunked pipeline
+  const u32 lane = threadIdx.x & 63u;
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32* lds_wave0 = lds + wave * (2 * GatherLds<Fq>::WAVE_BYTES / 4);
+  u32* lds_wave1 = lds_wave0 + GatherLds<Fq>::WAVE_BYTES / 4;
+  const u32 gw = blockIdx.x * 4u + wave;
+  if (gw >= n_groups) return;
+  const u32 base = __builtin_amdgcn_readfirstlane(grp[gw].base), m = __builtin_amdgcn_readfirstlane(grp[gw].m);
+  const u32* row = ents_t + base + lane;
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  if (m) {
+    u32 e0 = row[0];
+    u32 e1 = m > 1u ? row[64] : BPL_PAD;
+    u32 e2 = m > 2u ? row[128] : BPL_PAD;
+    gather_issue<Fq>(table, e0 & ENTRY_IDX, lds_wave0, lane);
+    gather_issue<Fq>(table, e1 & ENTRY_IDX, lds_wave1, lane);
+#pragma unroll 2
+    for (u32 k = 0; k < m; k++) {
+      const u32 e3_ld = row[(size_t)min(k + 3u, m - 1u) * 64u];  // always issued: the wait below counts it
+      const u32 e3 = k + 3u < m ? e3_ld : BPL_PAD;
+      u32* region = (k & 1u) ? lds_wave1 : lds_wave0;
+      if (GatherLds<Fq>::N_INSTR == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      Affine<Fq> pt = gather_read<Fq>(region, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      gather_issue<Fq>(table, e2 & ENTRY_IDX, region, lane);
+      if (!(e0 & BPL_PAD)) xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (e0 & ENTRY_NEG) != 0));
+      e0 = e1;
+      e1 = e2;
+      e2 = e3;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // the L parts of a bucket: butterfly over aligned groups of L lanes (both partners add in the same order)
+#pragma unroll 1
+  for (u32 w = (1u << log2_l) >> 1; w >= 1u; w >>= 1) {
+    XYZZ<Fq> o;
+#pragma unroll
+    for (int i = 0; i < Fq::L; i++) {
+      o.x.v[i] = __shfl_xor(acc.x.v[i], (int)w, 64);
+      o.y.v[i] = __shfl_xor(acc.y.v[i], (int)w, 64);
+      o.zz.v[i] = __shfl_xor(acc.zz.v[i], (int)w, 64);
+      o.zzz.v[i] = __shfl_xor(acc.zzz.v[i], (int)w, 64);
+    }
+    const bool lowl = (lane & w) == 0;
+    XYZZ<Fq> a = lowl ? acc : o;
+    XYZZ<Fq> b2 = lowl ? o : acc;
+    xyzz_add<Fq>(a, b2);
+    acc = a;
+  }
+  if ((lane & ((1u << log2_l) - 1u)) == 0u) xyzz_store<Fq>(buckets, (size_t)((gw * 64u + lane) >> log2_l), acc);
+}
+
 // Butterfly reduction of one XYZZ per lane over aligned groups of WIDTH lanes (WIDTH = 64: whole wave) with
 // __shfl_xor; every lane of a group ends with the group's sum.  All 64 lanes must be active.
 template <class Fq, int WIDTH>

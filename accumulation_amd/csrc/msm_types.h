@@ -41,7 +41,9 @@ struct MsmGeom {
                      // fall into the lowest 2^(that - 1) buckets -- a sixteenth of the partitions would receive a whole window.
                      // Its table level is 2^(c (W - 1) - s) G instead and its digit is shifted left by s: the same product, spread
                      // over every 2^s-th bucket of the whole range (raw digit <= 2^(c - 1 - s): never negative, no carry out)
-  u32 bpl;           // 1: bucket-per-lane pipeline (k_prep_local_t + k_accum_bpl; 20-bit windows), 0: chunked pipeline
+  u32 bpl;           // 1: bucket-per-lane pipeline (k_prep_local_t + k_accum_bpl; 20-bit windows), 2: bucket-split pipeline
+                     // (k_prep_local_s + k_accum_bps; small and medium MSMs), 0: chunked pipeline
+  u32 bps_log2_l;    // bucket-split: log2 of the lanes per bucket
   u32 red_s;         // buckets per reduce lane
   u32 red_threads;   // reduce lanes per set
 };

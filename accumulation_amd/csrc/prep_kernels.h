@@ -760,4 +760,92 @@ __global__ void __launch_bounds__(1024)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bucket-split layout for SMALL and MEDIUM MSMs (round 3; up to 2^19 pairs over a precomputed key, one or two bucket sets):
+// the chip has ~131 k lanes to fill and such an MSM only 2^12 .. 2^16 buckets of 30 .. 300 entries, so every bucket is cut
+// into L = 2^k parts (part r takes its entries r, r + L, ...: sizes differ by at most one) on L ADJACENT lanes of one wave;
+// k_accum_bps gives each lane its part -- a handful of mixed additions read as coalesced rows like k_accum_bpl's -- and adds
+// the L partial sums with log2 L lane exchanges.  Against the chunked pipeline this removes the partial records, accumulate
+// L1 / L2 and four dispatches from a chain that is latency-bound at these sizes (a 2^16-pair call: 0.40 ms, of which
+// accumulate L0 + L1 + L2 were 0.18).  A partition is 1024 / L consecutive buckets = 1024 lanes = 16 groups of 64; rows of a
+// group = the largest part in it; no size ordering (parts of one bucket are equal, buckets of one group similar on uniform
+// digits).  A skewed input makes one group long: if the padded block outgrows the partition's stride (or the partition its
+// LDS stage) the overflow flag sends the MSM to the chunked pipeline over the SAME key.
+// 32-bit interchange entries as in k_prep_local (negate | bucket low bits << IB | index).
+// dynamic LDS: (3 * NBP + 1024 + 2 * 16 + 2 + CAP) words, NBP = 2^SH = 1024 / L buckets per partition.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 BPS_LANES = 1024, BPS_GROUPS = BPS_LANES / BPL_GROUP;  // lane slots / 64-lane groups per partition
+__global__ void __launch_bounds__(1024)
+    k_prep_local_s(const u32* __restrict__ part_start, const u32* __restrict__ part, MsmGeom g, PrepGeom pg, u32 stride,
+                   u32 log2_l, u32* __restrict__ ents_t, BplGroup* __restrict__ grp, u32* __restrict__ err) {
+  extern __shared__ u32 prep_lds[];
+  const u32 NBP = 1u << pg.SH, L = 1u << log2_l, NG = BPS_GROUPS;
+  u32* cnt = prep_lds;        // entries per bucket
+  u32* cur = cnt + NBP;       // placement cursor
+  u32* beg = cur + NBP;       // first staged entry of the bucket
+  u32* sl = beg + NBP;        // 1024 scan words
+  u32* gm = sl + 1024;        // NG: rows per group
+  u32* gb = gm + NG;          // NG + 1
+  u32* stage = gb + NG + 2;   // CAP entries sorted by bucket
+  const u32 p = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  const u32 ps = part_start[p], pe = part_start[p + 1], n_p = pe - ps;
+  const u32 low = NBP - 1u, idx_mask = (1u << pg.IB) - 1u;
+  const bool fits = n_p <= pg.CAP;
+  for (u32 k = t; k < NBP; k += T) cnt[k] = 0;
+  for (u32 k = t; k < NG; k += T) gm[k] = 0;
+  __syncthreads();
+  if (fits)
+    for (u32 j = ps + t; j < pe; j += T) atomicAdd(&cnt[(part[j] >> pg.IB) & low], 1u);
+  __syncthreads();
+  const u32 c_t = t < NBP ? cnt[t] : 0u;
+  sl[t] = c_t;
+  __syncthreads();
+  for (u32 d = 1; d < T; d <<= 1) {
+    u32 v = t >= d ? sl[t - d] : 0u;
+    __syncthreads();
+    sl[t] += v;
+    __syncthreads();
+  }
+  if (t < NBP) {
+    beg[t] = sl[t] - c_t;
+    cur[t] = sl[t] - c_t;
+    // bucket t sits on lanes [t L, (t + 1) L): all in one group when L <= 64; its largest part has ceil(c / L) entries
+    atomicMax(&gm[(t << log2_l) / BPL_GROUP], (c_t + L - 1u) >> log2_l);
+  }
+  __syncthreads();
+  if (fits)
+    for (u32 j = ps + t; j < pe; j += T) {
+      const u32 e = part[j];
+      const u32 pos = atomicAdd(&cur[(e >> pg.IB) & low], 1u);
+      stage[pos] = (e & 0x80000000u) | entry_abs_index(g, e & idx_mask);
+    }
+  if (t == 0) {
+    u32 run = 0;
+    for (u32 q = 0; q < NG; q++) {
+      gb[q] = run;
+      run += gm[q] * BPL_GROUP;
+    }
+    gb[NG] = run;
+  }
+  __syncthreads();
+  const u32 total = gb[NG];
+  const bool ok = fits && total <= stride;
+  if (!ok && t == 0) atomicOr(err + 1, 1u);
+  if (t < NG) {
+    BplGroup h;
+    h.base = p * stride + gb[t];
+    h.m = ok ? gm[t] : 0u;
+    grp[p * NG + t] = h;
+  }
+  if (!ok) return;
+  for (u32 j = t; j < total; j += T) {
+    u32 q = 0;
+    while (q + 1u < NG && gb[q + 1u] <= j) q++;
+    const u32 k = (j - gb[q]) / BPL_GROUP, l = j % BPL_GROUP;
+    const u32 lane = q * BPL_GROUP + l, kb = lane >> log2_l, r = lane & (L - 1u);
+    const u32 i = (k << log2_l) + r;  // entry i of bucket kb belongs to part i mod L
+    ents_t[(size_t)p * stride + j] = i < cnt[kb] ? stage[beg[kb] + i] : BPL_ENTRY_PAD;
+  }
+}
+
 }  // namespace amsm

@@ -94,7 +94,9 @@ class Context:
         """MSMs that took the bucket-per-lane pipeline / that fell back to the chunked one (amsm_ctx_pipeline_stats)"""
         a, b = C.c_ulonglong(), C.c_ulonglong()
         ffi.check(self._lib.amsm_ctx_pipeline_stats(self._h, C.byref(a), C.byref(b)), "amsm_ctx_pipeline_stats")
-        return {"bucket_per_lane": a.value, "fallbacks": b.value}
+        c, d = C.c_ulonglong(), C.c_ulonglong()
+        ffi.check(self._lib.amsm_ctx_pipeline_stats_small(self._h, C.byref(c), C.byref(d)), "amsm_ctx_pipeline_stats_small")
+        return {"bucket_per_lane": a.value, "fallbacks": b.value, "bucket_split": c.value, "bucket_split_fallbacks": d.value}
 
     def trim(self):
         """Release the MSM workspace and every cached buffer (amsm_ctx_trim); live vectors and keys stay."""

@@ -110,6 +110,10 @@ unsigned long long amsm_ctx_collectives(const amsm_ctx* ctx);
  * a window: constant vectors) and were re-run through the chunked pipeline over the key's 17-bit-window twin,
  * which is built on the first such call.  Results do not depend on the path.  Either pointer may be NULL. */
 int amsm_ctx_pipeline_stats(const amsm_ctx* ctx, unsigned long long* n_bucket_per_lane, unsigned long long* n_fallbacks);
+/* The same counters for the bucket-split pipeline that MSMs of 2^13 .. 2^19 pairs over a precomputed key take (every bucket on
+ * 2 .. 64 adjacent lanes, no partial records): enqueued / re-run through the chunked pipeline over the same key because the
+ * scalars were skewed. */
+int amsm_ctx_pipeline_stats_small(const amsm_ctx* ctx, unsigned long long* n_bucket_split, unsigned long long* n_fallbacks);
 void amsm_ctx_destroy(amsm_ctx* ctx);
 int amsm_ctx_curve(const amsm_ctx* ctx);
 /* limbs (u64) of a base-field element: 4 (Pallas) or 6 (BLS12-381). */
