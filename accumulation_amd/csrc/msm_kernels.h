@@ -583,20 +583,23 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)set * gridDim.x + blockIdx.x, total);
 }
 template <class Fq>
-__global__ void __launch_bounds__(64) k_fold_quad(const u32* __restrict__ in, u32 n, u32* __restrict__ out,
-                                                  const u32* __restrict__ flags) {
+__global__ void __launch_bounds__(256) k_fold_quad(const u32* __restrict__ in, u32 n, u32* __restrict__ out,
+                                                   const u32* __restrict__ flags) {
+  // round 3: four waves (64 quads) instead of one -- the serial part of the fold drops from n / 16 to n / 64 additions per
+  // quad (n = 256 partial records after the reduction of a 2^19-bucket set), then the quad butterfly and one LDS step
+  __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   {
-    const u32 k0 = threadIdx.x >> 2;  // 16 quads
+    const u32 k0 = threadIdx.x >> 2, nq = blockDim.x >> 2;
     XYZZ<Fq> p = k0 < n ? xyzz_load<Fq>(in, (size_t)blockIdx.x * n + k0) : acc;
-    for (u32 k = k0; k < n; k += 16) {
+    for (u32 k = k0; k < n; k += nq) {
       XYZZ<Fq> nx = p;
-      if (k + 16 < n) nx = xyzz_load<Fq>(in, (size_t)blockIdx.x * n + k + 16);
+      if (k + nq < n) nx = xyzz_load<Fq>(in, (size_t)blockIdx.x * n + k + nq);
       xyzz_add_quad<Fq>(acc, p);
       p = nx;
     }
   }
-  wave_reduce_xyzz_quad<Fq>(acc);
+  block_reduce_xyzz_quad<Fq>(acc, lds);
   if (threadIdx.x == 0) {
     XYZZ<Fq> e;
     e.x = fe_export<Fq>(acc.x);
