@@ -54,6 +54,33 @@ struct Bls12381FqU {  // 14 x 28 bits, R' = 2^392 ~ 2520 p: measured against the
   AMSM_TABLE(k_export, 14, 0x0002fffdu, 0x00900000u, 0x0c000276u, 0x0000bc40u, 0x08baebf4u, 0x05753c75u, 0x055f4898u, 0x07052574u, 0x07ce5853u, 0x056ec6d7u, 0x071a97a2u, 0x0e4935c0u, 0x0ec3fa80u, 0x00015f65u)
 };
 
+// Round 3: the two SCALAR fields on 9 x 29 limbs for the arbitrary-coefficient linear combination (vec_kernels.h).  Memory stays what ark-ff defines (8
+// words, Montgomery radix R = 2^256): a multiplication here divides by 2^261, so every product carries a factor 1/32 -- which the
+// launcher absorbs into the (uniform) coefficients on the host.
+// Both moduli are 1 mod 2^29 (constant-add reduction step); Pallas' has the 2^22 top limb as well.
+struct PallasFr;
+struct PallasFrU {
+  using Sat = PallasFr;
+  static constexpr int L = 9;
+  static constexpr int W = 8;
+  static constexpr int B = 29;
+  static constexpr bool UNSAT = true;
+  static constexpr u32 NINV = 0x1fffffffu;
+  static constexpr bool CHAIN = true;
+  AMSM_TABLE(mod, 9, 0x00000001u, 0x02375908u, 0x052a3763u, 0x0d31f813u, 0x00000224u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00400000u)
+};
+struct Bls12381Fr;
+struct Bls12381FrU {
+  using Sat = Bls12381Fr;
+  static constexpr int L = 9;
+  static constexpr int W = 8;
+  static constexpr int B = 29;
+  static constexpr bool UNSAT = true;
+  static constexpr u32 NINV = 0x1fffffffu;
+  static constexpr bool CHAIN = false;
+  AMSM_TABLE(mod, 9, 0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u)
+};
+
 template <class P>
 AMSM_HD constexpr u32 u_mask() {
   return (1u << P::B) - 1u;
@@ -259,6 +286,38 @@ AMSM_DEV Fe<P> u_mul_add_mul(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, con
       }
     }
   });
+  return r;
+}
+
+// sum_{t < K} a[t] b[t] / 2^(B*L) mod p with ONE reduction (K <= 4 products of tight operands: 4 * 9 * 2^58 plus the reduction
+// terms stay below 2^64 per column).  Gives: tight, value < p + sum a[t] b[t] / 2^(B*L).
+template <class P, int K>
+AMSM_DEV Fe<P> u_dot(const Fe<P>* a, const Fe<P>* b) {
+  static_assert(K >= 1 && K <= 4, "column accumulators hold four products");
+  constexpr int L = P::L;
+  u64 acc = 0;
+  u32 m[L];
+  Fe<P> r;
+  u_columns<P, 0>(acc, m, r, nullptr, false, [&](u64& ac, int k) {
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+#pragma unroll
+      for (int i = 0; i < L; i++) {
+        int j = k - i;
+        if (j >= 0 && j < L) ac += (u64)a[t].v[i] * b[t].v[j];
+      }
+    }
+  });
+  return r;
+}
+
+// limb-wise a + b (both tight, sum < 2^(B*L)): tight
+template <class P>
+AMSM_DEV Fe<P> u_add(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.v[i] = a.v[i] + b.v[i];
+  u_carry<P>(r);
   return r;
 }
 

@@ -211,6 +211,52 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
                      make_uint4(v[4], v[5], v[6], v[7]), n);
 }
 
+// ---- host-side coefficient preparation for the 9 x 29-limb vector kernels (vec_kernels.h, round 3) ----
+static bool vec_sat() {  // AMSM_VEC_SAT=1: round 2's kernels on the generated 8 x 32 multiplier (A/B)
+  static const bool on = [] {
+    const char* e = getenv("AMSM_VEC_SAT");
+    return e && atoi(e) != 0;
+  }();
+  return on;
+}
+template <class Fr>
+static void fr_times_pow2(const u32 in[8], int k, u32 out[8]) {  // in * 2^k mod r (in < r)
+  u32 v[8];
+  memcpy(v, in, 32);
+  for (int t = 0; t < k; t++) {
+    u32 carry = 0;
+    for (int i = 0; i < 8; i++) {
+      const u32 nv = (v[i] << 1) | carry;
+      carry = v[i] >> 31;
+      v[i] = nv;
+    }
+    bool ge = carry != 0;
+    if (!ge) {
+      ge = true;
+      for (int i = 7; i >= 0; i--)
+        if (v[i] != Fr::mod(i)) {
+          ge = v[i] > Fr::mod(i);
+          break;
+        }
+    }
+    if (ge) {
+      u64 borrow = 0;
+      for (int i = 0; i < 8; i++) {
+        const u64 d = (u64)v[i] - Fr::mod(i) - borrow;
+        v[i] = (u32)d;
+        borrow = (d >> 63) & 1u;
+      }
+    }
+  }
+  memcpy(out, v, 32);
+}
+template <class Fr>
+static bool fr_is_one(const u32 c[8]) {
+  for (int i = 0; i < 8; i++)
+    if (c[i] != Fr::one(i)) return false;
+  return true;
+}
+
 #define AMSM_FR_LAUNCHERS(FR)                                                                                        \
   template <>                                                                                                        \
   int launch_prep<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBuffers& b) {               \
@@ -367,8 +413,24 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
     hipLaunchKernelGGL((k_vec_hadamard<FR>), dim3(stream_grid(n)), dim3(256), 0, st, a, b, out, n);                  \
   }                                                                                                                  \
   template <>                                                                                                        \
-  void launch_vec_combine<FR>(hipStream_t st, const CombineArgs& a, u32* out) {                                      \
-    dim3 grid(stream_grid(a.n)), block(256);                                                                         \
+  void launch_vec_combine<FR>(hipStream_t st, const CombineArgs& a_in, u32* out) {                                   \
+    dim3 grid(stream_grid(a_in.n)), block(256);                                                                      \
+    CombineArgs a = a_in;                                                                                            \
+    const bool f1 = a.n_vecs >= 1 && fr_is_one<FR>(a.coeff[0]);                                                      \
+    if (!vec_sat() && !f1 && a.n_vecs >= 1) { /* see vec_kernels.h: wins only without a unit first coefficient */    \
+      for (u32 j = 0; j < a.n_vecs && j < (u32)VEC_MAX; j++) fr_times_pow2<FR>(a.coeff[j], 5, a.coeff_u[j]);         \
+      switch (a.n_vecs) {                                                                                            \
+        case 1: hipLaunchKernelGGL((k_vec_combine_u<FR, 1>), grid, block, 0, st, a, out); break;                     \
+        case 2: hipLaunchKernelGGL((k_vec_combine_u<FR, 2>), grid, block, 0, st, a, out); break;                     \
+        case 3: hipLaunchKernelGGL((k_vec_combine_u<FR, 3>), grid, block, 0, st, a, out); break;                     \
+        case 4: hipLaunchKernelGGL((k_vec_combine_u<FR, 4>), grid, block, 0, st, a, out); break;                     \
+        case 5: hipLaunchKernelGGL((k_vec_combine_u<FR, 5>), grid, block, 0, st, a, out); break;                     \
+        case 6: hipLaunchKernelGGL((k_vec_combine_u<FR, 6>), grid, block, 0, st, a, out); break;                     \
+        case 7: hipLaunchKernelGGL((k_vec_combine_u<FR, 7>), grid, block, 0, st, a, out); break;                     \
+        default: hipLaunchKernelGGL((k_vec_combine_u<FR, 8>), grid, block, 0, st, a, out); break;                    \
+      }                                                                                                              \
+      return;                                                                                                        \
+    }                                                                                                                \
     switch (a.n_vecs) {                                                                                              \
       case 0: /* only the hiding addend */                                                                          \
       case 1: hipLaunchKernelGGL((k_vec_combine<FR, 1>), grid, block, 0, st, a, out); break;                         \
@@ -431,8 +493,9 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
                        witness, n_witness, out, n_rows);                                                             \
   }                                                                                                                  \
   template <>                                                                                                        \
-  void launch_hp_t_vecs<FR>(hipStream_t st, const TVecArgs& a, int n_inputs) {                                       \
-    dim3 grid(stream_grid(a.len)), block(256);                                                                       \
+  void launch_hp_t_vecs<FR>(hipStream_t st, const TVecArgs& a_in, int n_inputs) {                                    \
+    dim3 grid(stream_grid(a_in.len)), block(256);                                                                    \
+    const TVecArgs& a = a_in;                                                                                        \
     switch (n_inputs) {                                                                                              \
       case 1: hipLaunchKernelGGL((k_hp_t_vecs<FR, 1>), grid, block, 0, st, a); break;                                \
       case 2: hipLaunchKernelGGL((k_hp_t_vecs<FR, 2>), grid, block, 0, st, a); break;                                \

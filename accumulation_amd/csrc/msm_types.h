@@ -65,6 +65,9 @@ struct CombineArgs {
   const u32* vec[VEC_MAX];
   u32 len[VEC_MAX];
   u32 coeff[VEC_MAX][8];
+  // filled by the launcher for the 9 x 29-limb kernel (vec_kernels.h): coefficient * 32 mod r (a product there divides by 2^261
+  // instead of 2^256)
+  u32 coeff_u[VEC_MAX][8];
   const u32* hiding;
   u32 hiding_len;
   u32 n_vecs;

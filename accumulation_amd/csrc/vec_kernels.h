@@ -182,6 +182,94 @@ __global__ void __launch_bounds__(256) k_hp_t_vecs(TVecArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 3: the linear combination with ARBITRARY coefficients on the unsaturated 9 x 29-limb multiplier (fpu.h: PallasFrU /
+// Bls12381FrU; constant-add reduction step, one MAD per limb product, no carries) with the sum of products reduced ONCE (u_dot:
+// up to four products per Montgomery reduction).  Memory keeps ark-ff's format (Montgomery radix 2^256): a product here divides
+// by 2^261, so it carries a factor 1/32, which the launcher folds into the uniform coefficients with host field arithmetic.
+// Bounds (cap = 2^261 > 70 r): canonical operands < r; a product of A and B is < r + A B / 2^261; what is stored is
+// canonicalised from < 8 r.  Measured at 2^22 elements (profiles/r03_vec_unsat_ab.md): n = 2 0.53 -> 0.60 of 8 TB/s, n = 3
+// 0.49 -> 0.63.  The same treatment LOST for the Hadamard product (0.80 -> 0.785), for combinations whose first coefficient is
+// one (0.775 -> 0.70 at n = 2: one product left, nothing to share) and for compute_t_vecs (register pressure: 0.49 -> 0.43 with
+// the prefetch, 0.49 without), so those stay on the generated 8 x 32 schedule.  AMSM_VEC_SAT=1 puts everything there (A/B).
+// ---------------------------------------------------------------------------------------------
+template <class Fr>
+struct FrUnsat;
+template <>
+struct FrUnsat<PallasFr> {
+  using type = PallasFrU;
+};
+template <>
+struct FrUnsat<Bls12381Fr> {
+  using type = Bls12381FrU;
+};
+template <class U>
+AMSM_DEV Fe<U> fru_load(const u32* __restrict__ p) {  // canonical Montgomery element (8 words) -> 9 tight limbs
+  Fe<typename U::Sat> w = fe_load<typename U::Sat>(p);
+  return u_unpack<U>(w.v);
+}
+template <class U>
+AMSM_DEV Fe<U> fru_zero() {
+  Fe<U> r;
+#pragma unroll
+  for (int i = 0; i < U::L; i++) r.v[i] = 0;
+  return r;
+}
+template <class U>
+AMSM_DEV Fe<U> fru_arg(const u32 c[8]) {  // a kernel-argument element
+  return u_unpack<U>(c);
+}
+template <class U, u32 KMAX, bool NT>
+AMSM_DEV void fru_store(u32* __restrict__ p, Fe<U> a) {  // a tight, value < KMAX * r
+  u_canon<U, KMAX>(a);
+  Fe<typename U::Sat> w;
+  u_pack<U>(a, w.v);
+  if (NT) fe_store_nt<typename U::Sat>(p, w);
+  else fe_store<typename U::Sat>(p, w);
+}
+
+// sum_{t < NP} pa[t] pb[t] / 2^261, four products per reduction; NP compile time.  Each group is < r + (sum A B) / 2^261.
+template <class U, int NP, int G = 0>
+AMSM_DEV void fru_dot_acc(Fe<U>& acc, const Fe<U>* pa, const Fe<U>* pb) {
+  if constexpr (G < NP) {
+    constexpr int K = NP - G < 4 ? NP - G : 4;
+    acc = u_add<U>(acc, u_dot<U, K>(pa + G, pb + G));
+    fru_dot_acc<U, NP, G + 4>(acc, pa, pb);
+  }
+}
+
+template <class Fr, int NV>
+__global__ void __launch_bounds__(256) k_vec_combine_u(CombineArgs a, u32* __restrict__ out) {
+  using U = typename FrUnsat<Fr>::type;
+  const u32 stride = gridDim.x * blockDim.x;
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  auto load = [&](u32 e, Fe<U>* x, Fe<U>& h) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) x[j] = e < a.len[j] ? fru_load<U>(a.vec[j] + (size_t)e * 8) : fru_zero<U>();
+    h = (a.hiding && e < a.hiding_len) ? fru_load<U>(a.hiding + (size_t)e * 8) : fru_zero<U>();
+  };
+  Fe<U> cf[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) cf[j] = fru_arg<U>(a.coeff_u[j]);  // 32 c_j mod r
+  Fe<U> x[NV], acc;
+  load(i, x, acc);
+  for (;;) {
+    const u32 nx = i + stride;
+    const bool more = nx < a.n;
+    Fe<U> x2[NV], h2;
+    if (more) load(nx, x2, h2);
+    fru_dot_acc<U, NV>(acc, cf, x);                                            // hiding + two reduced sums at most  [< 4.2 r]
+    if (a.hiding == out) fru_store<U, 8, false>(out + (size_t)i * 8, acc);    // (in-place chunked combination re-reads `out`)
+    else fru_store<U, 8, true>(out + (size_t)i * 8, acc);
+    if (!more) break;
+#pragma unroll
+    for (int j = 0; j < NV; j++) x[j] = x2[j];
+    acc = h2;
+    i = nx;
+  }
+}
+
 // Row-sparse R1CS matrix times (input || witness): `matrix_vec_mul` / `inner_prod`,
 // src/r1cs_nark_as/r1cs_nark/mod.rs:443-462 (K7).  CSR in HBM: row_ptr (rows+1), col (nnz), val (nnz x 8 u32,
 // Montgomery).  One lane per row; the reference's "skip the multiplication when the coefficient is one"

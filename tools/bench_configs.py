@@ -181,6 +181,17 @@ def bench_vec(log2n):
     t = timed(ctx, lambda: compute_t_vecs(ctx, a, b, ch1, n, None, skip_uncommitted=True))
     emit(kind="vec", op="compute_t_vecs(n=2, mu = 1, x as in prove)", log2n=log2n, ms=t * 1e3, GBps=192 * n / t / 1e9,
          frac_hbm=192 * n / t / 1e9 / HBM, multiplications_per_element=3)
+    # the reference harness's shape (examples/scaling-as.rs:91-104): one input + two old accumulators = three (a, b) pairs
+    a3 = a + [ctx.random_vector(12, n, mont=True)]
+    b3 = b + [ctx.random_vector(22, n, mont=True)]
+    for label, chs, mults_c, mults_t in (("arbitrary", [3, 5, 7], 3, 12), ("mu_0 = 1 as in prove", [1, 5, 7], 2, 11)):
+        c3 = fr.to_limbs_many(chs)
+        t = timed(ctx, lambda: combine_vectors(ctx, a3, c3))
+        emit(kind="vec", op=f"combine_vectors(n=3, {label})", log2n=log2n, ms=t * 1e3, GBps=128 * n / t / 1e9,
+             frac_hbm=128 * n / t / 1e9 / HBM, multiplications_per_element=mults_c)
+        t = timed(ctx, lambda: compute_t_vecs(ctx, a3, b3, c3, n, None, skip_uncommitted=True))
+        emit(kind="vec", op=f"compute_t_vecs(n=3, 6 in / 4 out, {label})", log2n=log2n, ms=t * 1e3, GBps=320 * n / t / 1e9,
+             frac_hbm=320 * n / t / 1e9 / HBM, multiplications_per_element=mults_t)
     ctx.close()
 
 
@@ -277,7 +288,7 @@ def bench_hp_as(log2n, reps=3, zk=False, constant_vectors=False):
 
 if __name__ == "__main__":
     quick = "--quick" in sys.argv
-    only_vec = "--vec" in sys.argv
+    only_vec = "--vec" in sys.argv or "--vec-only" in sys.argv
     if not only_vec:
         bench_msm(ffi.AMSM_PALLAS, 16)
         bench_msm(ffi.AMSM_PALLAS, 18)
@@ -286,6 +297,8 @@ if __name__ == "__main__":
         if not quick:
             bench_msm(ffi.AMSM_PALLAS, 22, reps=6)
     bench_vec(20 if quick else 22)
+    if "--vec-only" in sys.argv:
+        sys.exit(0)
     bench_hp_as(18 if quick else 22)
     bench_hp_as(18 if quick else 22, constant_vectors=True)
     bench_hp_as(18 if quick else 22, zk=True)
