@@ -472,4 +472,36 @@ inline HXYZZ<P> hx_from_device(const u32* rec) {
 }
 
 }  // namespace host
+
+// generator coordinates in Montgomery form (computed from canonical constants at first use)
+template <class Fq>
+std::vector<u32> generator_mont(int curve) {
+  using H = host::HFe<Fq>;
+  H gx = host::h_zero<Fq>(), gy = host::h_zero<Fq>();
+  if (curve == 0 /* AMSM_PALLAS */) {
+    // (-1, 2)
+    H one = host::h_zero<Fq>();
+    one.v[0] = 1;
+    H two = host::h_zero<Fq>();
+    two.v[0] = 2;
+    gx = host::h_neg<Fq>(host::h_to_mont<Fq>(one));
+    gy = host::h_to_mont<Fq>(two);
+  } else {
+    static const u64 X[6] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull,
+                             0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull};
+    static const u64 Y[6] = {0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull,
+                             0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+    for (int i = 0; i < H::N && i < 6; i++) {
+      gx.v[i] = X[i];
+      gy.v[i] = Y[i];
+    }
+    gx = host::h_to_mont<Fq>(gx);
+    gy = host::h_to_mont<Fq>(gy);
+  }
+  std::vector<u32> g(2 * Fq::L);
+  memcpy(g.data(), gx.v, 4 * Fq::L);
+  memcpy(g.data() + Fq::L, gy.v, 4 * Fq::L);
+  return g;
+}
+
 }  // namespace amsm

@@ -63,6 +63,12 @@ template <class Fq>
 void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const u32 x_canon[8], u32 nbits, u32* out,
                         bool abi_radix, u32* xyzz_scratch);
 
+// Fold of a key that carries window multiples (table level w at w * stride points, = 2^(c w) G; levels 0 .. levels-1 usable):
+// out[i] = table[i] + x * table[n + i], i < n.  False (nothing launched) when x does not fit the usable levels.
+template <class Fq>
+bool launch_points_fold_tab(hipStream_t st, const u32* table, u32 stride, u32 c, u32 levels, u32 n, const u32 x_canon[8],
+                            u32 nbits, u32* out, u32* xyzz_scratch);
+
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>
 void launch_digits(hipStream_t st, const u32* scalars, int mont, MsmGeom g, void* keys, bool keys16, u32* vals, u32* err);

@@ -684,27 +684,36 @@ __global__ void __launch_bounds__(256)
 // out[i] = l[i] + x * r[i] for affine point vectors (the commitment-key fold `key_l += key_r * xi` of the IPA
 // opening, ark_poly_commit::ipa_pc ext, under src/ipa_pc_as/mod.rs:454): one lane per point, left-to-right
 // double-and-add over the `nbits` low bits of the canonical scalar x, then one inversion back to affine.
-struct Scalar256 {  // canonical scalar as a kernel argument
-  u32 w[8];
+struct FoldDigits {  // the scalar as kernel-argument digit masks (uniform over the grid), recoded once on the host
+  // plain form: x in non-adjacent form (digits +1 / -1 / 0, a third non-zero) in pos1 / neg1, up to 256 digits.
+  // GLV form (host_glv.h): x = k1 + k2 lambda, |k_i| ~ 2^128: NAF(k1) in pos1 / neg1, NAF(k2) in pos2 / neg2 (signs folded
+  // in), and beta (C-ABI Montgomery words) with phi(x, y) = (beta x, y) = [lambda](x, y): half the doublings.
+  u32 pos1[8], neg1[8], pos2[5], neg2[5];
+  u32 nd;         // digit positions to run
+  u32 beta[12];   // W words used
 };
 // ABI = true: l, r, out are caller-visible device buffers (C-ABI Montgomery radix in and out); false: key tables
 // (device radix, amsm_bases_fold)
 // XYZZ_OUT: leave the sums unconverted in out (XYZZ records, internal radix) for k_batch_to_affine.
-template <class Fq, bool ABI, bool XYZZ_OUT>
+template <class Fq, bool ABI, bool XYZZ_OUT, bool GLV>
 __global__ void __launch_bounds__(256)
-    k_points_fold(const u32* __restrict__ l, const u32* __restrict__ r, u32 n, Scalar256 pos, Scalar256 neg, u32 ndigits,
-                  u32* __restrict__ out) {
-  // x in non-adjacent form (digits +1 / -1 / 0, a third non-zero: the host recodes it once, the digits are uniform
-  // over the grid): ndigits doublings and ~ndigits/3 mixed additions of +-r[i] instead of ndigits/2
+    k_points_fold(const u32* __restrict__ l, const u32* __restrict__ r, u32 n, FoldDigits d, u32* __restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<Fq> pr = affine_load<Fq>(r, i);
   if (ABI) pr = affine_import<Fq>(pr);
+  Affine<Fq> pr2 = pr;
+  if (GLV) pr2.x = fe_mul<Fq>(fe_import<Fq>(fe_from_words<Fq>(d.beta)), pr.x);  // phi(r_i); (0, 0) stays (0, 0)   [< 1.1p]
   XYZZ<Fq> acc = xyzz_inf<Fq>();
-  for (int bit = (int)ndigits - 1; bit >= 0; bit--) {
+  for (int bit = (int)d.nd - 1; bit >= 0; bit--) {
     acc = xyzz_dbl<Fq>(acc);
-    bool p = (pos.w[bit >> 5] >> (bit & 31)) & 1u, m = (neg.w[bit >> 5] >> (bit & 31)) & 1u;
-    if (p | m) xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pr, m));
+    const u32 w = (u32)bit >> 5, sh = (u32)bit & 31u;
+    const bool p1 = (d.pos1[w] >> sh) & 1u, m1 = (d.neg1[w] >> sh) & 1u;
+    if (p1 | m1) xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pr, m1));
+    if (GLV) {
+      const bool p2 = (d.pos2[w] >> sh) & 1u, m2 = (d.neg2[w] >> sh) & 1u;
+      if (p2 | m2) xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pr2, m2));
+    }
   }
   Affine<Fq> pl = affine_load<Fq>(l, i);
   if (ABI) pl = affine_import<Fq>(pl);
@@ -716,6 +725,44 @@ __global__ void __launch_bounds__(256)
   Affine<Fq> res = xyzz_to_affine<Fq>(acc);
   if (ABI) res = affine_export<Fq>(res);
   affine_store<Fq>(out, i, res);
+}
+
+// The same fold over a key that carries its window multiples (level w = 2^(c w) G, the precomputed table of the MSM): with
+// x = sum_w x_w 2^(c w), x r_i = sum_w x_w T_w[r_i] is a joint ladder of c + 1 doublings instead of `nbits` -- the additions
+// (one per non-zero NAF digit of every x_w) stay what they were.  A 128-bit challenge over 17-bit windows: 18 doublings + ~45
+// mixed additions instead of 128 + ~43 (the first fold of an IPA opening, which is half of all its fold work, always runs over
+// the original key).  The host flattens the digits into one list of additions, most significant position first; they are
+// uniform over the grid, so the next table row is requested while the current addition runs.
+struct FoldTabOps {
+  uint16_t op[160];  // bits 0..4: digit position, 5..9: level, 15: negate
+  u32 n_ops, nd;
+};
+template <class Fq, bool XYZZ_OUT>
+__global__ void __launch_bounds__(256)
+    k_points_fold_tab(const u32* __restrict__ table, u32 stride, u32 n, FoldTabOps d, u32* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 r_i = n + i;  // r half of the key: generators [n, 2n)
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  u32 k = 0;
+  Affine<Fq> nx = affine_load<Fq>(table, i);  // (the l point when there is nothing to add)
+  if (d.n_ops) nx = affine_load<Fq>(table, (size_t)((d.op[0] >> 5) & 31u) * stride + r_i);
+  for (int bit = (int)d.nd - 1; bit >= 0; bit--) {
+    acc = xyzz_dbl<Fq>(acc);
+    while (k < d.n_ops && (int)(d.op[k] & 31u) == bit) {
+      const Affine<Fq> cur = nx;
+      const bool neg = (d.op[k] >> 15) & 1u;
+      k++;
+      nx = k < d.n_ops ? affine_load<Fq>(table, (size_t)((d.op[k] >> 5) & 31u) * stride + r_i) : affine_load<Fq>(table, i);
+      xyzz_madd<Fq>(acc, affine_neg_if<Fq>(cur, neg));
+    }
+  }
+  xyzz_madd<Fq>(acc, nx);  // + l_i
+  if (XYZZ_OUT) {
+    xyzz_store<Fq>(out, i, acc);
+    return;
+  }
+  affine_store<Fq>(out, i, xyzz_to_affine<Fq>(acc));
 }
 
 // is_inf bytes -> (0,0) encoding on device
