@@ -201,6 +201,15 @@ struct amsm_ctx {
   hipEvent_t up_ev[STAGE_RING] = {};
   hipStream_t s_copy = nullptr;
   DevBuf xyzz_scratch;  // unconverted sums of large key folds / precompute levels (launch.h: batch_affine_pays)
+  // two-valued device vectors (api_pipeline.inc: msm_two_valued_pass): every scalar is 0 or one value v -> v * (sum of the
+  // generators with a non-zero scalar), on its own stream beside the batch's other MSMs.  AMSM_TWO_VALUED=0 turns it off.
+  int two_valued = 1;
+  DevBuf tv_flags, tv_parts, tv_out;
+  void* tv_pinned = nullptr;
+  size_t tv_pinned_bytes = 0;
+  hipStream_t s_tv = nullptr;
+  hipEvent_t tv_done = nullptr;
+  unsigned long long n_two_valued = 0;
   // ---- multi-device (amsm_ctx_create_multi) ----
   // shard_ctx[0] == this (the primary); shard_ctx[g >= 1] are owned single-device contexts, each served by one host
   // worker thread so that the blocking single-device pipeline runs on all devices at once.

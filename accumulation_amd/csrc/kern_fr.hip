@@ -257,6 +257,11 @@ static bool fr_is_one(const u32 c[8]) {
   return true;
 }
 
+void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
+  const u32 blocks = std::max(1u, std::min(512u, (n + 1023u) / 1024u));
+  hipLaunchKernelGGL(k_tv_probe, dim3(blocks), dim3(256), 0, st, scalars, n, out16);
+}
+
 #define AMSM_FR_LAUNCHERS(FR)                                                                                        \
   template <>                                                                                                        \
   int launch_prep<FR>(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBuffers& b) {               \

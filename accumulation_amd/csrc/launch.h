@@ -69,6 +69,12 @@ template <class Fq>
 bool launch_points_fold_tab(hipStream_t st, const u32* table, u32 stride, u32 c, u32 levels, u32 n, const u32 x_canon[8],
                             u32 nbits, u32* out, u32* xyzz_scratch);
 
+// two-valued vectors (vec_kernels.h k_tv_probe, msm_kernels.h k_tv_sum): exact probe into out[16] (out[0] pre-zeroed), and the
+// sum of the generators with non-zero scalars as `blocks` partial records
+void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16);
+template <class Fq>
+void launch_tv_sum(hipStream_t st, const u32* table, u32 base_off, const u32* scalars, u32 n, u32 blocks, u32* parts);
+
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>
 void launch_digits(hipStream_t st, const u32* scalars, int mont, MsmGeom g, void* keys, bool keys16, u32* vals, u32* err);

@@ -523,6 +523,57 @@ __global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ sca
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two-valued vectors: is every scalar of the vector 0 or ONE other value v?  (ark-ec's multi_scalar_mul adds the bases of unit
+// scalars directly and skips zero ones -- SURVEY.md App. C; the reference's own harnesses go further: hp_as inputs are
+// `vec![rand; n]` (src/hp_as/mod.rs:189-190) and the DummyCircuit's A z, B z, C z are one value per row plus a zero row
+// (src/r1cs_nark_as/mod.rs:1159-1188), boolean witnesses are {0, 1}.)  Then sum s_i G_i = v * sum_{s_i != 0} G_i: n mixed
+// additions and one scalar multiplication instead of n windows' worth (k_tv_sum, msm_kernels.h).
+// EXACT test, not a sample: v = the first non-zero scalar among the first TV_HEAD; every lane compares its scalars with 0 and
+// v and raises out[0] on the first that is neither -- a uniform vector ends the kernel after one load per lane.
+// out: [0] mismatch (pre-zeroed by the caller), [1] a non-zero head scalar exists, [8..15] v as stored.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 TV_HEAD = 1024;
+__global__ void __launch_bounds__(256) k_tv_probe(const u32* __restrict__ scalars, u32 n, u32* __restrict__ out) {
+  __shared__ u32 first;
+  __shared__ u32 vw[8];
+  const u32 t = threadIdx.x;
+  if (t == 0) first = 0xffffffffu;
+  __syncthreads();
+  const uint4* s4 = (const uint4*)scalars;
+  for (u32 i = t; i < TV_HEAD && i < n; i += 256) {
+    const uint4 a = s4[2 * (size_t)i], b = s4[2 * (size_t)i + 1];
+    if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u) {
+      atomicMin(&first, i);
+      break;  // this lane's later candidates have larger indices
+    }
+  }
+  __syncthreads();
+  const u32 f = first;
+  if (f == 0xffffffffu) {  // head all zero: not handled here (the regular pipeline skips zero digits anyway)
+    if (blockIdx.x == 0 && t == 0) out[0] = 1u;
+    return;
+  }
+  if (t < 8) vw[t] = scalars[(size_t)f * 8 + t];
+  __syncthreads();
+  const uint4 va = make_uint4(vw[0], vw[1], vw[2], vw[3]), vb = make_uint4(vw[4], vw[5], vw[6], vw[7]);
+  if (blockIdx.x == 0 && t < 8) out[8 + t] = vw[t];
+  if (blockIdx.x == 0 && t == 0) out[1] = 1u;
+  const u32 stride = gridDim.x * 256u;
+  volatile u32* bad = out;
+  for (u32 i = blockIdx.x * 256u + t; i < n; i += stride) {
+    const uint4 a = s4[2 * (size_t)i], b = s4[2 * (size_t)i + 1];
+    const bool zero = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0u;
+    const bool same = a.x == va.x && a.y == va.y && a.z == va.z && a.w == va.w && b.x == vb.x && b.y == vb.y && b.z == vb.z &&
+                      b.w == vb.w;
+    if (!zero && !same) {
+      out[0] = 1u;
+      return;
+    }
+    if (*bad) return;  // some lane found a third value: nothing left to learn
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // digits: scalar -> W signed digits -> (key, value) entries, window-major (entry w*n + i).
 // Reads are 2 x dwordx4 per lane, coalesced; writes are coalesced per window.
 // ---------------------------------------------------------------------------------------------

@@ -90,6 +90,10 @@ class Context:
         ffi.check(self._lib.amsm_ctx_memory(self._h, C.byref(ws), C.byref(live), C.byref(pooled)), "amsm_ctx_memory")
         return {"workspace_bytes": ws.value, "vectors_live_bytes": live.value, "vectors_pooled_bytes": pooled.value}
 
+    def two_valued_msms(self) -> int:
+        """MSMs of device vectors that took the two-valued form (every scalar 0 or one value v) so far"""
+        return int(self._lib.amsm_ctx_two_valued_msms(self._h))
+
     def pipeline_stats(self) -> dict:
         """MSMs that took the bucket-per-lane pipeline / that fell back to the chunked one (amsm_ctx_pipeline_stats)"""
         a, b = C.c_ulonglong(), C.c_ulonglong()

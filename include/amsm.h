@@ -104,6 +104,10 @@ const char* amsm_ctx_collective(const amsm_ctx* ctx);
  * exactly ONE per sharded MSM / commit call however many vectors the call carries, so a prover's exchange count is its
  * number of DEPENDENT commit rounds (tests/test_cpp_multi_device.py counts them).  0 for single-device contexts. */
 unsigned long long amsm_ctx_collectives(const amsm_ctx* ctx);
+/* MSMs of device vectors that took the two-valued form so far: every scalar 0 or one value v -> v * (sum of the generators
+ * with a non-zero scalar).  ark-ec's multi_scalar_mul special-cases the scalars 0 and 1 the same way (ark-ec ^0.2.0 msm, not
+ * in /root/reference: Cargo.toml:15); the reference's hp_as inputs are `vec![rand; n]` (src/hp_as/mod.rs:189-190). */
+unsigned long long amsm_ctx_two_valued_msms(const amsm_ctx* ctx);
 /* Which accumulation pipeline the context's MSMs took so far: *n_bucket_per_lane = MSMs enqueued on the bucket-per-lane
  * pipeline (keys of >= 2^20 generators, MSMs of (2^19, 2^20] pairs -- longer ones as windows of 2^20; 20-bit windows, 13
  * gathered additions per pair), *n_fallbacks = those whose scalars turned out skewed (a digit value shared by a large part of

@@ -1,0 +1,121 @@
+"""Two-valued scalar vectors (every scalar 0 or one value v: the reference harness's `vec![rand; n]` hp_as inputs,
+src/hp_as/mod.rs:189-190, the DummyCircuit's A z / B z / C z, src/r1cs_nark_as/mod.rs:1159-1188, boolean witnesses) take
+v * (sum of the generators with a non-zero scalar) instead of the windowed pipelines.  Same canonical results as the C oracle
+(oracle/ark_msm.c: ark-ec's algorithm) for every shape of such a vector, and vectors that are ALMOST two-valued must not take
+the shortcut."""
+import numpy as np
+import pytest
+
+from accumulation_amd import ffi
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+CURVES = [ffi.AMSM_PALLAS, ffi.AMSM_BLS12_381_G1]
+
+
+def _vectors(curve, n):
+    """name -> (canonical scalars (n, 4), expected to take the shortcut)"""
+    rnd = cref.rng_scalars(0x7E57 + n, n)
+    v = rnd[5].copy()
+    out = {}
+    const = np.tile(v, (n, 1))
+    out["constant"] = (const, True)
+    dummy = const.copy()
+    dummy[-1] = 0                                   # the DummyCircuit's zero row
+    out["constant_with_zero_row"] = (dummy, True)
+    ones = np.zeros((n, 4), dtype=np.uint64)
+    ones[:, 0] = (np.arange(n) % 3 != 0).astype(np.uint64)   # boolean witness: {0, 1}
+    out["boolean"] = (ones, True)
+    sparse = np.zeros((n, 4), dtype=np.uint64)
+    sparse[7::997] = v                              # few non-zero entries, head mostly zero
+    out["sparse_one_value"] = (sparse, True)
+    third = const.copy()
+    third[n - 3] = rnd[9]                           # a third value near the end: the probe must see it
+    out["third_value_at_the_end"] = (third, False)
+    off_by_one = const.copy()
+    off_by_one[n // 2, 3] ^= np.uint64(1)           # differs in the top word only
+    out["one_scalar_differs_in_its_top_word"] = (off_by_one, False)
+    head_zero = rnd.copy()
+    head_zero[:2048] = 0                            # all-zero head: left to the regular pipelines
+    out["uniform_behind_a_zero_head"] = (head_zero, False)
+    out["uniform"] = (rnd, False)
+    return out
+
+
+@pytest.fixture(scope="module")
+def env():
+    from accumulation_amd import CommitterKey, Context
+    out = {}
+    for curve in CURVES:
+        ctx = Context(curve)
+        n_key = (1 << 16) + 37
+        pre = CommitterKey.generate(ctx, 0x5EED7E57, n_key)
+        xy, inf = pre.read()
+        plain = CommitterKey.load(ctx, xy, inf, 2)
+        out[curve] = (ctx, pre, plain, xy)
+    yield out
+    for ctx, pre, plain, _ in out.values():
+        pre.free()
+        plain.free()
+        ctx.close()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=["pallas", "bls12_381_g1"])
+@pytest.mark.parametrize("mont", [False, True], ids=["canonical", "montgomery"])
+def test_two_valued_vectors_in_a_batch_vs_c_oracle(env, curve, mont):
+    from accumulation_amd import VariableBaseMSM
+    ctx, pre, plain, xy = env[curve]
+    n = (1 << 16) + 37
+    vecs = _vectors(curve, n)
+    names = list(vecs)
+    want = {k: cref.msm(curve, xy[:n], vecs[k][0]) for k in names}
+    for key in (pre, plain):
+        up = [ctx.upload(cref.fr_to_mont(curve, vecs[k][0]) if mont else vecs[k][0]) for k in names]
+        before = ctx.two_valued_msms()
+        out, inf = VariableBaseMSM.multi_scalar_mul_batch(key, up, mont=mont)
+        taken = ctx.two_valued_msms() - before
+        assert taken == sum(1 for k in names if vecs[k][1]), (taken, names)
+        for j, k in enumerate(names):
+            ref, ref_inf = want[k]
+            assert bool(inf[j]) == bool(ref_inf) and np.array_equal(out[j], ref), (k, mont, key.precomputed)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=["pallas", "bls12_381_g1"])
+def test_windows_of_the_key_and_short_vectors(env, curve):
+    """base_off != 0 (a window of the key) and vectors below the probe's minimum length (regular pipelines)."""
+    from accumulation_amd import VariableBaseMSM
+    ctx, pre, _, xy = env[curve]
+    n = 1 << 15
+    v = cref.rng_scalars(0x7E58, 4)[2]
+    const = np.tile(v, (n, 1))
+    for off, m, expect in ((1234, n, 2), (n, n // 8, 0)):
+        vec = ctx.upload(const[:m])
+        before = ctx.two_valued_msms()
+        out, inf = VariableBaseMSM.multi_scalar_mul_batch(pre, [vec, vec], mont=False, base_off=off)
+        assert ctx.two_valued_msms() - before == expect
+        ref, ref_inf = cref.msm(curve, xy[off:off + m], const[:m])
+        for j in range(2):
+            assert bool(inf[j]) == bool(ref_inf) and np.array_equal(out[j], ref), (off, m, j)
+
+
+def test_switch_off(env):
+    """AMSM_TWO_VALUED=0: the same vectors through the regular pipelines, same results."""
+    import os
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    curve = ffi.AMSM_PALLAS
+    os.environ["AMSM_TWO_VALUED"] = "0"
+    try:
+        ctx = Context(curve)
+    finally:
+        os.environ.pop("AMSM_TWO_VALUED", None)
+    n = 1 << 15
+    ck = CommitterKey.generate(ctx, 0x5EED7E57, n)
+    xy, _ = ck.read()
+    const = np.tile(cref.rng_scalars(0x7E59, 1)[0], (n, 1))
+    out, inf = VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(const)] * 2, mont=False)
+    assert ctx.two_valued_msms() == 0
+    ref, ref_inf = cref.msm(curve, xy, const)
+    assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref) and bool(inf[0]) == bool(ref_inf)
+    ck.free()
+    ctx.close()
