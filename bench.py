@@ -192,6 +192,7 @@ def main() -> int:
                 raise SystemExit("host-slice batch differs from the device-resident batch")
             del h_vecs
             pipe = ctx.pipeline_stats()
+            pipe["two_valued"] = ctx.two_valued_msms()  # 0 here: the timed vectors are uniform
             # the TRUE variable-base rate: no precomputed multiples (what an ark-ec `[patch]` that passes its bases per
             # call gets, or pays ~50 ms of table building per new base set to avoid)
             if not args.no_precompute and args.log2n <= 21:
@@ -317,9 +318,18 @@ def scheme_rates():
             os.makedirs(os.path.dirname(exe), exist_ok=True)
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", libdir,
                                    "-l:libamsm.so", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+        out["inputs"] = ("hp_as: uniform random vectors; `hp_as_..._harness_constant_inputs` repeats it with the reference harness's "
+                         "own inputs, vec![rand; n] (src/hp_as/mod.rs:189-190, :991-992): every commitment of such a vector takes the "
+                         "two-valued form (v * sum of generators, amsm_ctx_two_valued_msms) instead of a windowed MSM.  r1cs_nark_as: the "
+                         "reference's DummyCircuit (src/r1cs_nark_as/mod.rs:1159-1188), whose A z / B z / C z are one value per row: "
+                         "two-valued as well.  The `value` of this bench line is measured on uniform random scalars only")
         for scheme, lg, extra in (("trivial_pc_as", 10, ["--reps", "5"]), ("ipa_pc_as", 16, ["--reps", "3"]),
-                                  ("r1cs_nark_as", 18, ["--reps", "3"]), ("hp_as", 22, ["--reps", "3", "--no-roundtrip"])):
+                                  ("r1cs_nark_as", 18, ["--reps", "3"]), ("hp_as", 22, ["--reps", "3", "--no-roundtrip"]),
+                                  ("hp_as", 22, ["--reps", "3", "--no-roundtrip", "--constant"])):
+            tag = "_harness_constant_inputs" if "--constant" in extra else ""
             for sponge in ("poseidon", "sha256"):
+                if tag and sponge == "sha256":
+                    continue
                 try:
                     p = subprocess.run([exe, scheme, str(lg), str(lg), "--sponge", sponge, *extra], capture_output=True, text=True,
                                        timeout=600)
@@ -331,10 +341,10 @@ def scheme_rates():
                         r = json.loads(line[5:])
                         shape = "harness_1in_2acc_zk" if r["shape"].startswith("harness") else "n2_1in_1acc_nozk"
                         if sponge == "sha256":  # the stand-in: prove time only, never the reported rate
-                            out.setdefault("sha256_standin_prove_ms", {})[f"{scheme}_2^{lg}_{shape}"] = round(r["prove_ms"], 3)
+                            out.setdefault("sha256_standin_prove_ms", {})[f"{scheme}_2^{lg}_{shape}{tag}"] = round(r["prove_ms"], 3)
                             continue
                         rt = r["serialize_roundtrip_decides"]  # null when the harness skipped the check (--no-roundtrip)
-                        out[f"{scheme}_2^{lg}_{shape}"] = {
+                        out[f"{scheme}_2^{lg}_{shape}{tag}"] = {
                             "accumulations_per_s": round(r["accumulations_per_s"], 2), "prove_ms": round(r["prove_ms"], 3),
                             "verify_ms": round(r["verify_ms"], 3), "decide_ms": round(r["decide_ms"], 3),
                             "index_ms": round(r["index_ms"], 1), "zk": r["zk"], "sponge": r["sponge"],
@@ -342,7 +352,7 @@ def scheme_rates():
                             "verified": bool(r["verified"] and r["decided"]),
                             "serialize_roundtrip": "skipped" if rt is None else bool(rt)}
                 except Exception as e:  # noqa: BLE001
-                    out[f"{scheme}_2^{lg}" + ("" if sponge == "poseidon" else "_sha256")] = {"error": f"{type(e).__name__}: {e}"}
+                    out[f"{scheme}_2^{lg}{tag}" + ("" if sponge == "poseidon" else "_sha256")] = {"error": f"{type(e).__name__}: {e}"}
     except Exception as e:  # noqa: BLE001
         out["error"] = f"{type(e).__name__}: {e}"
     return out
