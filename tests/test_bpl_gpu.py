@@ -25,10 +25,14 @@ def env(cref, request):
     net under the probe, exercised on its own here"""
     from accumulation_amd import CommitterKey, Context
     os.environ["AMSM_BPL_PROBE"] = "1" if request.param == "probe" else "0"
+    # constant vectors are this file's skewed inputs: with the two-valued form on they never reach the pipelines under test
+    # (tests/test_two_valued_gpu.py covers that form)
+    os.environ["AMSM_TWO_VALUED"] = "0"
     try:
         ctx = Context(C.curve_id)
     finally:
         del os.environ["AMSM_BPL_PROBE"]
+        del os.environ["AMSM_TWO_VALUED"]
     ctx.probe = request.param == "probe"
     ck = CommitterKey.generate(ctx, 0x5EED1001, N)
     xy, _ = ck.read()
