@@ -61,6 +61,7 @@ static PrepGeom prep_geom(const MsmGeom& g) {
   pg.CAP = budget_words > fixed_words + 4096u ? budget_words - fixed_words : 0u;
   // heavy: several times the expected size AND big enough for 64 workgroups to beat one (below, one workgroup is fine)
   pg.HEAVY = std::max<u32>(4u * (g.E / pg.P + 1u), 1u << 17);
+  pg.FIX = 0;
   if (const char* e = getenv("AMSM_PREP_HEAVY"))  // 0: one workgroup per partition whatever its size (A/B)
     if (atoi(e) == 0) pg.HEAVY = 0xffffffffu;
   return pg;
@@ -108,7 +109,14 @@ static PrepGeom prep_bpl_geom(const MsmGeom& g) {
   const u32 budget_words = 37888u, fixed_words = 4u * nb + 1024u + BPL_BINS + 2u * BPL_GROUPS + 2u;
   pg.CAP = budget_words - fixed_words;  // ~31.4 k entries: a partition of a 2^20-pair MSM holds ~26.6 k
   pg.HEAVY = 0xffffffffu;
+  static const bool with_hist = [] { const char* e = getenv("AMSM_BPL_HIST"); return e && atoi(e) != 0; }();  // A/B
+  pg.FIX = with_hist ? 0u : pg.CAP;
   return pg;
+}
+// 8-byte interchange entries the partition pass may write (fixed partitions reserve CAP each)
+size_t prep_bpl_part_entries(const MsmGeom& g) {
+  PrepGeom pg = prep_bpl_geom(g);
+  return std::max<size_t>(g.E, pg.FIX ? (size_t)pg.P * pg.FIX : 0);
 }
 static size_t prep_bpl_local_lds(const PrepGeom& pg) {
   const u32 nb = 1u << pg.SH;
@@ -164,6 +172,7 @@ static PrepGeom prep_bps_geom(const MsmGeom& g, u32 log2_l) {
   const u32 budget_words = 37888u, fixed_words = 3u * nbp + 1024u + 2u * BPS_GROUPS + 2u;
   pg.CAP = budget_words - fixed_words;
   pg.HEAVY = 0xffffffffu;
+  pg.FIX = 0;
   return pg;
 }
 static size_t prep_bps_local_lds(const PrepGeom& pg) {
@@ -382,17 +391,18 @@ void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
       if (hipMemsetAsync(b.err, 0, zero_bytes, st) != hipSuccess) return -1;                                         \
     }                                                                                                                \
     prep_bpl_attr(k_prep_scatter<FR, 16, 1, true>);                                                                  \
-    {                                                                                                                \
+    if (!pg.FIX) {                                                                                                   \
       PrepGeom ph = pg;                                                                                              \
       ph.SPB = 1024;                                                                                                 \
       hipLaunchKernelGGL((k_prep_hist<FR>), dim3(cdiv_(g.n, 1024)), dim3(1024), pg.P * sizeof(u32), st, scalars,      \
                          mont, g, ph, part_total, b.err);                                                            \
+      hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P, pg.HEAVY, hv);       \
     }                                                                                                                \
-    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P, pg.HEAVY, hv);         \
     hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1, true>), dim3(cdiv_(g.n, pg.SPB)), dim3(512),                       \
-                       prep_bpl_scatter_lds(g, pg), st, scalars, mont, g, pg, part_start, part_cursor, b.part);      \
-    hipLaunchKernelGGL(k_prep_local_t, dim3(pg.P), dim3(1024), prep_bpl_local_lds(pg), st, part_start,               \
-                       (const u64*)b.part, g, pg, prep_bpl_stride(g), b.ents_t, (BplGroup*)b.grp, b.order, b.err);   \
+                       prep_bpl_scatter_lds(g, pg), st, scalars, mont, g, pg, part_start, part_cursor, b.part, b.err); \
+    hipLaunchKernelGGL(k_prep_local_t, dim3(pg.P), dim3(1024), prep_bpl_local_lds(pg), st,                           \
+                       pg.FIX ? part_cursor : part_start, (const u64*)b.part, g, pg, prep_bpl_stride(g), b.ents_t,   \
+                       (BplGroup*)b.grp, b.order, b.err);                                                            \
     return 0;                                                                                                        \
   }                                                                                                                  \
   template <>                                                                                                        \

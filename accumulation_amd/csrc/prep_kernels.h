@@ -34,6 +34,11 @@ struct PrepGeom {
   u32 IB;   // bits of a table index (entry word: negate | bucket id low bits << IB | index)
   u32 CAP;  // entries k_prep_local can assemble in LDS (larger partitions scatter straight to memory)
   u32 HEAVY;  // partitions with more entries than this are split over PREP_HEAVY_SLICES workgroups (k_prep_heavy_*)
+  // FIX != 0 (bucket-per-lane prep, round 3): partition p owns entries [p * FIX, (p + 1) * FIX) of the interchange buffer --
+  // no histogram, no scan: uniform digits fill a partition to E / P +- a few hundred entries, and FIX = CAP, what
+  // k_prep_local_t can stage anyway; a partition that would overflow drops the excess and its count (the cursor) trips the
+  // overflow flag there, i.e. the skew fallback that a partition above CAP takes in any case
+  u32 FIX;
 };
 
 // A skewed digit distribution (the all-equal vectors the reference's harness commits to put a whole
@@ -156,8 +161,9 @@ AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont,
 
 // The same walk over a scalar already in registers (canonical form): k_prep_scatter walks every scalar twice and keeps
 // it (8 registers) instead of loading -- and converting from Montgomery form -- a second time.
+// Returns non-zero when the scalar does not fit W windows, like scalar_entries (callers that walk twice ignore it once).
 template <class Fr, int MAXW, class F>
-AMSM_DEV void scalar_entries_unrolled_reg(Fe<Fr> s, const MsmGeom& g, u32 i, F&& f) {
+AMSM_DEV u32 scalar_entries_unrolled_reg(Fe<Fr> s, const MsmGeom& g, u32 i, F&& f) {
   const u32 c = g.c;
   const u32 mask = (1u << c) - 1u;
   const u32 half = 1u << (c - 1);
@@ -177,7 +183,10 @@ AMSM_DEV void scalar_entries_unrolled_reg(Fe<Fr> s, const MsmGeom& g, u32 i, F&&
       u32 d = raw;
       if (g.top_shift && (u32)w == g.W - 1u) {
         d = raw << g.top_shift;  // MsmGeom::top_shift
-        if (d > half) d = 0;     // non-canonical scalar: k_prep_hist's walk reports it
+        if (d > half) {          // non-canonical scalar: reported, no entry
+          d = 0;
+          carry = 1;
+        }
       } else if (raw > half) {
         d = (1u << c) - raw;
         neg = 1;
@@ -186,6 +195,10 @@ AMSM_DEV void scalar_entries_unrolled_reg(Fe<Fr> s, const MsmGeom& g, u32 i, F&&
       if (d != 0) f(w, set * g.nb + (d - 1), idx | (neg << 31));
     }
   }
+  u32 rest = carry;
+#pragma unroll
+  for (int k = 0; k < 8; k++) rest |= s.v[k];
+  return rest;
 }
 
 // dynamic LDS: P counters
@@ -262,7 +275,7 @@ __global__ void __launch_bounds__(1024)
 template <class Fr, int MAXW, int SPT, bool WIDE = false>
 __global__ void __launch_bounds__(512)
     k_prep_scatter(const u32* __restrict__ scalars, int mont, MsmGeom g, PrepGeom pg, const u32* __restrict__ part_start,
-                   u32* __restrict__ part_cursor, u32* __restrict__ part) {
+                   u32* __restrict__ part_cursor, u32* __restrict__ part, u32* __restrict__ err = nullptr) {
   extern __shared__ u32 prep_lds[];
   const u32 cap = pg.SPB * g.S;  // staged entries (upper bound)
   u32* cnt = prep_lds;           // entries per partition (rank counters in step 1)
@@ -285,10 +298,11 @@ __global__ void __launch_bounds__(512)
     if (i < g.n) {
       sreg[r] = fe_load<Fr>(scalars + (size_t)i * 8);
       if (mont) sreg[r] = fe_from_mont<Fr>(sreg[r]);
-      scalar_entries_unrolled_reg<Fr, MAXW>(sreg[r], g, i, [&](int w, u32 key, u32) {
+      const u32 bad = scalar_entries_unrolled_reg<Fr, MAXW>(sreg[r], g, i, [&](int w, u32 key, u32) {
         u32 rank = atomicAdd(&cnt[key >> pg.SH], 1u);
         rk[r][w >> 1] |= rank << ((w & 1) * 16);
       });
+      if (pg.FIX && bad && err) atomicOr(err, 1u);  // (with a histogram pass, that pass reports it)
     }
   }
   __syncthreads();
@@ -323,7 +337,7 @@ __global__ void __launch_bounds__(512)
         u32 v = cnt[p];
         loff[p] = run;
         if (v) {
-          rsv_base[q] = part_start[p];
+          rsv_base[q] = pg.FIX ? p * pg.FIX : part_start[p];
           rsv[q] = atomicAdd(&part_cursor[p], v);
         }
         run += v;
@@ -332,7 +346,7 @@ __global__ void __launch_bounds__(512)
     for (u32 p = lo + RSV_MAX; p < hi; p++) {  // more partitions per lane than registers kept for them
       u32 v = cnt[p];
       loff[p] = run;
-      gbase[p] = v ? part_start[p] + atomicAdd(&part_cursor[p], v) : 0u;
+      gbase[p] = v ? (pg.FIX ? p * pg.FIX : part_start[p]) + atomicAdd(&part_cursor[p], v) : 0u;
       run += v;
     }
   }
@@ -360,8 +374,10 @@ __global__ void __launch_bounds__(512)
   u32 total = loff[pg.P - 1] + cnt[pg.P - 1];
   for (u32 j = t; j < total; j += T) {
     u32 p = staged_p[j];
-    if (WIDE) reinterpret_cast<u64*>(part)[gbase[p] + (j - loff[p])] = reinterpret_cast<const u64*>(staged)[j];
-    else part[gbase[p] + (j - loff[p])] = staged[j];
+    const u32 dst = gbase[p] + (j - loff[p]);
+    if (pg.FIX && dst - p * pg.FIX >= pg.FIX) continue;  // the partition is full: skewed digits (the count flags it)
+    if (WIDE) reinterpret_cast<u64*>(part)[dst] = reinterpret_cast<const u64*>(staged)[j];
+    else part[dst] = staged[j];
   }
 }
 
@@ -664,7 +680,10 @@ __global__ void __launch_bounds__(1024)
   u32* gb = gm + NG;              // NG + 1: first entry of the group inside the partition's block
   u32* stage = gb + NG + 1;       // CAP sorted entries
   const u32 p = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-  const u32 ps = part_start[p], pe = part_start[p + 1], n_p = pe - ps;
+  // fixed partitions (PrepGeom::FIX): `part_start` is the scatter's CURSOR array -- entries reserved, possibly more than fit
+  const u32 ps = pg.FIX ? p * pg.FIX : part_start[p];
+  const u32 n_p = pg.FIX ? part_start[p] : part_start[p + 1] - ps;
+  const u32 pe = ps + (pg.FIX ? min(n_p, pg.FIX) : n_p);
   const u32 low = NB - 1u, idx_mask = (1u << pg.IB) - 1u, b0 = p << pg.SH;
   const bool fits = n_p <= pg.CAP;
   for (u32 k = t; k < NB; k += T) cnt[k] = 0;
