@@ -172,8 +172,16 @@ static PrepGeom prep_bps_geom(const MsmGeom& g, u32 log2_l) {
   const u32 budget_words = 37888u, fixed_words = 3u * nbp + 1024u + 2u * BPS_GROUPS + 2u;
   pg.CAP = budget_words - fixed_words;
   pg.HEAVY = 0xffffffffu;
-  pg.FIX = 0;
+  // fixed partitions (PrepGeom::FIX): half as much again as a uniform partition holds, at most what the LDS stage takes
+  static const bool with_hist = [] { const char* e = getenv("AMSM_BPS_HIST"); return e && atoi(e) != 0; }();  // A/B
+  const unsigned long long per = ((unsigned long long)g.E + pg.P - 1) / std::max(1u, pg.P);
+  pg.FIX = with_hist ? 0u : (u32)std::min<unsigned long long>(pg.CAP, (per + per / 2ull + 1024ull + 15ull) & ~15ull);
   return pg;
+}
+// 4-byte interchange entries the partition pass may write
+size_t prep_bps_part_entries(const MsmGeom& g, u32 log2_l) {
+  PrepGeom pg = prep_bps_geom(g, log2_l);
+  return std::max<size_t>(g.E, pg.FIX ? (size_t)pg.P * pg.FIX : 0);
 }
 static size_t prep_bps_local_lds(const PrepGeom& pg) {
   return (size_t)(3u * (1u << pg.SH) + 1024u + 2u * BPS_GROUPS + 2u + pg.CAP) * sizeof(u32);
@@ -348,28 +356,29 @@ void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
       if (hipMemsetAsync(b.err, 0, zero_bytes, st) != hipSuccess) return -1;                                         \
     }                                                                                                                \
     prep_bps_attr();                                                                                                 \
-    {                                                                                                                \
+    if (!pg.FIX) {                                                                                                   \
       PrepGeom ph = pg;                                                                                              \
       ph.SPB = 1024;                                                                                                 \
       hipLaunchKernelGGL((k_prep_hist<FR>), dim3(cdiv_(g.n, 1024)), dim3(1024), pg.P * sizeof(u32), st, scalars,      \
                          mont, g, ph, part_total, b.err);                                                            \
+      hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P, pg.HEAVY, hv);       \
     }                                                                                                                \
-    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P, pg.HEAVY, hv);         \
     const size_t lds_scatter = prep_scatter_lds(g, pg);                                                              \
     if (g.S <= 16u) {                                                                                                \
       if (lds_scatter > 64 * 1024)                                                                                   \
         (void)hipFuncSetAttribute((const void*)k_prep_scatter<FR, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)PREP_LDS_LIMIT);                                                              \
       hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1>), dim3(cdiv_(g.n, pg.SPB)), dim3(512), lds_scatter, st, scalars, \
-                         mont, g, pg, part_start, part_cursor, b.part);                                              \
+                         mont, g, pg, part_start, part_cursor, b.part, b.err);                                       \
     } else {                                                                                                         \
       if (lds_scatter > 64 * 1024)                                                                                   \
         (void)hipFuncSetAttribute((const void*)k_prep_scatter<FR, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)PREP_LDS_LIMIT);                                                              \
       hipLaunchKernelGGL((k_prep_scatter<FR, 32, 1>), dim3(cdiv_(g.n, pg.SPB)), dim3(256), lds_scatter, st, scalars, \
-                         mont, g, pg, part_start, part_cursor, b.part);                                              \
+                         mont, g, pg, part_start, part_cursor, b.part, b.err);                                       \
     }                                                                                                                \
-    hipLaunchKernelGGL(k_prep_local_s, dim3(pg.P), dim3(1024), prep_bps_local_lds(pg), st, part_start, b.part, g, pg, \
+    hipLaunchKernelGGL(k_prep_local_s, dim3(pg.P), dim3(1024), prep_bps_local_lds(pg), st,                           \
+                       pg.FIX ? part_cursor : part_start, b.part, g, pg,                                             \
                        prep_bps_stride(g, log2_l), log2_l, b.ents_t, (BplGroup*)b.grp, b.err);                       \
     return 0;                                                                                                        \
   }                                                                                                                  \

@@ -104,7 +104,8 @@ struct PrepBplBuffers {
 bool prep_bpl_supported(const MsmGeom& g);
 u32 prep_bpl_stride(const MsmGeom& g);  // entries per partition block of ents_t
 u32 prep_bpl_partitions(const MsmGeom& g);
-size_t prep_bpl_part_entries(const MsmGeom& g);  // 8-byte interchange entries the partition pass may write
+size_t prep_bpl_part_entries(const MsmGeom& g);
+size_t prep_bps_part_entries(const MsmGeom& g, u32 log2_l);  // 4-byte interchange entries of the bucket-split prep  // 8-byte interchange entries the partition pass may write
 u32 prep_bpl_groups_per_partition();  // group headers (and 64-lane blocks of `order`) per partition
 template <class Fr>
 int launch_prep_bpl(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBplBuffers& b);

@@ -807,9 +807,12 @@ __global__ void __launch_bounds__(1024)
   u32* gb = gm + NG;          // NG + 1
   u32* stage = gb + NG + 2;   // CAP entries sorted by bucket
   const u32 p = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-  const u32 ps = part_start[p], pe = part_start[p + 1], n_p = pe - ps;
+  // fixed partitions (PrepGeom::FIX): `part_start` is the scatter's CURSOR array, as in k_prep_local_t
+  const u32 ps = pg.FIX ? p * pg.FIX : part_start[p];
+  const u32 n_p = pg.FIX ? part_start[p] : part_start[p + 1] - ps;
+  const u32 pe = ps + (pg.FIX ? min(n_p, pg.FIX) : n_p);
   const u32 low = NBP - 1u, idx_mask = (1u << pg.IB) - 1u;
-  const bool fits = n_p <= pg.CAP;
+  const bool fits = n_p <= pg.CAP && (!pg.FIX || n_p <= pg.FIX);
   for (u32 k = t; k < NBP; k += T) cnt[k] = 0;
   for (u32 k = t; k < NG; k += T) gm[k] = 0;
   __syncthreads();
