@@ -72,8 +72,10 @@ bool launch_points_fold_tab(hipStream_t st, const u32* table, u32 stride, u32 c,
 // two-valued vectors (vec_kernels.h k_tv_probe, msm_kernels.h k_tv_sum): exact probe into out[16] (out[0] pre-zeroed), and the
 // sum of the generators with non-zero scalars as `blocks` partial records
 void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16);
+// nv <= 8 vectors in one launch: vector v's `blocks` partial records at parts + v * blocks
 template <class Fq>
-void launch_tv_sum(hipStream_t st, const u32* table, u32 base_off, const u32* scalars, u32 n, u32 blocks, u32* parts);
+void launch_tv_sum(hipStream_t st, const u32* table, u32 nv, const u32* const* scalars, const u32* ns, const u32* base_offs,
+                   u32 blocks, u32* parts);
 
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>

@@ -532,20 +532,27 @@ __global__ void __launch_bounds__(256)
 
 // Sum of the generators whose scalar is non-zero: the MSM of a two-valued vector up to one scalar multiplication
 // (vec_kernels.h: k_tv_probe verified that every non-zero scalar is the same value).  Lane-strided mixed additions, one
-// partial record per workgroup (k_fold sums them).
+// partial record per workgroup (k_fold sums them).  blockIdx.y = which of up to TV_BATCH vectors of a call (one launch for all:
+// each is a latency-bound chain of a few additions and a workgroup reduction).
+constexpr int TV_BATCH = 8;
+struct TvBatch {
+  const u32* scalars[TV_BATCH];
+  u32 n[TV_BATCH];
+  u32 base_off[TV_BATCH];
+};
 template <class Fq>
-__global__ void __launch_bounds__(256)
-    k_tv_sum(const u32* __restrict__ table, u32 base_off, const u32* __restrict__ scalars, u32 n, u32* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_tv_sum(const u32* __restrict__ table, TvBatch b, u32* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
-  const uint4* s4 = (const uint4*)scalars;
+  const u32 v = blockIdx.y, n = b.n[v], base_off = b.base_off[v];
+  const uint4* s4 = (const uint4*)b.scalars[v];
   const u32 stride = gridDim.x * 256u;
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
-    const uint4 a = s4[2 * (size_t)i], b = s4[2 * (size_t)i + 1];
-    if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u) xyzz_madd<Fq>(acc, affine_load<Fq>(table, (size_t)base_off + i));
+    const uint4 lo = s4[2 * (size_t)i], hi = s4[2 * (size_t)i + 1];
+    if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0u) xyzz_madd<Fq>(acc, affine_load<Fq>(table, (size_t)base_off + i));
   }
   block_reduce_xyzz<Fq>(acc, lds);
-  if (threadIdx.x == 0) xyzz_store<Fq>(out, blockIdx.x, acc);
+  if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)v * gridDim.x + blockIdx.x, acc);
 }
 
 // fold: wave b sums records [b*n, (b+1)*n) (lane-strided + shuffle butterfly) and writes out[b] (C-ABI radix).
