@@ -530,7 +530,8 @@ __global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ sca
 // additions and one scalar multiplication instead of n windows' worth (k_tv_sum, msm_kernels.h).
 // EXACT test, not a sample: v = the first non-zero scalar among the first TV_HEAD; every lane compares its scalars with 0 and
 // v and raises out[0] on the first that is neither -- a uniform vector ends the kernel after one load per lane.
-// out: [0] mismatch (pre-zeroed by the caller), [1] a non-zero head scalar exists, [8..15] v as stored.
+// out: [0] mismatch (pre-zeroed by the caller), [1] a non-zero head scalar exists, [2] the head is zero (with [0] == 0: the whole
+// vector is), [8..15] v as stored.
 // ---------------------------------------------------------------------------------------------
 constexpr u32 TV_HEAD = 1024;
 __global__ void __launch_bounds__(256) k_tv_probe(const u32* __restrict__ scalars, u32 n, u32* __restrict__ out) {
@@ -549,8 +550,18 @@ __global__ void __launch_bounds__(256) k_tv_probe(const u32* __restrict__ scalar
   }
   __syncthreads();
   const u32 f = first;
-  if (f == 0xffffffffu) {  // head all zero: not handled here (the regular pipeline skips zero digits anyway)
-    if (blockIdx.x == 0 && t == 0) out[0] = 1u;
+  if (f == 0xffffffffu) {  // head all zero: two-valued only if EVERYTHING is zero (out[2]); a non-zero scalar further on -> out[0]
+    const u32 stride0 = gridDim.x * 256u;
+    volatile u32* bad0 = out;
+    for (u32 i = blockIdx.x * 256u + t; i < n; i += stride0) {
+      const uint4 a = s4[2 * (size_t)i], b = s4[2 * (size_t)i + 1];
+      if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u) {
+        out[0] = 1u;
+        return;
+      }
+      if (*bad0) return;
+    }
+    if (blockIdx.x == 0 && t == 0) out[2] = 1u;
     return;
   }
   if (t < 8) vw[t] = scalars[(size_t)f * 8 + t];

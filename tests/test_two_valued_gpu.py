@@ -30,6 +30,7 @@ def _vectors(curve, n):
     sparse = np.zeros((n, 4), dtype=np.uint64)
     sparse[7::997] = v                              # few non-zero entries, head mostly zero
     out["sparse_one_value"] = (sparse, True)
+    out["all_zero"] = (np.zeros((n, 4), dtype=np.uint64), True)   # the identity, nothing launched
     third = const.copy()
     third[n - 3] = rnd[9]                           # a third value near the end: the probe must see it
     out["third_value_at_the_end"] = (third, False)
