@@ -192,6 +192,98 @@ AMSM_DEV Affine<P> affine_neg_if(const Affine<P>& p, bool negate) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Jacobian coordinates (x = X / Z^2, y = Y / Z^3; infinity <=> Z = 0) for the LADDERS of the key folds (k_points_fold: 128
+// doublings and ~43 mixed additions per point): the doubling is 3M + 4S against XYZZ's 6M + 3S, the mixed addition 8M + 3S
+// against 8M + 2S -- 1/6 fewer multiplier passes over a fold.  (The bucket accumulation adds, it does not double: XYZZ stays
+// there.)  ark-ec's own formulas for these curves are Jacobian as well (ec.h header); only canonical affine results are compared.
+// Invariant of a point held in registers (unsaturated fields, cap = 2^261 ~ 128 p for Pallas, far more for BLS12-381):
+//        X < 12p      Y < 13p      Z < 3p        all tight
+// with the same bound notation as above.
+// ---------------------------------------------------------------------------------------------
+template <class P>
+struct Jac {
+  Fe<P> x, y, z;
+};
+template <class P>
+AMSM_DEV Jac<P> jac_inf() {
+  Jac<P> r;
+  r.x = fe_zero<P>();
+  r.y = fe_zero<P>();
+  r.z = fe_zero<P>();
+  return r;
+}
+template <class P>
+AMSM_DEV bool jac_is_inf(const Jac<P>& p) {
+  return fe_is_zero<P>(p.z);
+}
+// dbl-2007-bl shape with a = 0 (S = X Y^2 as a product): 3M + 4S
+template <class P>
+AMSM_DEV Jac<P> jac_dbl(const Jac<P>& p) {
+  if (jac_is_inf<P>(p)) return p;
+  const Fe<P> zero = fe_zero<P>();
+  Fe<P> xx = fe_sqr<P>(p.x);                                  // [< 2.2p]
+  Fe<P> yy = fe_sqr<P>(p.y);                                  // [< 2.4p]
+  Fe<P> yyyy = fe_sqr<P>(yy);                                 // [< 1.1p]
+  Fe<P> s4 = fe_dbl<P>(fe_dbl<P>(fe_mul<P>(p.x, yy)));        // 4 X Y^2: product [< 1.3p] -> [< 5p]
+  Fe<P> m = fe_triple<P>(xx);                                 // [< 6.5p]
+  Jac<P> r;
+  r.x = fe_sqr_sub_bcc_k<P, 10>(m, zero, s4);                 // m^2 [< 1.4p] - 2 s4 [< 10p] (+10p)  [< 11.4p]
+  Fe<P> t = fe_sub_k<P, 12>(s4, r.x);                         // [< 17p]
+  Fe<P> y8 = fe_dbl<P>(fe_dbl<P>(fe_dbl<P>(yyyy)));           // 8 Y^4  [< 8.5p]
+  r.y = fe_mul_sub_k<P, 10>(m, t, y8);                        // m t [< 1.9p] - y8 (+10p)  [< 11.9p]
+  r.z = fe_dbl<P>(fe_mul<P>(p.y, p.z));                       // 2 Y Z: product [< 1.4p] -> [< 2.7p]
+  return r;
+}
+// acc += q (q affine; same conventions as xyzz_madd: (0, 0) is infinity, q.y may be a lazily negated y): 8M + 3S
+template <class P>
+AMSM_DEV void jac_madd(Jac<P>& acc, const Affine<P>& q) {
+  if (affine_is_inf<P>(q)) return;
+  if (jac_is_inf<P>(acc)) {
+    acc.x = q.x;
+    acc.y = fe_tight<P>(q.y);
+    acc.z = fe_one<P>();
+    return;
+  }
+  Fe<P> zz = fe_sqr<P>(acc.z);                                // [< 1.1p]
+  Fe<P> zzz = fe_mul<P>(acc.z, zz);                           // [< 1.1p]
+  Fe<P> h = fe_mul_sub_k<P, 13>(q.x, zz, acc.x);              // u2 - X1 (+13p)  [< 14.1p]
+  Fe<P> r = fe_mul_sub_k<P, 14>(q.y, zzz, acc.y);             // s2 - Y1 (+14p)  [< 15.1p]
+  if (fe_is_zero_mod<P, 16>(h)) {
+    if (fe_is_zero_mod<P, 16>(r)) {
+      Jac<P> d;
+      d.x = q.x;
+      d.y = fe_tight<P>(q.y);
+      d.z = fe_one<P>();
+      acc = jac_dbl<P>(d);
+    } else {
+      acc = jac_inf<P>();
+    }
+    return;
+  }
+  Fe<P> hh = fe_sqr<P>(h);                                    // [< 2.6p]
+  Fe<P> hhh = fe_mul<P>(h, hh);                               // [< 1.3p]
+  Fe<P> v = fe_mul<P>(acc.x, hh);                             // [< 1.3p]
+  Fe<P> x3 = fe_sqr_sub_bcc_k<P, 4>(r, hhh, v);               // r^2 [< 2.8p] - hhh - 2v [< 3.9p] (+4p)  [< 6.8p]
+  Fe<P> t = fe_sub_k<P, 8>(v, x3);                            // [< 9.3p]
+  Fe<P> y3 = fe_mul_sub_mul_k<P, 16>(r, t, acc.y, hhh);       // (r t + (16p - Y1) hhh) / R': (141 + 21) / 128  [< 2.3p]
+  acc.z = fe_mul<P>(acc.z, h);                                // [< 1.4p]
+  acc.x = x3;
+  acc.y = y3;
+}
+// -> XYZZ (ZZ = Z^2, ZZZ = Z^3), X and Y brought back under the XYZZ invariant by one multiplication by one each
+template <class P>
+AMSM_DEV XYZZ<P> xyzz_from_jac(const Jac<P>& p) {
+  if (jac_is_inf<P>(p)) return xyzz_inf<P>();
+  XYZZ<P> r;
+  const Fe<P> one = fe_one<P>();
+  r.zz = fe_sqr<P>(p.z);              // [< 1.1p]
+  r.zzz = fe_mul<P>(p.z, r.zz);       // [< 1.1p]
+  r.x = fe_mul<P>(p.x, one);          // [< 1.1p]
+  r.y = fe_mul<P>(p.y, one);          // [< 1.2p]
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Quad-cooperative group law for the latency-bound tail kernels (bucket reduce, fold): the four lanes of an aligned quad
 // hold the SAME operands (replicated state); the independent field multiplications of one level of the formula run on
 // different lanes of the quad and the products are broadcast back, so a full addition is 4 multiplication-times deep
