@@ -20,7 +20,10 @@ struct DevBuf {
 // One pipeline slot = one stream + one private workspace, so two MSMs of a batch can be in flight:
 // the latency-bound tail of MSM i (fold partials, bucket reduce) overlaps the throughput-bound head of
 // MSM i+1 on the other slot's stream.
-constexpr int N_SLOTS = 3;  // MSMs of one batch in flight
+#ifndef AMSM_N_SLOTS
+#define AMSM_N_SLOTS 3
+#endif
+constexpr int N_SLOTS = AMSM_N_SLOTS;  // MSMs of one batch in flight (tools/build_variant.sh: -DAMSM_N_SLOTS=4 for an A/B)
 
 struct Slot {  // buffers and events of one MSM in flight (the streams belong to the context: one per pipeline stage)
   hipEvent_t l0_done = nullptr, prep_done = nullptr;
