@@ -197,6 +197,7 @@ u32 prep_bps_stride(const MsmGeom& g, u32 log2_l) {
 int prep_bps_choose(const MsmGeom& g) {
   if (!g.precomp || g.n == 0 || g.S > 32u || g.B < 64u || (g.B & (g.B - 1u))) return -1;
   unsigned long long want = 128;
+  if (const char* e = getenv("AMSM_BPS_WANT")) want = (unsigned long long)std::max(1, atoi(e));  // partitions wanted (A/B)
   while (want * 24576ull < g.E) want <<= 1;
   for (int l = 0; l <= 6; l++) {
     if ((10 - l) < 0 || (g.B >> (10 - l)) == 0) continue;
@@ -379,7 +380,7 @@ void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
     }                                                                                                                \
     hipLaunchKernelGGL(k_prep_local_s, dim3(pg.P), dim3(1024), prep_bps_local_lds(pg), st,                           \
                        pg.FIX ? part_cursor : part_start, b.part, g, pg,                                             \
-                       prep_bps_stride(g, log2_l), log2_l, b.ents_t, (BplGroup*)b.grp, b.err);                       \
+                       prep_bps_stride(g, log2_l), log2_l, b.ents_t, (BplGroup*)b.grp, b.order, b.err);              \
     return 0;                                                                                                        \
   }                                                                                                                  \
   template <>                                                                                                        \

@@ -119,8 +119,8 @@ u32 prep_bps_stride(const MsmGeom& g, u32 log2_l);
 template <class Fr>
 int launch_prep_bps(hipStream_t st, const u32* scalars, int mont, MsmGeom g, u32 log2_l, const PrepBplBuffers& b);
 template <class Fq>
-void launch_accum_bps(hipStream_t st, const u32* table, const u32* ents_t, const void* grp, u32 n_groups, u32 log2_l,
-                      const u32* flags, u32* buckets);
+void launch_accum_bps(hipStream_t st, const u32* table, const u32* ents_t, const void* grp, const u32* order, u32 n_groups,
+                      u32 log2_l, const u32* flags, u32* buckets);
 template <class Fr>
 int launch_prep(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const PrepBuffers& b);
 

@@ -266,12 +266,12 @@ __global__ void __launch_bounds__(256)
   if (!pairs || !(lane & 1u)) xyzz_store<Fq>(buckets, b, acc);
 }
 
-// accumulate, bucket-split (k_prep_local_s): lane l of group gw sums part (l mod L) of bucket (64 gw + l) / L; after the
+// accumulate, bucket-split (k_prep_local_s): lane l of group gw sums part (l mod L) of the bucket at position (64 gw + l) / L; after the
 // rows, log2 L exchanges add the parts and the first lane of every bucket stores it.  Same loop as k_accum_bpl.
 template <class Fq>
 __global__ void __launch_bounds__(256)
-    k_accum_bps(const u32* __restrict__ table, const u32* __restrict__ ents_t, const BplGroupHdr* __restrict__ grp, u32 n_groups,
-                u32 log2_l, const u32* __restrict__ flags, u32* __restrict__ buckets) {
+    k_accum_bps(const u32* __restrict__ table, const u32* __restrict__ ents_t, const BplGroupHdr* __restrict__ grp,
+                const u32* __restrict__ order, u32 n_groups, u32 log2_l, const u32* __restrict__ flags, u32* __restrict__ buckets) {
   __shared__ __attribute__((aligned(16))) u32 lds[2 * 4 * GatherLds<Fq>::WAVE_BYTES / 4];
   if (flags[1]) return;  // the prep overflowed: the host reruns this MSM through the chunked pipeline
   const u32 lane = threadIdx.x & 63u;
@@ -323,7 +323,8 @@ __global__ void __launch_bounds__(256)
     xyzz_add<Fq>(a, b2);
     acc = a;
   }
-  if ((lane & ((1u << log2_l) - 1u)) == 0u) xyzz_store<Fq>(buckets, (size_t)((gw * 64u + lane) >> log2_l), acc);
+  // (position in the partition's size order -> bucket: k_prep_local_s)
+  if ((lane & ((1u << log2_l) - 1u)) == 0u) xyzz_store<Fq>(buckets, (size_t)order[(gw * 64u + lane) >> log2_l], acc);
 }
 
 // Butterfly reduction of one XYZZ per lane over aligned groups of WIDTH lanes (WIDTH = 64: whole wave) with

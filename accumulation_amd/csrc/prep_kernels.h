@@ -791,19 +791,27 @@ __global__ void __launch_bounds__(1024)
 // digits).  A skewed input makes one group long: if the padded block outgrows the partition's stride (or the partition its
 // LDS stage) the overflow flag sends the MSM to the chunked pipeline over the SAME key.
 // 32-bit interchange entries as in k_prep_local (negate | bucket low bits << IB | index).
-// dynamic LDS: (3 * NBP + 1024 + 2 * 16 + 2 + CAP) words, NBP = 2^SH = 1024 / L buckets per partition.
+// dynamic LDS: see k_prep_local_s; NBP = 2^SH = 1024 / L buckets per partition.
 // ---------------------------------------------------------------------------------------------
 constexpr u32 BPS_LANES = 1024, BPS_GROUPS = BPS_LANES / BPL_GROUP;  // lane slots / 64-lane groups per partition
+// Round 3, late: the partition's buckets are ORDERED BY SIZE (descending, counting sort over BPL_BINS size classes, as in
+// k_prep_local_t) before they are laid on the lanes: a group's rows are its largest part, and 32 neighbouring buckets of a
+// uniform 2^16-pair MSM spread over 8 +- 2 entries per part -- 12.4 rows for 8.3 of work; sorted, a group's parts differ by
+// one.  `order[p * NBP + pos]` = the bucket at position pos (k_accum_bps stores there).
+// dynamic LDS: (4 * NBP + 1024 + BPL_BINS + 2 * 16 + 2 + CAP) words.
 __global__ void __launch_bounds__(1024)
     k_prep_local_s(const u32* __restrict__ part_start, const u32* __restrict__ part, MsmGeom g, PrepGeom pg, u32 stride,
-                   u32 log2_l, u32* __restrict__ ents_t, BplGroup* __restrict__ grp, u32* __restrict__ err) {
+                   u32 log2_l, u32* __restrict__ ents_t, BplGroup* __restrict__ grp, u32* __restrict__ order,
+                   u32* __restrict__ err) {
   extern __shared__ u32 prep_lds[];
   const u32 NBP = 1u << pg.SH, L = 1u << log2_l, NG = BPS_GROUPS;
   u32* cnt = prep_lds;        // entries per bucket
   u32* cur = cnt + NBP;       // placement cursor
   u32* beg = cur + NBP;       // first staged entry of the bucket
-  u32* sl = beg + NBP;        // 1024 scan words
-  u32* gm = sl + 1024;        // NG: rows per group
+  u32* ord = beg + NBP;       // bucket at position i of the size order
+  u32* sl = ord + NBP;        // 1024 scan words
+  u32* bins = sl + 1024;      // BPL_BINS size classes: count, then first position
+  u32* gm = bins + BPL_BINS;  // NG: rows per group
   u32* gb = gm + NG;          // NG + 1
   u32* stage = gb + NG + 2;   // CAP entries sorted by bucket
   const u32 p = blockIdx.x, t = threadIdx.x, T = blockDim.x;
@@ -814,6 +822,7 @@ __global__ void __launch_bounds__(1024)
   const u32 low = NBP - 1u, idx_mask = (1u << pg.IB) - 1u;
   const bool fits = n_p <= pg.CAP && (!pg.FIX || n_p <= pg.FIX);
   for (u32 k = t; k < NBP; k += T) cnt[k] = 0;
+  for (u32 k = t; k < BPL_BINS; k += T) bins[k] = 0;
   for (u32 k = t; k < NG; k += T) gm[k] = 0;
   __syncthreads();
   if (fits)
@@ -831,9 +840,11 @@ __global__ void __launch_bounds__(1024)
   if (t < NBP) {
     beg[t] = sl[t] - c_t;
     cur[t] = sl[t] - c_t;
-    // bucket t sits on lanes [t L, (t + 1) L): all in one group when L <= 64; its largest part has ceil(c / L) entries
-    atomicMax(&gm[(t << log2_l) / BPL_GROUP], (c_t + L - 1u) >> log2_l);
   }
+  // size class of my bucket and my rank inside it
+  const u32 bin = min(c_t, BPL_BINS - 1u);
+  u32 rank = 0;
+  if (t < NBP) rank = atomicAdd(&bins[bin], 1u);
   __syncthreads();
   if (fits)
     for (u32 j = ps + t; j < pe; j += T) {
@@ -841,6 +852,26 @@ __global__ void __launch_bounds__(1024)
       const u32 pos = atomicAdd(&cur[(e >> pg.IB) & low], 1u);
       stage[pos] = (e & 0x80000000u) | entry_abs_index(g, e & idx_mask);
     }
+  // descending size order: first position of class b = buckets in larger classes
+  if (t < BPL_BINS) sl[t] = bins[BPL_BINS - 1u - t];
+  __syncthreads();
+  for (u32 d = 1; d < BPL_BINS; d <<= 1) {
+    u32 v = (t < BPL_BINS && t >= d) ? sl[t - d] : 0u;
+    __syncthreads();
+    if (t < BPL_BINS) sl[t] += v;
+    __syncthreads();
+  }
+  if (t < BPL_BINS) bins[BPL_BINS - 1u - t] = sl[t] - bins[BPL_BINS - 1u - t];  // exclusive
+  __syncthreads();
+  if (t < NBP) {
+    const u32 my_pos = bins[bin] + rank;
+    ord[my_pos] = t;
+    order[(size_t)p * NBP + my_pos] = p * NBP + t;
+    // the bucket at position pos sits on lanes [pos L, (pos + 1) L): all in one group (L <= 64); its largest part has
+    // ceil(c / L) entries
+    atomicMax(&gm[(my_pos << log2_l) / BPL_GROUP], (c_t + L - 1u) >> log2_l);
+  }
+  __syncthreads();
   if (t == 0) {
     u32 run = 0;
     for (u32 q = 0; q < NG; q++) {
@@ -864,7 +895,7 @@ __global__ void __launch_bounds__(1024)
     u32 q = 0;
     while (q + 1u < NG && gb[q + 1u] <= j) q++;
     const u32 k = (j - gb[q]) / BPL_GROUP, l = j % BPL_GROUP;
-    const u32 lane = q * BPL_GROUP + l, kb = lane >> log2_l, r = lane & (L - 1u);
+    const u32 lane = q * BPL_GROUP + l, kb = ord[lane >> log2_l], r = lane & (L - 1u);
     const u32 i = (k << log2_l) + r;  // entry i of bucket kb belongs to part i mod L
     ents_t[(size_t)p * stride + j] = i < cnt[kb] ? stage[beg[kb] + i] : BPL_ENTRY_PAD;
   }
