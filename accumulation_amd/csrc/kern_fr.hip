@@ -276,6 +276,7 @@ static bool fr_is_one(const u32 c[8]) {
 }
 
 void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
+  static_assert(TV_PROBE_WORDS == TV_WORDS && TV_EXC_SLOTS == TV_EXC_MAX, "launch.h mirrors vec_kernels.h");
   const u32 blocks = std::max(1u, std::min(512u, (n + 1023u) / 1024u));
   hipLaunchKernelGGL(k_tv_probe, dim3(blocks), dim3(256), 0, st, scalars, n, out16);
 }

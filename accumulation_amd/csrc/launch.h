@@ -69,13 +69,15 @@ template <class Fq>
 bool launch_points_fold_tab(hipStream_t st, const u32* table, u32 stride, u32 c, u32 levels, u32 n, const u32 x_canon[8],
                             u32 nbits, u32* out, u32* xyzz_scratch);
 
-// two-valued vectors (vec_kernels.h k_tv_probe, msm_kernels.h k_tv_sum): exact probe into out[16] (out[0] pre-zeroed), and the
+// two-valued vectors (vec_kernels.h k_tv_probe, msm_kernels.h k_tv_sum): exact probe into TV_PROBE_WORDS zeroed words, and the
 // sum of the generators with non-zero scalars as `blocks` partial records
-void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16);
-// nv <= 8 vectors in one launch: vector v's `blocks` partial records at parts + v * blocks
+void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out_words);  // TV_PROBE_WORDS words, zeroed
+// nv <= 8 vectors in one launch: vector v's `blocks` partial records at parts + v * blocks, its exception records (8 slots of
+// 8 + 2 W words: scalar | generator in the C-ABI radix) at exc + v * 8 slots; probes[v] = the vector's k_tv_probe words
 template <class Fq>
-void launch_tv_sum(hipStream_t st, const u32* table, u32 nv, const u32* const* scalars, const u32* ns, const u32* base_offs,
-                   u32 blocks, u32* parts);
+void launch_tv_sum(hipStream_t st, const u32* table, u32 nv, const u32* const* scalars, const u32* const* probes, const u32* ns,
+                   const u32* base_offs, u32 blocks, u32* parts, u32* exc);
+constexpr u32 TV_PROBE_WORDS = 32, TV_EXC_SLOTS = 8;  // == TV_WORDS / TV_EXC_MAX of vec_kernels.h
 
 // ---- scalar-field (Fr) launchers ----------------------------------------------------------------
 template <class Fr>

@@ -531,26 +531,39 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)set * gridDim.x + blockIdx.x, total);
 }
 
-// Sum of the generators whose scalar is non-zero: the MSM of a two-valued vector up to one scalar multiplication
-// (vec_kernels.h: k_tv_probe verified that every non-zero scalar is the same value).  Lane-strided mixed additions, one
-// partial record per workgroup (k_fold sums them).  blockIdx.y = which of up to TV_BATCH vectors of a call (one launch for all:
-// each is a latency-bound chain of a few additions and a workgroup reduction).
+// Sum of the generators whose scalar equals v: the MSM of a two-valued vector up to one scalar multiplication and its (at most
+// eight) exceptions (vec_kernels.h: k_tv_probe found v and listed them).  Lane-strided mixed additions, one partial record per
+// workgroup (k_fold sums them).  blockIdx.y = which of up to TV_BATCH vectors of a call (one launch for all: each is a
+// latency-bound chain of a few additions and a workgroup reduction).  Workgroup 0 of a vector also copies out its exceptions:
+// record t = the scalar as stored (8 words) | the generator (affine, C-ABI radix).
 constexpr int TV_BATCH = 8;
 struct TvBatch {
   const u32* scalars[TV_BATCH];
+  const u32* probe[TV_BATCH];  // the vector's k_tv_probe words
   u32 n[TV_BATCH];
   u32 base_off[TV_BATCH];
 };
 template <class Fq>
-__global__ void __launch_bounds__(256) k_tv_sum(const u32* __restrict__ table, TvBatch b, u32* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_tv_sum(const u32* __restrict__ table, TvBatch b, u32* __restrict__ out, u32* __restrict__ exc_out) {
   __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
   const u32 v = blockIdx.y, n = b.n[v], base_off = b.base_off[v];
   const uint4* s4 = (const uint4*)b.scalars[v];
+  const u32* pr = b.probe[v];
+  const uint4 va = make_uint4(pr[8], pr[9], pr[10], pr[11]), vb = make_uint4(pr[12], pr[13], pr[14], pr[15]);
   const u32 stride = gridDim.x * 256u;
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
     const uint4 lo = s4[2 * (size_t)i], hi = s4[2 * (size_t)i + 1];
-    if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0u) xyzz_madd<Fq>(acc, affine_load<Fq>(table, (size_t)base_off + i));
+    if (lo.x == va.x && lo.y == va.y && lo.z == va.z && lo.w == va.w && hi.x == vb.x && hi.y == vb.y && hi.z == vb.z && hi.w == vb.w)
+      xyzz_madd<Fq>(acc, affine_load<Fq>(table, (size_t)base_off + i));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < pr[3] && threadIdx.x < 8u) {
+    constexpr u32 REC = 8u + 2u * Fq::W;
+    const u32 j = pr[16u + threadIdx.x];
+    u32* o = exc_out + ((size_t)v * 8u + threadIdx.x) * REC;
+    for (int k = 0; k < 8; k++) o[k] = b.scalars[v][(size_t)j * 8 + k];
+    const Affine<Fq> g = affine_export<Fq>(affine_load<Fq>(table, (size_t)base_off + j));
+    affine_store<Fq>(o + 8, 0, g);
   }
   block_reduce_xyzz<Fq>(acc, lds);
   if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)v * gridDim.x + blockIdx.x, acc);

@@ -526,31 +526,57 @@ __global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ sca
 // Two-valued vectors: is every scalar of the vector 0 or ONE other value v?  (ark-ec's multi_scalar_mul adds the bases of unit
 // scalars directly and skips zero ones -- SURVEY.md App. C; the reference's own harnesses go further: hp_as inputs are
 // `vec![rand; n]` (src/hp_as/mod.rs:189-190) and the DummyCircuit's A z, B z, C z are one value per row plus a zero row
-// (src/r1cs_nark_as/mod.rs:1159-1188), boolean witnesses are {0, 1}.)  Then sum s_i G_i = v * sum_{s_i != 0} G_i: n mixed
+// (src/r1cs_nark_as/mod.rs:1159-1188), boolean witnesses are {0, 1}.)  Then sum s_i G_i = v * sum_{s_i = v} G_i: n mixed
 // additions and one scalar multiplication instead of n windows' worth (k_tv_sum, msm_kernels.h).
-// EXACT test, not a sample: v = the first non-zero scalar among the first TV_HEAD; every lane compares its scalars with 0 and
-// v and raises out[0] on the first that is neither -- a uniform vector ends the kernel after one load per lane.
-// out: [0] mismatch (pre-zeroed by the caller), [1] a non-zero head scalar exists, [2] the head is zero (with [0] == 0: the whole
-// vector is), [8..15] v as stored.
+// Up to TV_EXC_MAX scalars may be something else (the accumulated vectors of the DummyCircuit end in ONE other value where the
+// zero row picked up a blinding term): their indices are listed and the host adds s_j G_j for each.
+// EXACT test, not a sample: v = the majority of the first three non-zero scalars among the first TV_HEAD; every lane compares its
+// scalars with 0 and v; a wave that meets more than TV_EXC_MAX others at once -- any wave of a uniform vector, on its first load --
+// raises out[0] and the kernel ends.
+// out (TV_WORDS words, zeroed by the caller): [0] not of this form, [1] v found, [2] the head is zero (with [0] == 0: the whole
+// vector is), [3] exceptions, [8..15] v as stored, [16..23] the exceptions' indices.
 // ---------------------------------------------------------------------------------------------
-constexpr u32 TV_HEAD = 1024;
+constexpr u32 TV_HEAD = 1024, TV_EXC_MAX = 8, TV_WORDS = 32;
+AMSM_DEV bool tv_words_equal(const u32* a, const u32* b) {
+  bool eq = true;
+#pragma unroll
+  for (int k = 0; k < 8; k++) eq = eq && a[k] == b[k];
+  return eq;
+}
 __global__ void __launch_bounds__(256) k_tv_probe(const u32* __restrict__ scalars, u32 n, u32* __restrict__ out) {
-  __shared__ u32 first;
+  __shared__ u32 cand[3];
+  __shared__ u32 minv;
   __shared__ u32 vw[8];
   const u32 t = threadIdx.x;
-  if (t == 0) first = 0xffffffffu;
-  __syncthreads();
   const uint4* s4 = (const uint4*)scalars;
-  for (u32 i = t; i < TV_HEAD && i < n; i += 256) {
-    const uint4 a = s4[2 * (size_t)i], b = s4[2 * (size_t)i + 1];
-    if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u) {
-      atomicMin(&first, i);
-      break;  // this lane's later candidates have larger indices
+  // which of this lane's (at most four) head scalars are non-zero
+  u32 nz = 0;
+  for (u32 k = 0; k < TV_HEAD / 256u; k++) {
+    const u32 i = t + 256u * k;
+    if (i < n && i < TV_HEAD) {
+      const uint4 a = s4[2 * (size_t)i], b = s4[2 * (size_t)i + 1];
+      if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u) nz |= 1u << k;
     }
   }
-  __syncthreads();
-  const u32 f = first;
-  if (f == 0xffffffffu) {  // head all zero: two-valued only if EVERYTHING is zero (out[2]); a non-zero scalar further on -> out[0]
+  // the three smallest non-zero head indices
+  u32 prev = 0;
+  for (u32 pass = 0; pass < 3u; pass++) {
+    if (t == 0) minv = 0xffffffffu;
+    __syncthreads();
+    for (u32 k = 0; k < TV_HEAD / 256u; k++) {
+      const u32 i = t + 256u * k;
+      if (((nz >> k) & 1u) && (pass == 0u || i > prev)) {
+        atomicMin(&minv, i);
+        break;
+      }
+    }
+    __syncthreads();
+    if (t == 0) cand[pass] = minv;
+    prev = minv;
+    __syncthreads();
+  }
+  const u32 f = cand[0];
+  if (f == 0xffffffffu) {  // head all zero: of this form only if EVERYTHING is zero (out[2]); a non-zero scalar further on -> out[0]
     const u32 stride0 = gridDim.x * 256u;
     volatile u32* bad0 = out;
     for (u32 i = blockIdx.x * 256u + t; i < n; i += stride0) {
@@ -564,23 +590,46 @@ __global__ void __launch_bounds__(256) k_tv_probe(const u32* __restrict__ scalar
     if (blockIdx.x == 0 && t == 0) out[2] = 1u;
     return;
   }
-  if (t < 8) vw[t] = scalars[(size_t)f * 8 + t];
+  if (t == 0) {  // majority of the (up to) three candidates: an odd value FIRST must not be taken for v
+    u32 pick = cand[0];
+    if (cand[1] != 0xffffffffu && cand[2] != 0xffffffffu) {
+      const u32* s0 = scalars + (size_t)cand[0] * 8;
+      const u32* s1 = scalars + (size_t)cand[1] * 8;
+      const u32* s2 = scalars + (size_t)cand[2] * 8;
+      if (!tv_words_equal(s0, s1) && !tv_words_equal(s0, s2) && tv_words_equal(s1, s2)) pick = cand[1];
+    }
+    for (int k = 0; k < 8; k++) vw[k] = scalars[(size_t)pick * 8 + k];
+  }
   __syncthreads();
   const uint4 va = make_uint4(vw[0], vw[1], vw[2], vw[3]), vb = make_uint4(vw[4], vw[5], vw[6], vw[7]);
   if (blockIdx.x == 0 && t < 8) out[8 + t] = vw[t];
   if (blockIdx.x == 0 && t == 0) out[1] = 1u;
-  const u32 stride = gridDim.x * 256u;
+  const u32 stride = gridDim.x * 256u, lane = t & 63u;
   volatile u32* bad = out;
   for (u32 i = blockIdx.x * 256u + t; i < n; i += stride) {
     const uint4 a = s4[2 * (size_t)i], b = s4[2 * (size_t)i + 1];
     const bool zero = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0u;
     const bool same = a.x == va.x && a.y == va.y && a.z == va.z && a.w == va.w && b.x == vb.x && b.y == vb.y && b.z == vb.z &&
                       b.w == vb.w;
-    if (!zero && !same) {
-      out[0] = 1u;
-      return;
+    const bool exc = !zero && !same;
+    const unsigned long long mask = __ballot(exc);  // over the lanes still in the loop
+    if (mask) {
+      const u32 cnt = (u32)__popcll(mask);
+      if (cnt > TV_EXC_MAX) {
+        out[0] = 1u;
+        return;
+      }
+      const u32 leader = (u32)__ffsll((long long)mask) - 1u;
+      u32 base = 0;
+      if (lane == leader) base = atomicAdd(&out[3], cnt);
+      base = (u32)__shfl((int)base, (int)leader, 64);
+      if (base + cnt > TV_EXC_MAX) {
+        out[0] = 1u;
+        return;
+      }
+      if (exc) out[16u + base + (u32)__popcll(mask & ((1ull << lane) - 1ull))] = i;
     }
-    if (*bad) return;  // some lane found a third value: nothing left to learn
+    if (*bad) return;  // some wave gave up: nothing left to learn
   }
 }
 

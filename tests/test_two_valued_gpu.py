@@ -1,8 +1,8 @@
 """Two-valued scalar vectors (every scalar 0 or one value v: the reference harness's `vec![rand; n]` hp_as inputs,
 src/hp_as/mod.rs:189-190, the DummyCircuit's A z / B z / C z, src/r1cs_nark_as/mod.rs:1159-1188, boolean witnesses) take
 v * (sum of the generators with a non-zero scalar) instead of the windowed pipelines.  Same canonical results as the C oracle
-(oracle/ark_msm.c: ark-ec's algorithm) for every shape of such a vector, and vectors that are ALMOST two-valued must not take
-the shortcut."""
+(oracle/ark_msm.c: ark-ec's algorithm) for every shape of such a vector; up to eight scalars may be something else (added one by
+one on the host), more than that -- or anything uniform -- must not take the shortcut."""
 import numpy as np
 import pytest
 
@@ -32,11 +32,24 @@ def _vectors(curve, n):
     out["sparse_one_value"] = (sparse, True)
     out["all_zero"] = (np.zeros((n, 4), dtype=np.uint64), True)   # the identity, nothing launched
     third = const.copy()
-    third[n - 3] = rnd[9]                           # a third value near the end: the probe must see it
-    out["third_value_at_the_end"] = (third, False)
+    third[n - 3] = rnd[9]                           # one other value near the end (the DummyCircuit's blinded zero row): an exception
+    out["one_exception_at_the_end"] = (third, True)
     off_by_one = const.copy()
-    off_by_one[n // 2, 3] ^= np.uint64(1)           # differs in the top word only
-    out["one_scalar_differs_in_its_top_word"] = (off_by_one, False)
+    off_by_one[n // 2, 3] ^= np.uint64(1)           # differs in the top word only: an exception too, never mistaken for v
+    out["one_scalar_differs_in_its_top_word"] = (off_by_one, True)
+    odd_first = const.copy()
+    odd_first[0] = rnd[11]                          # the odd value FIRST: v is the majority of the first three non-zero scalars
+    out["odd_value_first"] = (odd_first, True)
+    eight = dummy.copy()
+    for j, pos in enumerate((1, 70, 4099, n // 3, n // 3 + 1, n // 2 + 17, n - 2000, n - 2)):
+        eight[pos] = rnd[20 + j]                    # eight exceptions, two of them in one wave
+    out["eight_exceptions"] = (eight, True)
+    nine = eight.copy()
+    nine[n // 5] = rnd[40]                          # a ninth, in another wave: over the limit, regular pipelines
+    out["nine_exceptions"] = (nine, False)
+    clump = const.copy()
+    clump[5000:5012] = rnd[50:62]                   # twelve others inside one wave
+    out["twelve_others_in_one_wave"] = (clump, False)
     head_zero = rnd.copy()
     head_zero[:2048] = 0                            # all-zero head: left to the regular pipelines
     out["uniform_behind_a_zero_head"] = (head_zero, False)
