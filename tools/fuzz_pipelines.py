@@ -37,7 +37,8 @@ def ctx_with(curve_id, **env):
 
 def scalars(c, n):
     base = cref.rng_scalars(int(rs.randint(1 << 30)), n)
-    kind = rs.choice(["uniform", "uniform", "share_equal", "few", "small_range", "top", "sparse", "constant", "one_window"])
+    kind = rs.choice(["uniform", "uniform", "share_equal", "few", "small_range", "top", "sparse", "constant", "one_window",
+                      "two_valued_with_exceptions"])
     if kind == "share_equal":
         share = float(rs.choice([1e-5, 1e-4, 1e-3, 0.01, 0.1, 0.5, 0.9]))
         base[rs.rand(n) < share] = base[0]
@@ -57,6 +58,17 @@ def scalars(c, n):
         base[rs.rand(n) >= float(rs.choice([0.01, 0.2]))] = 0
     elif kind == "constant":
         base[:] = base[0]
+    elif kind == "two_valued_with_exceptions":  # 0 / v with 0 .. 12 other values anywhere (<= 8: the two-valued form's exceptions)
+        others = base[1:13].copy()
+        v = base[0].copy()
+        base[:] = v
+        base[rs.rand(n) < float(rs.choice([0.0, 0.3, 0.999]))] = 0
+        k = int(rs.randint(0, 13))
+        if k:
+            pos = rs.randint(0, n, size=k)
+            if rs.rand() < 0.3:
+                pos[: min(k, 3)] = [0, 1, n - 1][: min(k, 3)]
+            base[pos] = others[:k]
     elif kind == "one_window":
         w = int(rs.randint(0, 12))
         limb, sh = (20 * w) // 64, (20 * w) % 64
