@@ -181,8 +181,11 @@ struct amsm_ctx {
   // the IPA opening rounds only -- their scalars are challenge products, uniform by construction, and the call is one blocking
   // MSM (ipa_pc_as 2^16 prove 8.17 -> 7.69 ms); 2 every candidate, behind the skew probe -- pays on uniform vectors (hp_as 2^16
   // prove 1.03 -> 0.85 ms, batches 216 -> 250 M pairs/s) but the probe's synchronisation and the constant vectors of the
-  // reference's DummyCircuit cost r1cs_nark_as at 2^16 more than that (5.2 -> 5.9 ms): not the default
-  int bps = 1;
+  // reference's DummyCircuit cost r1cs_nark_as at 2^16 more than that (5.2 -> 5.9 ms): not the default THEN.  Late in round 3 the
+  // constant vectors take the two-valued form, both probes share one synchronisation, the skew probe leaves at its first skewed
+  // window and skips two-valued vectors: r1cs_nark_as 2^16 harness-zk pays 1.73 -> 1.8 ms, uniform work gains (2^16 batches 199 ->
+  // 228 M pairs/s, hp_as 2^16 n = 2 prove 0.99 -> 0.84 ms) -- and north_star's workload is the uniform one: 2 is the default
+  int bps = 2;  // (late round 3: 2 -- see the comment's last lines)
   unsigned long long n_bps = 0, n_bps_fallbacks = 0;
   bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline
                           // (AMSM_BPL_PROBE=0: find out from the prep's overflow flag only -- the safety net either way)

@@ -128,7 +128,7 @@ int launch_prep(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const P
 
 // *d_flag (zeroed by the caller) = 1 when the vector's c-bit digits look skewed (vec_kernels.h: k_skew_probe)
 template <class Fr>
-void launch_skew_probe(hipStream_t st, const u32* scalars, int mont, u32 n, u32 c, u32 W, u32* d_flag);
+void launch_skew_probe(hipStream_t st, const u32* scalars, int mont, u32 n, u32 c, u32 W, u32* d_flag, const u32* d_tv_words = nullptr);
 template <class Fr>
 void launch_vec_random(hipStream_t st, u32* out, u64 seed, u32 n, int mont);
 template <class Fr>

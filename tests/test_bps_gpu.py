@@ -70,7 +70,7 @@ def test_skewed_vectors_end_up_chunked(cref, probe):
         ctx.close()
 
 
-def test_grouped_msm_takes_it_by_default(cref):
+def test_grouped_and_plain_msms_take_it_by_default(cref):
     """the IPA rounds' form: two sums over index classes in one pass (two bucket sets), default settings"""
     from accumulation_amd import CommitterKey, Context, VariableBaseMSM
     c = o.PALLAS
@@ -88,9 +88,11 @@ def test_grouped_msm_takes_it_by_default(cref):
             sel[((np.arange(n) >> 5) & 1) != g] = 0
             ref, rinf = cref.msm(c.curve_id, xy, sel, threads=8)
             assert bool(infs[g]) == bool(rinf) and np.array_equal(pts[g], ref), g
-        # and a plain MSM of the same size does not (default: grouped only)
-        VariableBaseMSM.multi_scalar_mul(ck, v, mont=True)
-        assert ctx.pipeline_stats()["bucket_split"] == 1
+        # and so does a plain MSM of the same size (default since late round 3: AMSM_BPS=2, behind the skew probe)
+        got, ginf = VariableBaseMSM.multi_scalar_mul(ck, v, mont=True)
+        assert ctx.pipeline_stats()["bucket_split"] == 2
+        ref, rinf = cref.msm(c.curve_id, xy, sc, threads=8)
+        assert bool(ginf) == bool(rinf) and np.array_equal(got, ref)
         ck.free()
     finally:
         ctx.close()
