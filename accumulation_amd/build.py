@@ -37,12 +37,26 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _unit_deps(unit: str, all_deps):
+    """The files a unit really includes (the depfile hipcc wrote on its last compile: -MD), else everything."""
+    dep = os.path.join(OBJ, unit.replace(".hip", ".d"))
+    if not os.path.exists(dep):
+        return all_deps
+    try:
+        words = open(dep).read().replace("\\\n", " ").split()
+    except OSError:
+        return all_deps
+    files = [w for w in words[1:] if not w.endswith(":") and (w.startswith(ROOT) or not os.path.isabs(w))]
+    files = [f if os.path.isabs(f) else os.path.join(ROOT, f) for f in files]
+    return [f for f in files if os.path.exists(f)] or all_deps
+
+
 def _compile(unit: str) -> str:
     src = os.path.join(CSRC, unit)
     obj = os.path.join(OBJ, unit.replace(".hip", ".o"))
     log = obj + ".log"
     extra = os.environ.get("AMSM_EXTRA_FLAGS", "").split()  # e.g. -DAMSM_PALLAS_SAT (A/B of the Pallas field layout)
-    cmd = ["hipcc", *FLAGS, *extra, "-c", src, "-o", obj]
+    cmd = ["hipcc", *FLAGS, *extra, "-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
     with open(log, "w") as lf:
         rc = subprocess.call(cmd, stdout=lf, stderr=subprocess.STDOUT)
     if rc != 0:
@@ -54,7 +68,7 @@ def _compile(unit: str) -> str:
 def build_lib(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     deps = _deps()
-    todo = [u for u in UNITS if force or _stale(os.path.join(OBJ, u.replace(".hip", ".o")), deps)]
+    todo = [u for u in UNITS if force or _stale(os.path.join(OBJ, u.replace(".hip", ".o")), _unit_deps(u, deps))]
     if todo and verbose:
         print(f"[accumulation_amd.build] hipcc --offload-arch={ARCH}: {', '.join(todo)}", flush=True)
     with ThreadPoolExecutor(max_workers=4) as ex:

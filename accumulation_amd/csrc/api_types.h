@@ -154,6 +154,14 @@ struct amsm_ctx {
   hipStream_t stream = nullptr;  // main: the caller's stream -- accumulate L0 and every non-MSM kernel
   hipStream_t s_prep = nullptr;  // digits, sort, bounds, scan (memory-bound)
   hipStream_t s_tail = nullptr;  // fold partials, bucket reduce, fold, D2H (latency-bound)
+  // round 4: the one-lane bucket reduction is a ~0.55 ms chain of dependent point operations WHATEVER the bucket count; with one
+  // tail stream the tails of consecutive MSMs queue behind each other, which bounds a batch of 2^18 / 2^19-pair MSMs (whose
+  // accumulation takes 0.25 / 0.5 ms) at one MSM per 0.6 ms.  Consecutive MSMs alternate between two tail streams
+  // (AMSM_TAIL_STREAMS=1: one, A/B)
+  hipStream_t s_tail2 = nullptr;
+  unsigned tail_rr = 0;
+  int tail_streams = 1;  // (measured, same box: 2^19 batches 697 -> 580 M pairs/s with two, 2^20 unchanged: off)
+  int bpl_wg_per_cu = 0;  // AMSM_BPL_WG_PER_CU: resident k_accum_bpl workgroups per CU for small grids (0 = automatic)
   bool own_stream = false;
   bool custom_prep = true;  // AMSM_PREP=rocprim: digits + rocPRIM radix sort + bounds + rocPRIM scan instead (A/B, fallback)
   int window_override = 0;
@@ -175,6 +183,14 @@ struct amsm_ctx {
   bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
   bool bpl = true;  // keys of 2^20 generators and more are precomputed for 20-bit windows and their MSMs of (2^19, 2^20] pairs
                     // take the bucket-per-lane pipeline (AMSM_BPL=0: 17-bit windows + the chunked pipeline, round 2's path)
+  // round 4: window widths that add up to exactly 256 bits (MsmGeom::n_narrow) -- keys of 2^18 generators and more are
+  // precomputed that way and take the bucket-per-lane pipeline for any range that fills a quarter of their buckets, grouped
+  // MSMs included (AMSM_NARROW=0: round 3's tables -- 20-bit windows with a spread top window from 2^20, 16 bits below)
+  bool narrow = true;
+  bool narrow_mid = false;  // AMSM_NARROW=2: also keys of 2^18 / 2^19 generators (c = 18 / 19; measured slower, api_pipeline.inc)
+  // round 4: plain keys (no precomputed multiples) of 2^16 .. 2^20 pairs take the bucket-per-lane pipeline with one bucket set
+  // per window, longer ones as ranges of 2^20 (AMSM_BPL_PLAIN=0: the chunked pipeline, round 3's path)
+  bool bpl_plain = true;
   bool bpl_mid = false;  // (experiment, off: measured no better than the other pipelines) Pallas keys of 2^16 .. 2^19 generators: 17-bit windows and the bucket-per-lane pipeline for MSMs of
                         // 2^15 .. 2^19 pairs over them (AMSM_BPL_MID=0: round 2's widths and the other pipelines)
   // Bucket-split pipeline for precomputed-key MSMs of 2^16 .. 2^17 pairs (AMSM_BPS): 0 never; 1 (default) the grouped MSMs of
@@ -258,6 +274,7 @@ struct amsm_bases {
   // over `alt`, the same generators precomputed for 17-bit windows, built on first use (under alt_mu: keys are shared)
   int bpl = 0;
   int top_shift = 0;  // MsmGeom::top_shift of the table (level W - 1 = 2^(c (W - 1) - top_shift) G)
+  int n_narrow = 0;   // MsmGeom::n_narrow of the table (level w = 2^(window_exponent) G)
   mutable amsm_bases* alt = nullptr;
   mutable std::mutex alt_mu;
   // sharded key of a multi-device context: shard g (a single-device key on shard_ctx[g]'s device) holds generators

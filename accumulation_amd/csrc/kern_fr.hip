@@ -5,6 +5,7 @@
 #include "prep_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -96,32 +97,36 @@ bool prep_supported(const MsmGeom& g) {
 }
 
 // ---- bucket-per-lane prep (k_prep_local_t): partitions of exactly 1024 buckets, one 1024-lane workgroup each ----
+// words of LDS k_prep_local_t keeps beside its CAP staged entries (the kernel carves the same layout)
+constexpr u32 BPL_LOCAL_FIXED_WORDS = 3u * BPL_NB + 2u * BPL_BINS + 2u * BPL_GROUPS + 2u;
+// round 4: the whole 160 KiB a workgroup may declare (round 3: 148 KiB, and 1792 more fixed words) -- a plain-key MSM of 2^20
+// pairs over 16 bucket sets of 2^15 puts 32 768 entries into a partition, 36 200 into those of the top window on BLS12-381
+constexpr u32 BPL_LOCAL_BUDGET_WORDS = 40960u;
 static PrepGeom prep_bpl_geom(const MsmGeom& g) {
   PrepGeom pg;
   pg.SH = 10;
   pg.P = g.B >> pg.SH;
-  pg.SPB = 512;
-  unsigned long long max_idx = (unsigned long long)g.base_off + g.n - 1ull + (unsigned long long)(g.W - 1u) * g.table_stride;
+  pg.SPB = g.S <= 16u ? 512u : 256u;  // SPB * S <= 8192 staged entries
+  unsigned long long max_idx = (unsigned long long)g.base_off + g.n - 1ull +
+                               (g.precomp ? (unsigned long long)(g.W - 1u) * g.table_stride : 0ull);
   if (g.idx_rel_bits) max_idx = ((unsigned long long)(g.W - 1u) << g.idx_rel_bits) | ((1ull << g.idx_rel_bits) - 1ull);
   pg.IB = 1;
   while ((max_idx >> pg.IB) != 0ull) pg.IB++;
-  const u32 nb = 1u << pg.SH;
-  const u32 budget_words = 37888u, fixed_words = 4u * nb + 1024u + BPL_BINS + 2u * BPL_GROUPS + 2u;
-  pg.CAP = budget_words - fixed_words;  // ~31.4 k entries: a partition of a 2^20-pair MSM holds ~26.6 k
+  pg.CAP = BPL_LOCAL_BUDGET_WORDS - BPL_LOCAL_FIXED_WORDS;  // ~35.3 k entries: a partition of a 2^20-pair MSM holds ~26.6 k
   pg.HEAVY = 0xffffffffu;
   static const bool with_hist = [] { const char* e = getenv("AMSM_BPL_HIST"); return e && atoi(e) != 0; }();  // A/B
-  pg.FIX = with_hist ? 0u : pg.CAP;
+  // fixed partitions: what uniform digits bring plus a quarter and a constant, at most what the LDS stage takes (a partition
+  // beyond it takes the skew fallback either way)
+  const unsigned long long per = std::max<unsigned long long>(((unsigned long long)g.E + pg.P - 1) / std::max(1u, pg.P), g.part_max);
+  pg.FIX = with_hist ? 0u : (u32)std::min<unsigned long long>(pg.CAP, (per + per / 4ull + 2048ull + 15ull) & ~15ull);
   return pg;
 }
-// 8-byte interchange entries the partition pass may write (fixed partitions reserve CAP each)
+// 8-byte interchange entries the partition pass may write (fixed partitions reserve FIX each)
 size_t prep_bpl_part_entries(const MsmGeom& g) {
   PrepGeom pg = prep_bpl_geom(g);
   return std::max<size_t>(g.E, pg.FIX ? (size_t)pg.P * pg.FIX : 0);
 }
-static size_t prep_bpl_local_lds(const PrepGeom& pg) {
-  const u32 nb = 1u << pg.SH;
-  return (size_t)(4u * nb + 1024u + BPL_BINS + 2u * BPL_GROUPS + 2u + pg.CAP) * sizeof(u32);
-}
+static size_t prep_bpl_local_lds(const PrepGeom& pg) { return (size_t)(BPL_LOCAL_FIXED_WORDS + pg.CAP) * sizeof(u32); }
 static size_t prep_bpl_scatter_lds(const MsmGeom& g, const PrepGeom& pg) {
   const size_t cap = (size_t)pg.SPB * g.S;
   return (3 * (size_t)pg.P + 2 * cap) * sizeof(u32) + cap * sizeof(uint16_t);
@@ -132,16 +137,19 @@ u32 prep_bpl_groups_per_partition() { return BPL_GROUPS; }  // 17 groups of 64 l
 // on uniform digits) + a constant; anything that does not fit is a skewed input and takes the fallback
 u32 prep_bpl_stride(const MsmGeom& g) {
   const u32 P = std::max(1u, prep_bpl_partitions(g));
-  const unsigned long long per = ((unsigned long long)g.E + P - 1) / P;
+  const unsigned long long per = std::max<unsigned long long>(((unsigned long long)g.E + P - 1) / P, g.part_max);
   return (u32)((per + per / 4ull + 4096ull + 1023ull) & ~1023ull);
 }
 bool prep_bpl_supported(const MsmGeom& g) {
-  if (!g.precomp || g.n_sets != g.groups || g.S > 16u || g.n == 0) return false;  // one bucket set per group (precomputed key)
+  // one bucket set per group over a precomputed key, W per group over a plain one (round 4); <= 16 entry slots per scalar
+  if (g.S > 32u || g.n == 0 || g.n_sets != g.groups * sets_per_group(g)) return false;
   if (g.B < (1u << 16) || (g.B & 1023u) || (g.B >> 10) > PREP_MAX_P || ((g.B >> 10) & 3u)) return false;
   PrepGeom pg = prep_bpl_geom(g);
   if (pg.IB > 30u) return false;
-  // the expected partition must fit the LDS stage with room for the digits' spread (sigma ~ 180 entries at 30 k)
+  // the expected partition -- the fullest one -- must fit the LDS stage with room for the digits' spread (sigma ~ 180 entries at
+  // 30 k: 1024 on the average partition, 5 sigma on the fullest)
   if ((unsigned long long)g.E / pg.P + 1024ull > pg.CAP) return false;
+  if (g.part_max && (unsigned long long)g.part_max + 5ull * (unsigned long long)std::sqrt((double)g.part_max) > pg.CAP) return false;
   return prep_bpl_scatter_lds(g, pg) <= PREP_LDS_LIMIT && prep_bpl_local_lds(pg) <= PREP_LDS_LIMIT &&
          (unsigned long long)pg.P * prep_bpl_stride(g) < (1ull << 31);
 }
@@ -153,11 +161,18 @@ static void prep_bpl_attr(KS scatter_kernel) {
   const unsigned long long bit = 1ull << dev;
   (void)hipFuncSetAttribute((const void*)scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_LDS_LIMIT);
   if (dev != 63 && (prep_bpl_attr_devices.load(std::memory_order_acquire) & bit)) return;
-  (void)hipFuncSetAttribute((const void*)k_prep_local_t, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  static_assert((BPL_LOCAL_BUDGET_WORDS) * sizeof(u32) <= PREP_LDS_LIMIT, "k_prep_local_t's LDS must fit a workgroup");
+  (void)hipFuncSetAttribute((const void*)k_prep_local_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_LDS_LIMIT);
   prep_bpl_attr_devices.fetch_or(bit, std::memory_order_release);
 }
 
 // ---- bucket-split prep (k_prep_local_s): partitions of 1024 / L buckets = 1024 lanes, 32-bit interchange entries ----
+// words of LDS k_prep_local_s keeps beside its CAP staged entries: cnt / cur / beg / ord (4 NBP), 1024 scan words, the size
+// classes, rows and bases of the 16 groups -- ONE expression for the geometry, the launch size and the kernel's carving
+// (round 3 budgeted 3 NBP + 1024 + 34 after the size ordering had added NBP + BPL_BINS: the top of stage[] lay past the
+// allocation, reachable once a partition held more than CAP - NBP - 256 entries)
+constexpr u32 bps_local_fixed_words(u32 nbp) { return 4u * nbp + 1024u + BPL_BINS + 2u * BPS_GROUPS + 2u; }
+constexpr u32 BPS_LOCAL_BUDGET_WORDS = 37888u;  // 148 KiB
 static PrepGeom prep_bps_geom(const MsmGeom& g, u32 log2_l) {
   PrepGeom pg;
   pg.SH = 10u - log2_l;
@@ -168,9 +183,7 @@ static PrepGeom prep_bps_geom(const MsmGeom& g, u32 log2_l) {
   if (g.idx_rel_bits) max_idx = ((unsigned long long)(g.W - 1u) << g.idx_rel_bits) | ((1ull << g.idx_rel_bits) - 1ull);
   pg.IB = 1;
   while ((max_idx >> pg.IB) != 0ull) pg.IB++;
-  const u32 nbp = 1u << pg.SH;
-  const u32 budget_words = 37888u, fixed_words = 3u * nbp + 1024u + 2u * BPS_GROUPS + 2u;
-  pg.CAP = budget_words - fixed_words;
+  pg.CAP = BPS_LOCAL_BUDGET_WORDS - bps_local_fixed_words(1u << pg.SH);
   pg.HEAVY = 0xffffffffu;
   // fixed partitions (PrepGeom::FIX): half as much again as a uniform partition holds, at most what the LDS stage takes
   static const bool with_hist = [] { const char* e = getenv("AMSM_BPS_HIST"); return e && atoi(e) != 0; }();  // A/B
@@ -184,7 +197,7 @@ size_t prep_bps_part_entries(const MsmGeom& g, u32 log2_l) {
   return std::max<size_t>(g.E, pg.FIX ? (size_t)pg.P * pg.FIX : 0);
 }
 static size_t prep_bps_local_lds(const PrepGeom& pg) {
-  return (size_t)(3u * (1u << pg.SH) + 1024u + 2u * BPS_GROUPS + 2u + pg.CAP) * sizeof(u32);
+  return (size_t)(bps_local_fixed_words(1u << pg.SH) + pg.CAP) * sizeof(u32);
 }
 u32 prep_bps_partitions(const MsmGeom& g, u32 log2_l) { return g.B >> (10u - log2_l); }
 u32 prep_bps_stride(const MsmGeom& g, u32 log2_l) {
@@ -220,6 +233,7 @@ static void prep_bps_attr() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
   const unsigned long long bit = 1ull << dev;
   if (dev != 63 && (prep_bps_attr_devices.load(std::memory_order_acquire) & bit)) return;
+  static_assert(BPS_LOCAL_BUDGET_WORDS * sizeof(u32) <= 152 * 1024, "k_prep_local_s's LDS must fit its attribute");
   (void)hipFuncSetAttribute((const void*)k_prep_local_s, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
   prep_bps_attr_devices.fetch_or(bit, std::memory_order_release);
 }
@@ -401,7 +415,8 @@ void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
       if (b.err != b.d_small - 16) return -1;                                                                        \
       if (hipMemsetAsync(b.err, 0, zero_bytes, st) != hipSuccess) return -1;                                         \
     }                                                                                                                \
-    prep_bpl_attr(k_prep_scatter<FR, 16, 1, true>);                                                                  \
+    if (g.S <= 16u) prep_bpl_attr(k_prep_scatter<FR, 16, 1, true>);                                                  \
+    else prep_bpl_attr(k_prep_scatter<FR, 32, 1, true>);                                                             \
     if (!pg.FIX) {                                                                                                   \
       PrepGeom ph = pg;                                                                                              \
       ph.SPB = 1024;                                                                                                 \
@@ -409,8 +424,12 @@ void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
                          mont, g, ph, part_total, b.err);                                                            \
       hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, part_total, part_start, pg.P, pg.HEAVY, hv);       \
     }                                                                                                                \
-    hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1, true>), dim3(cdiv_(g.n, pg.SPB)), dim3(512),                       \
-                       prep_bpl_scatter_lds(g, pg), st, scalars, mont, g, pg, part_start, part_cursor, b.part, b.err); \
+    if (g.S <= 16u)                                                                                                  \
+      hipLaunchKernelGGL((k_prep_scatter<FR, 16, 1, true>), dim3(cdiv_(g.n, pg.SPB)), dim3(512),                     \
+                         prep_bpl_scatter_lds(g, pg), st, scalars, mont, g, pg, part_start, part_cursor, b.part, b.err); \
+    else /* plain keys with 18 / 19 windows: 256 scalars per workgroup */                                            \
+      hipLaunchKernelGGL((k_prep_scatter<FR, 32, 1, true>), dim3(cdiv_(g.n, pg.SPB)), dim3(256),                     \
+                         prep_bpl_scatter_lds(g, pg), st, scalars, mont, g, pg, part_start, part_cursor, b.part, b.err); \
     hipLaunchKernelGGL(k_prep_local_t, dim3(pg.P), dim3(1024), prep_bpl_local_lds(pg), st,                           \
                        pg.FIX ? part_cursor : part_start, (const u64*)b.part, g, pg, prep_bpl_stride(g), b.ents_t,   \
                        (BplGroup*)b.grp, b.order, b.err);                                                            \
@@ -427,9 +446,10 @@ void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
                          vals, err);                                                                                 \
   }                                                                                                                  \
   template <>                                                                                                        \
-  void launch_skew_probe<FR>(hipStream_t st, const u32* scalars, int mont, u32 n, u32 c, u32 W, u32* d_flag,         \
-                             const u32* d_tv_words) {                                                               \
-    hipLaunchKernelGGL((k_skew_probe<FR>), dim3(1), dim3(1024), 0, st, scalars, mont, n, c, W, d_flag, d_tv_words);  \
+  void launch_skew_probe<FR>(hipStream_t st, const u32* scalars, int mont, u32 n, u32 c, u32 W, u32 n_narrow,        \
+                             u32* d_flag, const u32* d_tv_words) {                                                  \
+    hipLaunchKernelGGL((k_skew_probe<FR>), dim3(1), dim3(1024), 0, st, scalars, mont, n, c, W, n_narrow, d_flag,     \
+                       d_tv_words);                                                                                  \
   }                                                                                                                  \
   template <>                                                                                                        \
   void launch_vec_random<FR>(hipStream_t st, u32* out, u64 seed, u32 n, int mont) {                                  \

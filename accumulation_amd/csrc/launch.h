@@ -15,7 +15,7 @@ void launch_accum_l0(hipStream_t st, const u32* table, const u32* vals_sorted, c
 // bucket-per-lane accumulation (msm_kernels.h: k_accum_bpl) over the transposed layout k_prep_local_t wrote
 template <class Fq>
 void launch_accum_bpl(hipStream_t st, const u32* table, const u32* ents_t, const void* grp, const u32* order, u32 n_groups,
-                      u32 groups_per_part, const u32* flags, u32* buckets);
+                      u32 groups_per_part, const u32* flags, u32* buckets, u32 wg_per_cu = 0);
 // resident 256-lane workgroups of accumulate L0 per CU (occupancy query); lds_pad = unused dynamic LDS per workgroup,
 // which caps the residency (AMSM_L0_LDS_PAD: leaves wave slots / registers to the kernels of the other MSMs in flight)
 template <class Fq>
@@ -63,11 +63,12 @@ template <class Fq>
 void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const u32 x_canon[8], u32 nbits, u32* out,
                         bool abi_radix, u32* xyzz_scratch);
 
-// Fold of a key that carries window multiples (table level w at w * stride points, = 2^(c w) G; levels 0 .. levels-1 usable):
-// out[i] = table[i] + x * table[n + i], i < n.  False (nothing launched) when x does not fit the usable levels.
+// Fold of a key that carries window multiples (table level w at w * stride points, = 2^(e_w) G with e_w =
+// window_exponent_of(c, W, n_narrow, 0, w); levels 0 .. levels-1 usable): out[i] = table[i] + x * table[n + i], i < n.  False
+// (nothing launched) when x does not fit the usable levels.
 template <class Fq>
-bool launch_points_fold_tab(hipStream_t st, const u32* table, u32 stride, u32 c, u32 levels, u32 n, const u32 x_canon[8],
-                            u32 nbits, u32* out, u32* xyzz_scratch);
+bool launch_points_fold_tab(hipStream_t st, const u32* table, u32 stride, u32 c, u32 W, u32 n_narrow, u32 levels, u32 n,
+                            const u32 x_canon[8], u32 nbits, u32* out, u32* xyzz_scratch);
 
 // two-valued vectors (vec_kernels.h k_tv_probe, msm_kernels.h k_tv_sum): exact probe into TV_PROBE_WORDS zeroed words, and the
 // sum of the generators with non-zero scalars as `blocks` partial records
@@ -128,7 +129,8 @@ int launch_prep(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const P
 
 // *d_flag (zeroed by the caller) = 1 when the vector's c-bit digits look skewed (vec_kernels.h: k_skew_probe)
 template <class Fr>
-void launch_skew_probe(hipStream_t st, const u32* scalars, int mont, u32 n, u32 c, u32 W, u32* d_flag, const u32* d_tv_words = nullptr);
+void launch_skew_probe(hipStream_t st, const u32* scalars, int mont, u32 n, u32 c, u32 W, u32 n_narrow, u32* d_flag,
+                       const u32* d_tv_words = nullptr);
 template <class Fr>
 void launch_vec_random(hipStream_t st, u32* out, u64 seed, u32 n, int mont);
 template <class Fr>

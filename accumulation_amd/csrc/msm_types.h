@@ -37,10 +37,23 @@ struct MsmGeom {
   u32 n_chunks;      // work items of accumulate L0 (upper bound: sized for E entries)
   u32 l0_per_cu;     // host only: resident accumulate-L0 workgroups per CU to enforce for this launch (0 = natural occupancy)
   u32 K1;            // max partials folded by one L1 lane
+  u32 top_split;     // plain keys on the bucket-per-lane pipeline (round 4): the TOP window owns two bucket sets, the scalars with an
+                     // even index feed the first, the odd ones the second (the host adds the two sums) -- its digits reach only
+                     // r / 2^256 of their range and carry no sign to fold, so its partitions run 10 % fuller than the others' on
+                     // uniform BLS12-381 scalars and twice as full on 254-bit ones (the synthetic stream of rng.h); sets per group
+                     // = W + top_split
+  u32 part_max;      // host only (bucket-per-lane prep): entries the fullest partition is expected to hold on uniform scalars -- the
+                     // top window's digits cover only r / 2^256 of its range (no sign to fold), 10 % denser than the others'
+                     // on BLS12-381; a plain key gives that window a bucket set of its own
   u32 top_shift;     // s > 0 (bucket-per-lane keys): the TOP window holds only 255 - c (W - 1) scalar bits, so its digits would all
                      // fall into the lowest 2^(that - 1) buckets -- a sixteenth of the partitions would receive a whole window.
                      // Its table level is 2^(c (W - 1) - s) G instead and its digit is shifted left by s: the same product, spread
                      // over every 2^s-th bucket of the whole range (raw digit <= 2^(c - 1 - s): never negative, no carry out)
+  u32 n_narrow;      // round 4: the TOP n_narrow windows are c - 1 bits wide, so that the W widths add up to EXACTLY 256 bits (W c - 256
+                     // narrow ones): every window is full -- no short top window -- and the recoding never carries out of the top.
+                     // A narrow window's signed digit is DOUBLED (it lands on the even buckets of the full range) and what it
+                     // multiplies stands one doubling short: table level w = 2^(e_w) G (precomputed key) / the set's sum counts
+                     // 2^(e_w) (plain key), e_w = window_exponent().  0: the legacy walk (equal widths, top_shift)
   u32 bpl;           // 1: bucket-per-lane pipeline (k_prep_local_t + k_accum_bpl; 20-bit windows), 2: bucket-split pipeline
                      // (k_prep_local_s + k_accum_bps; small and medium MSMs), 0: chunked pipeline
   u32 bps_log2_l;    // bucket-split: log2 of the lanes per bucket
@@ -54,6 +67,30 @@ struct MsmGeom {
 #else
 #define AMSM_GEOM_FN inline
 #endif
+// width of window w, and the power of two its digit multiplies (MsmGeom::n_narrow, MsmGeom::top_shift)
+AMSM_GEOM_FN u32 window_bits_of(u32 c, u32 W, u32 n_narrow, u32 w) { return c - ((w + n_narrow >= W) ? 1u : 0u); }
+// first bit of window w
+AMSM_GEOM_FN u32 window_position_of(u32 c, u32 W, u32 n_narrow, u32 w) {
+  const u32 R = W - n_narrow;  // regular windows
+  return w < R ? w * c : R * c + (w - R) * (c - 1u);
+}
+AMSM_GEOM_FN u32 window_exponent_of(u32 c, u32 W, u32 n_narrow, u32 top_shift, u32 w) {
+  // the window's position, minus the doubling a narrow window's digit carries, minus the top window's spread
+  return window_position_of(c, W, n_narrow, w) - ((w + n_narrow >= W) ? 1u : 0u) - ((w == W - 1u) ? top_shift : 0u);
+}
+AMSM_GEOM_FN u32 window_exponent(const MsmGeom& g, u32 w) { return window_exponent_of(g.c, g.W, g.n_narrow, g.top_shift, w); }
+// narrow windows a width-c walk over 256 bits needs (0 when the widths divide evenly; ~0u when c - 1 is not narrow enough)
+AMSM_GEOM_FN u32 narrow_windows_for(u32 c) {
+  const u32 W = 255u / c + 1u, nn = W * c - 256u;
+  return nn < W ? nn : ~0u;
+}
+// bucket sets per group / the set window w of scalar i feeds, relative to its group's first
+AMSM_GEOM_FN u32 sets_per_group(const MsmGeom& g) { return g.precomp ? 1u : g.W + g.top_split; }
+AMSM_GEOM_FN u32 window_set(const MsmGeom& g, u32 w, u32 i) {
+  // (the bit that splits the top window must not be the bit that picks the group: a group would feed ONE of its two top sets)
+  const u32 sb = (g.groups > 1u && g.group_shift == 0u) ? 1u : 0u;
+  return g.precomp ? 0u : w + ((g.top_split && w == g.W - 1u) ? ((i >> sb) & 1u) : 0u);
+}
 // interchange index -> table index (see idx_rel_bits)
 AMSM_GEOM_FN u32 entry_abs_index(const MsmGeom& g, u32 v) {
   return g.idx_rel_bits ? (g.base_off + (v & ((1u << g.idx_rel_bits) - 1u)) + (v >> g.idx_rel_bits) * g.table_stride) : v;

@@ -24,6 +24,7 @@
 #pragma once
 #include "fp.h"
 #include "msm_types.h"
+#include "vec_kernels.h"  // digit_step
 
 namespace amsm {
 
@@ -78,7 +79,7 @@ AMSM_DEV u32 lds_count(u32* ctr, u32 idx) {
   return atomicAdd(&ctr[idx], 1u);
 }
 
-// Calls f(key, value) for every non-zero signed c-bit digit of scalar i; returns non-zero when the scalar does not
+// Calls f(key, value) for every non-zero signed digit of scalar i; returns non-zero when the scalar does not
 // fit W windows (caller reports AMSM_E_SCALAR_RANGE).  key = bucket id, value = sign | index into the key table.
 // (An unsigned top window -- W = ceil(255 / c) windows, the digit excess over the bucket count as a second entry --
 // was built and measured: c = 17 / W = 15 is no faster than c = 16 / W = 16 at any size, and the extra branch in the
@@ -87,33 +88,14 @@ template <class Fr, class F>
 AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const MsmGeom& g, u32 i, F&& f) {
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
   if (mont) s = fe_from_mont<Fr>(s);
-  const u32 c = g.c;
-  const u32 mask = (1u << c) - 1u;
-  const u32 half = 1u << (c - 1);
   // first bucket set of this scalar's group (grouped MSM: two sums over index classes in one pass)
-  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W);
+  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * sets_per_group(g);
   u32 carry = 0;
   for (u32 w = 0; w < g.W; w++) {
-    u32 raw = (s.v[0] & mask) + carry;
-#pragma unroll
-    for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
-    s.v[7] >>= c;
-    u32 set = set0 + (g.precomp ? 0u : w);
+    u32 neg;
+    const u32 d = digit_step<Fr>(s, g.c, g.W, g.n_narrow, g.top_shift, w, carry, neg);
+    u32 set = set0 + window_set(g, w, i);
     u32 idx = g.idx_rel_bits ? ((w << g.idx_rel_bits) | i) : g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
-    u32 neg = 0;
-    carry = 0;
-    u32 d = raw;
-    if (g.top_shift && w == g.W - 1u) {
-      d = raw << g.top_shift;  // MsmGeom::top_shift: the short top window, spread over the bucket range
-      if (d > half) {          // only a non-canonical scalar gets here: reported, no entry
-        carry = 1;             // (makes `rest` non-zero below)
-        d = 0;
-      }
-    } else if (raw > half) {
-      d = (1u << c) - raw;
-      neg = 1;
-      carry = 1;
-    }
     if (d != 0) f(set * g.nb + (d - 1), idx | (neg << 31));
   }
   u32 rest = carry;
@@ -122,76 +104,21 @@ AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const Msm
   return rest;
 }
 
-// Same walk with the window loop unrolled to MAXW (>= g.W): f(w, key, value) sees w as an unrolled index, so callers
-// can keep per-window state in registers.
-template <class Fr, int MAXW, class F>
-AMSM_DEV void scalar_entries_unrolled(const u32* __restrict__ scalars, int mont, const MsmGeom& g, u32 i, F&& f) {
-  Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
-  if (mont) s = fe_from_mont<Fr>(s);
-  const u32 c = g.c;
-  const u32 mask = (1u << c) - 1u;
-  const u32 half = 1u << (c - 1);
-  // first bucket set of this scalar's group (grouped MSM: two sums over index classes in one pass)
-  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W);
-  u32 carry = 0;
-#pragma unroll
-  for (int w = 0; w < MAXW; w++) {
-    if ((u32)w < g.W) {
-      u32 raw = (s.v[0] & mask) + carry;
-#pragma unroll
-      for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
-      s.v[7] >>= c;
-      u32 set = set0 + (g.precomp ? 0u : (u32)w);
-      u32 idx = g.idx_rel_bits ? (((u32)w << g.idx_rel_bits) | i) : g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
-      u32 neg = 0;
-      carry = 0;
-      u32 d = raw;
-      if (g.top_shift && (u32)w == g.W - 1u) {
-        d = raw << g.top_shift;  // MsmGeom::top_shift
-        if (d > half) d = 0;     // non-canonical scalar: k_prep_hist's walk reports it
-      } else if (raw > half) {
-        d = (1u << c) - raw;
-        neg = 1;
-        carry = 1;
-      }
-      if (d != 0) f(w, set * g.nb + (d - 1), idx | (neg << 31));
-    }
-  }
-}
-
-// The same walk over a scalar already in registers (canonical form): k_prep_scatter walks every scalar twice and keeps
-// it (8 registers) instead of loading -- and converting from Montgomery form -- a second time.
+// The same walk over a scalar already in registers (canonical form), the window loop unrolled to MAXW (>= g.W): f(w, key,
+// value) sees w as an unrolled index, so callers can keep per-window state in registers.  k_prep_scatter walks every scalar
+// twice and keeps it (8 registers) instead of loading -- and converting from Montgomery form -- a second time.
 // Returns non-zero when the scalar does not fit W windows, like scalar_entries (callers that walk twice ignore it once).
 template <class Fr, int MAXW, class F>
 AMSM_DEV u32 scalar_entries_unrolled_reg(Fe<Fr> s, const MsmGeom& g, u32 i, F&& f) {
-  const u32 c = g.c;
-  const u32 mask = (1u << c) - 1u;
-  const u32 half = 1u << (c - 1);
-  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W);
+  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * sets_per_group(g);
   u32 carry = 0;
 #pragma unroll
   for (int w = 0; w < MAXW; w++) {
     if ((u32)w < g.W) {
-      u32 raw = (s.v[0] & mask) + carry;
-#pragma unroll
-      for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
-      s.v[7] >>= c;
-      u32 set = set0 + (g.precomp ? 0u : (u32)w);
+      u32 neg;
+      const u32 d = digit_step<Fr>(s, g.c, g.W, g.n_narrow, g.top_shift, (u32)w, carry, neg);
+      u32 set = set0 + window_set(g, (u32)w, i);
       u32 idx = g.idx_rel_bits ? (((u32)w << g.idx_rel_bits) | i) : g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
-      u32 neg = 0;
-      carry = 0;
-      u32 d = raw;
-      if (g.top_shift && (u32)w == g.W - 1u) {
-        d = raw << g.top_shift;  // MsmGeom::top_shift
-        if (d > half) {          // non-canonical scalar: reported, no entry
-          d = 0;
-          carry = 1;
-        }
-      } else if (raw > half) {
-        d = (1u << c) - raw;
-        neg = 1;
-        carry = 1;
-      }
       if (d != 0) f(w, set * g.nb + (d - 1), idx | (neg << 31));
     }
   }
@@ -664,28 +591,30 @@ AMSM_DEV void bpl_slot(u32 s, u32& pos, u32& half) {
   }
 }
 
-// dynamic LDS: (4 * NB + 1024 + BPL_BINS + 2 * BPL_GROUPS + 2 + CAP) words, NB = 2^SH = 1024
+// dynamic LDS: (3 * NB + 2 * BPL_BINS + 2 * BPL_GROUPS + 2 + CAP) words, NB = 2^SH = 1024 (kern_fr.hip: BPL_LOCAL_FIXED_WORDS).
+// Round 4: the 1024 scan words of the bucket-size prefix live in the (still empty) entry stage and a bucket's first staged
+// entry is its cursor's final value minus its count -- 1792 words more for entries.
 __global__ void __launch_bounds__(1024)
     k_prep_local_t(const u32* __restrict__ part_start, const u64* __restrict__ part, MsmGeom g, PrepGeom pg, u32 stride,
                    u32* __restrict__ ents_t, BplGroup* __restrict__ grp, u32* __restrict__ order, u32* __restrict__ err) {
   extern __shared__ u32 prep_lds[];
   const u32 NB = BPL_NB, NG = BPL_GROUPS;
   u32* cnt = prep_lds;            // entries per bucket
-  u32* cur = cnt + NB;            // placement cursor
-  u32* beg = cur + NB;            // first staged entry of the bucket
-  u32* ord = beg + NB;            // bucket at position i of the size order
-  u32* sl = ord + NB;             // 1024 scan words
-  u32* bins = sl + 1024;          // BPL_BINS size classes: count, then first position
-  u32* gm = bins + BPL_BINS;      // NG: rows per group
+  u32* cur = cnt + NB;            // placement cursor: the bucket's first staged entry, after the placement its end
+  u32* ord = cur + NB;            // bucket at position i of the size order
+  u32* bins = ord + NB;           // BPL_BINS size classes: count, then first position
+  u32* bscan = bins + BPL_BINS;   // BPL_BINS scan words of the size-class prefix
+  u32* gm = bscan + BPL_BINS;     // NG: rows per group
   u32* gb = gm + NG;              // NG + 1: first entry of the group inside the partition's block
   u32* stage = gb + NG + 1;       // CAP sorted entries
+  u32* sl = stage;                // 1024 scan words of the bucket-size prefix: done before the first entry is staged
   const u32 p = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   // fixed partitions (PrepGeom::FIX): `part_start` is the scatter's CURSOR array -- entries reserved, possibly more than fit
   const u32 ps = pg.FIX ? p * pg.FIX : part_start[p];
   const u32 n_p = pg.FIX ? part_start[p] : part_start[p + 1] - ps;
   const u32 pe = ps + (pg.FIX ? min(n_p, pg.FIX) : n_p);
   const u32 low = NB - 1u, idx_mask = (1u << pg.IB) - 1u, b0 = p << pg.SH;
-  const bool fits = n_p <= pg.CAP;
+  const bool fits = n_p <= pg.CAP && (!pg.FIX || n_p <= pg.FIX);  // (beyond FIX the scatter dropped entries)
   for (u32 k = t; k < NB; k += T) cnt[k] = 0;
   for (u32 k = t; k < BPL_BINS; k += T) bins[k] = 0;
   for (u32 k = t; k < NG; k += T) gm[k] = 0;
@@ -703,15 +632,12 @@ __global__ void __launch_bounds__(1024)
     sl[t] += v;
     __syncthreads();
   }
-  if (t < NB) {
-    beg[t] = sl[t] - c_t;
-    cur[t] = sl[t] - c_t;
-  }
+  if (t < NB) cur[t] = sl[t] - c_t;
   // size class of my bucket and my rank inside it
   const u32 bin = min(c_t, BPL_BINS - 1u);
   u32 rank = 0;
   if (t < NB) rank = atomicAdd(&bins[bin], 1u);
-  __syncthreads();
+  __syncthreads();  // (every lane has read its sl[t]: the stage may be written)
   // entries to their bucket's run (order inside a bucket is arbitrary: the sum does not depend on it)
   if (fits)
     for (u32 j = ps + t; j < pe; j += T) {
@@ -721,15 +647,15 @@ __global__ void __launch_bounds__(1024)
       stage[pos] = (lo & 0x80000000u) | entry_abs_index(g, lo & idx_mask);
     }
   // descending size order: first position of class b = buckets in larger classes
-  if (t < BPL_BINS) sl[t] = bins[BPL_BINS - 1u - t];  // reversed, so that an inclusive scan counts the larger classes
+  if (t < BPL_BINS) bscan[t] = bins[BPL_BINS - 1u - t];  // reversed, so that an inclusive scan counts the larger classes
   __syncthreads();
   for (u32 d = 1; d < BPL_BINS; d <<= 1) {
-    u32 v = (t < BPL_BINS && t >= d) ? sl[t - d] : 0u;
+    u32 v = (t < BPL_BINS && t >= d) ? bscan[t - d] : 0u;
     __syncthreads();
-    if (t < BPL_BINS) sl[t] += v;
+    if (t < BPL_BINS) bscan[t] += v;
     __syncthreads();
   }
-  if (t < BPL_BINS) bins[BPL_BINS - 1u - t] = sl[t] - bins[BPL_BINS - 1u - t];  // exclusive
+  if (t < BPL_BINS) bins[BPL_BINS - 1u - t] = bscan[t] - bins[BPL_BINS - 1u - t];  // exclusive
   __syncthreads();
   u32 my_pos = 0;
   if (t < NB) {
@@ -754,6 +680,9 @@ __global__ void __launch_bounds__(1024)
   const u32 total = gb[NG];
   const bool ok = fits && total <= stride;
   if (!ok && t == 0) atomicOr(err + 1, 1u);  // overflow: the host falls back to the chunked pipeline
+#ifdef AMSM_PREP_DEBUG
+  if (!ok && t == 0) printf("[k_prep_local_t] partition %u: %u entries (FIX %u CAP %u), padded %u of stride %u, rows %u .. %u\n", p, n_p, pg.FIX, pg.CAP, total, stride, gm[0], gm[NG - 1u]);
+#endif
   if (t < NG) {
     BplGroup h;
     h.base = p * stride + gb[t];
@@ -775,7 +704,7 @@ __global__ void __launch_bounds__(1024)
     bpl_slot(q * BPL_GROUP + l, pos, half);
     const u32 kb = ord[pos], c = cnt[kb], h0 = (c + 1u) >> 1;
     const u32 off = half == 2u ? h0 : 0u, sz = half == 0u ? c : (half == 1u ? h0 : c - h0);
-    ents_t[(size_t)p * stride + j] = k < sz ? stage[beg[kb] + off + k] : BPL_ENTRY_PAD;
+    ents_t[(size_t)p * stride + j] = k < sz ? stage[cur[kb] - c + off + k] : BPL_ENTRY_PAD;  // (cur = the bucket's end now)
   }
 }
 

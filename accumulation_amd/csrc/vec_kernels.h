@@ -14,6 +14,36 @@
 
 namespace amsm {
 
+// One window of the signed-digit walk: takes the low bits of s, returns the bucket digit d (0: none) and its sign, leaves the
+// recoding's carry for the next window and shifts s.  Window w is c bits wide, or c - 1 (MsmGeom::n_narrow: the top windows,
+// digit doubled); the legacy short top window of a top_shift key is spread by its shift.  A scalar that does not fit the
+// windows (non-canonical: >= 2^255) leaves carry = 1 behind the last window -- the callers' `rest`.
+template <class Fr>
+AMSM_DEV u32 digit_step(Fe<Fr>& s, u32 c, u32 W, u32 n_narrow, u32 top_shift, u32 w, u32& carry, u32& neg) {
+  const u32 narrow = (w + n_narrow >= W) ? 1u : 0u;  // uniform over the grid
+  const u32 cw = c - narrow;
+  const u32 raw = (s.v[0] & ((1u << cw) - 1u)) + carry;
+#pragma unroll
+  for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> cw) | (s.v[k + 1] << (32 - cw));
+  s.v[7] >>= cw;
+  neg = 0;
+  carry = 0;
+  u32 d = raw;
+  if (top_shift && w == W - 1u) {
+    d = raw << (narrow + top_shift);  // MsmGeom::top_shift: the top window (never negative), spread over the bucket range
+    if (d > (1u << (c - 1))) {         // only a non-canonical scalar gets here: reported, no entry
+      carry = 1;
+      d = 0;
+    }
+    return d;
+  } else if (raw > (1u << (cw - 1))) {
+    d = (1u << cw) - raw;
+    neg = 1;
+    carry = 1;
+  }
+  return d << narrow;
+}
+
 
 // The three streaming kernels below run as a grid-stride loop over a grid sized to the resident wave slots, with the NEXT
 // element's operands loaded before the current element's multiplications (register double buffering): with one element per
@@ -492,7 +522,7 @@ constexpr u32 PROBE_SAMPLES = 1024, PROBE_BINS = 2048, PROBE_LIMIT = 24;
 template <class Fr>
 // tv (may be null): the vector's k_tv_probe words, written earlier on the same stream -- a two-valued vector never reaches the
 // pipelines this probe protects, so there is nothing to look at
-__global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ scalars, int mont, u32 n, u32 c, u32 W,
+__global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ scalars, int mont, u32 n, u32 c, u32 W, u32 n_narrow,
                                                       u32* __restrict__ flag, const u32* __restrict__ tv) {
   __shared__ u32 bins[PROBE_BINS];
   __shared__ u32 worst;
@@ -502,21 +532,13 @@ __global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ sca
   const u32 i = (u32)(((u64)t * n) / PROBE_SAMPLES);
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
   if (mont) s = fe_from_mont<Fr>(s);
-  const u32 mask = (1u << c) - 1u, half = 1u << (c - 1);
   u32 carry = 0;
   for (u32 w = 0; w < W; w++) {
     for (u32 k = t; k < PROBE_BINS; k += blockDim.x) bins[k] = 0;
     __syncthreads();
-    u32 raw = (s.v[0] & mask) + carry;
-#pragma unroll
-    for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
-    s.v[7] >>= c;
-    carry = 0;
-    u32 d = raw;
-    if (raw > half && w + 1 < W) {
-      d = (1u << c) - raw;
-      carry = 1;
-    }
+    u32 neg;
+    // (the legacy short top window is looked at unshifted: the histogram only asks how many samples share a digit)
+    const u32 d = digit_step<Fr>(s, c, W, n_narrow, 0u, w, carry, neg);
     u32 seen = 0;
     if (d != 0 && t < n) seen = atomicAdd(&bins[(d * 2654435761u) >> 21], 1u) + 1u;
     if (seen >= PROBE_LIMIT) atomicMax(&worst, seen);
@@ -651,33 +673,14 @@ __global__ void __launch_bounds__(256)
   if (i >= g.n) return;
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
   if (mont) s = fe_from_mont<Fr>(s);
-  const u32 c = g.c;
-  const u32 mask = (1u << c) - 1u;
-  const u32 half = 1u << (c - 1);
   // first bucket set of this scalar's group (grouped MSM: two sums over index classes in one pass)
-  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * (g.precomp ? 1u : g.W);
+  const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * sets_per_group(g);
   u32 carry = 0;
   for (u32 w = 0; w < g.W; w++) {
-    u32 raw = (s.v[0] & mask) + carry;
-#pragma unroll
-    for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
-    s.v[7] >>= c;
-    u32 set = set0 + (g.precomp ? 0u : w);
+    u32 neg;
+    const u32 d = digit_step<Fr>(s, g.c, g.W, g.n_narrow, g.top_shift, w, carry, neg);
+    u32 set = set0 + window_set(g, w, i);
     u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
-    u32 neg = 0;
-    carry = 0;
-    u32 d = raw;
-    if (g.top_shift && w == g.W - 1u) {
-      d = raw << g.top_shift;  // MsmGeom::top_shift
-      if (d > half) {          // non-canonical scalar: reported by the `rest` test below
-        carry = 1;
-        d = 0;
-      }
-    } else if (raw > half) {
-      d = (1u << c) - raw;
-      neg = 1;
-      carry = 1;
-    }
     keys[(size_t)w * g.n + i] = (KeyT)(d == 0 ? g.B : set * g.nb + (d - 1));
     vals[(size_t)w * g.n + i] = idx | (neg << 31);
   }

@@ -77,10 +77,13 @@ class HipEngine:
 class ShardedMSM:
     """msm(local_scalars) -> the affine result of the WHOLE (all ranks) MSM, identical on every rank."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, force_collective: bool = False):
+        """force_collective: run the all-gather even when the group has ONE rank (round 4: a one-GPU box then executes the
+        RCCL call an 8-GPU node will -- tests/test_rccl_gpu.py)"""
         import torch.distributed as dist
         self.engine = engine
         self.group = group
+        self.force_collective = bool(force_collective) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -108,7 +111,7 @@ class ShardedMSM:
 
     def msm(self, local_scalars, mont: bool = True):
         part = self.engine.partial(local_scalars, mont)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return self.engine.combine(part, 1)
         gathered = self._all_gather(part)
         self._settle(gathered)
@@ -127,7 +130,7 @@ class ShardedMSM:
         else:  # engines without a batched entry point: one record at a time
             parts = torch.cat([self.engine.partial(v, mont).clone() for v in local_vecs]) if k else \
                 torch.zeros(0, dtype=torch.uint8)
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             gathered = self._all_gather(parts.contiguous())
             # [rank][msm][record] -> [msm][rank][record]
             grouped = gathered.view(self.world, k, rec).permute(1, 0, 2).contiguous().view(-1)

@@ -1,5 +1,5 @@
 """The bucket-per-lane accumulation pipeline (round 3: keys of >= 2^20 generators are precomputed for 20-bit windows; MSMs of
-(2^19, 2^20] pairs run k_prep_local_t + k_accum_bpl, longer ones as windows of 2^20) against the CPU restatement
+(2^18, 2^20] pairs run k_prep_local_t + k_accum_bpl, longer ones as windows of 2^20) against the CPU restatement
 oracle/ark_msm.c, bit for bit -- uniform scalars, sizes at both edges of the range, base offsets into a longer key, batches,
 BLS12-381 -- and its FALLBACK: scalars whose digits concentrate in a few buckets (the constant vectors of SURVEY.md F8, vectors
 with many equal small values, a skew confined to one window) must be detected by the prep and re-run through the chunked
@@ -79,9 +79,17 @@ def test_sizes_inside_the_range(env, cref, n):
     check(ctx, ck, xy, cref.rng_scalars(77 + n, n), cref, expect_fallback=False)
 
 
-@pytest.mark.parametrize("n", [1 << 19, 1 << 18, 4097, 1])
+@pytest.mark.parametrize("n", [1 << 19, (1 << 18) + 1])
+def test_ranges_down_to_a_quarter_stay_on_the_pipeline(env, cref, n):
+    """round 4 (window widths that add up to 256 bits: no spread top window to overfill a sparser bucket table): any range that
+    fills the 2^19 buckets at least a quarter as well as the whole key does"""
+    ctx, ck, xy = env
+    check(ctx, ck, xy, cref.rng_scalars(5 + n, n), cref, off=(N - n) // 3, expect_fallback=False)
+
+
+@pytest.mark.parametrize("n", [1 << 18, 4097, 1])
 def test_shorter_ranges_run_chunked_over_the_twin_key(env, cref, n):
-    """the same key serves every length: below the range the 17-bit-window twin and the chunked pipeline take over"""
+    """the same key serves every length: below a quarter of the key the 17-bit-window twin and the chunked pipeline take over"""
     ctx, ck, xy = env
     took, fell = check(ctx, ck, xy, cref.rng_scalars(5 + n, n), cref, off=(N - n) // 3)
     assert took == 0 and fell == 0
