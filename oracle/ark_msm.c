@@ -565,6 +565,67 @@ int ark_rng_points(int curve, u64 seed, size_t n, int threads, u64* out) {
   return 0;
 }
 
+/* ---- the IPA opening's folds (ark_poly_commit::ipa_pc, ext: `key_l += key_r.mul(round_challenge)` per round, under
+ * src/ipa_pc_as/mod.rs:454; restated from the published construction, BCMS20 section 7 / the Halo-style IPA) -------------
+ * out[i] = l[i] + x * r[i] over affine Montgomery points ((0, 0) = identity), x canonical (4 words): plain left-to-right
+ * double-and-add in Jacobian coordinates, one inversion per point -- the definition, nothing clever, so that the device's
+ * three fold formulations (NAF ladder, joint ladder over window multiples, GLV split) have an independent check at the
+ * opening's sizes. */
+typedef struct {
+  const curve_t* cv;
+  const u64 *l, *r, *x;
+  size_t lo, hi;
+  u64* out;
+} fold_job_t;
+static void* fold_worker(void* arg) {
+  fold_job_t* j = (fold_job_t*)arg;
+  const field_t* f = &j->cv->fq;
+  int L = f->n;
+  int top = -1;
+  for (int b = 255; b >= 0; b--)
+    if ((j->x[b >> 6] >> (b & 63)) & 1) {
+      top = b;
+      break;
+    }
+  for (size_t i = j->lo; i < j->hi; i++) {
+    const u64 *lx = j->l + 2 * L * i, *rx = j->r + 2 * L * i;
+    jac_t acc;
+    jac_set_inf(f, &acc);
+    int r_inf = is_zero(rx, 2 * L);
+    if (!r_inf)
+      for (int b = top; b >= 0; b--) {
+        jac_dbl(f, &acc);
+        if ((j->x[b >> 6] >> (b & 63)) & 1) jac_madd(f, &acc, rx, rx + L);
+      }
+    if (!is_zero(lx, 2 * L)) jac_madd(f, &acc, lx, lx + L);
+    uint8_t inf;
+    jac_to_affine(f, &acc, j->out + 2 * L * i, &inf);
+  }
+  return NULL;
+}
+int ark_points_fold(int curve, const u64* l_xy, const u64* r_xy, size_t n, const u64* x_canon, int threads, u64* out_xy) {
+  if (curve < 0 || curve > 1) return -1;
+  curves_init();
+  if (threads < 1) threads = 1;
+  if ((size_t)threads > n) threads = n ? (int)n : 1;
+  pthread_t* th = (pthread_t*)malloc(threads * sizeof(pthread_t));
+  fold_job_t* jobs = (fold_job_t*)malloc(threads * sizeof(fold_job_t));
+  for (int t = 0; t < threads; t++) {
+    jobs[t].cv = &g_curves[curve];
+    jobs[t].l = l_xy;
+    jobs[t].r = r_xy;
+    jobs[t].x = x_canon;
+    jobs[t].lo = n * t / threads;
+    jobs[t].hi = n * (t + 1) / threads;
+    jobs[t].out = out_xy;
+    pthread_create(&th[t], NULL, fold_worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+  free(th);
+  free(jobs);
+  return 0;
+}
+
 /* ---- scalar-field vector loops (Montgomery in, Montgomery out) --------------------------------- */
 /* compute_hp, src/hp_as/mod.rs:278-285 */
 int ark_fr_hadamard(int curve, const u64* a, const u64* b, size_t n, u64* out) {
@@ -589,6 +650,32 @@ int ark_fr_combine(int curve, const u64* const* vecs, const size_t* lens, size_t
       f_add(f, acc, acc, t);
     }
     memcpy(out + 4 * i, acc, 32);
+  }
+  return 0;
+}
+/* <a, b> (Montgomery in, Montgomery out): the opening's inner products and evaluations */
+int ark_fr_inner_product(int curve, const u64* a, const u64* b, size_t n, u64* out) {
+  if (curve < 0 || curve > 1) return -1;
+  curves_init();
+  const field_t* f = &g_curves[curve].fr;
+  u64 acc[4] = {0, 0, 0, 0}, t[4];
+  for (size_t i = 0; i < n; i++) {
+    f_mul(f, t, a + 4 * i, b + 4 * i);
+    f_add(f, acc, acc, t);
+  }
+  memcpy(out, acc, 32);
+  return 0;
+}
+/* out[i] = point^i (Montgomery in, Montgomery out): the evaluation vector z of the opening */
+int ark_fr_powers(int curve, const u64* point, size_t n, u64* out) {
+  if (curve < 0 || curve > 1) return -1;
+  curves_init();
+  const field_t* f = &g_curves[curve].fr;
+  u64 cur[4];
+  memcpy(cur, f->one, 32);
+  for (size_t i = 0; i < n; i++) {
+    memcpy(out + 4 * i, cur, 32);
+    f_mul(f, cur, cur, point);
   }
   return 0;
 }

@@ -49,6 +49,12 @@ def load():
                                       vp, sz, C.POINTER(vp)]
         lib.ark_fr_spmv.restype = C.c_int
         lib.ark_fr_spmv.argtypes = [C.c_int, vp, vp, vp, sz, vp, sz, vp, sz, vp]
+        lib.ark_points_fold.restype = C.c_int
+        lib.ark_points_fold.argtypes = [C.c_int, vp, vp, sz, vp, C.c_int, vp]
+        lib.ark_fr_inner_product.restype = C.c_int
+        lib.ark_fr_inner_product.argtypes = [C.c_int, vp, vp, sz, vp]
+        lib.ark_fr_powers.restype = C.c_int
+        lib.ark_fr_powers.argtypes = [C.c_int, vp, sz, vp]
         _lib = lib
     return _lib
 
@@ -109,6 +115,33 @@ def fr_combine(curve_id: int, vecs: Sequence[np.ndarray], coeffs: np.ndarray,
     out = np.empty((n, 4), dtype=np.uint64)
     assert load().ark_fr_combine(curve_id, ptrs, lens, len(vecs), _p(coeffs), _p(h), 0 if h is None else h.shape[0], n,
                                  _p(out)) == 0
+    return out
+
+
+def points_fold(curve_id: int, l_xy: np.ndarray, r_xy: np.ndarray, x: int, threads: int = 8) -> np.ndarray:
+    """out[i] = l[i] + x * r[i] (affine Montgomery arrays, (0, 0) = identity; x a canonical Python int)"""
+    L = fq_limbs(curve_id)
+    l = np.ascontiguousarray(l_xy, dtype=np.uint64).reshape(-1, 2 * L)
+    r = np.ascontiguousarray(r_xy, dtype=np.uint64).reshape(-1, 2 * L)
+    assert l.shape == r.shape
+    xw = np.array([(int(x) >> (64 * k)) & ((1 << 64) - 1) for k in range(4)], dtype=np.uint64)
+    out = np.zeros_like(l)
+    assert load().ark_points_fold(curve_id, _p(l), _p(r), l.shape[0], _p(xw), threads, _p(out)) == 0
+    return out
+
+
+def fr_inner_product(curve_id: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a, b = _m4(a), _m4(b)
+    n = min(a.shape[0], b.shape[0])
+    out = np.zeros((4,), dtype=np.uint64)
+    assert load().ark_fr_inner_product(curve_id, _p(a), _p(b), n, _p(out)) == 0
+    return out
+
+
+def fr_powers(curve_id: int, point_mont: np.ndarray, n: int) -> np.ndarray:
+    pt = np.ascontiguousarray(point_mont, dtype=np.uint64).reshape(4)
+    out = np.empty((n, 4), dtype=np.uint64)
+    assert load().ark_fr_powers(curve_id, _p(pt), n, _p(out)) == 0
     return out
 
 

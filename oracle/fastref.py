@@ -83,5 +83,48 @@ class NumpyOps:
         return cref.fr_t_vecs(c.curve_id, [self.vec(v) for v in a_vecs], [self.vec(v) for v in b_vecs], self.mont(mu), hp_len,
                               hid)
 
+    # ---- the O(len) steps of the IPA opening (pyref_as.ipa_open): vectors (n, 4) Montgomery arrays, keys (n, 2L) arrays ----
+    def vlen(self, v) -> int:
+        return int(np.asarray(v).shape[0])
+
+    def split(self, v):
+        half = v.shape[0] // 2
+        return v[:half], v[half:]
+
+    def scalar_at(self, c, v, i: int) -> int:
+        return o.fr_from_mont(c, o.limbs_to_int([int(x) for x in self.vec(v)[i]]))
+
+    def powers(self, c, point: int, n: int) -> np.ndarray:
+        return cref.fr_powers(c.curve_id, self.mont([point])[0], n)
+
+    def inner_product(self, c, a, b) -> int:
+        return o.fr_from_mont(c, o.limbs_to_int([int(x) for x in cref.fr_inner_product(c.curve_id, self.vec(a), self.vec(b))]))
+
+    def axpy(self, c, a, coeff: int, b) -> np.ndarray:
+        return cref.fr_combine(c.curve_id, [self.vec(a), self.vec(b)], self.mont([1, coeff]))
+
+    def pad(self, c, v, n: int) -> np.ndarray:
+        v = self.vec(v)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        out[:v.shape[0]] = v
+        return out
+
+    def cm_commit(self, c, key: np.ndarray, v):
+        return self.pedersen_commit(c, key, None, v, None)
+
+    def fold_points(self, c, key_l: np.ndarray, key_r: np.ndarray, x: int) -> np.ndarray:
+        return cref.points_fold(c.curve_id, key_l, key_r, x % c.r, threads=self.threads)
+
+    def point_at(self, c, key: np.ndarray, i: int):
+        return self.point(key[i], not key[i].any())
+
+    def check_poly_coeffs(self, c, xi) -> np.ndarray:
+        """SuccinctCheckPolynomial::compute_coeffs over limb arrays: doubling steps, the LAST challenge on X^1"""
+        k = len(xi)
+        co = self.mont([1])
+        for i in range(k):
+            co = np.concatenate([co, cref.fr_combine(c.curve_id, [co], self.mont([xi[k - 1 - i]]))])
+        return co
+
     def matrix_vec_mul(self, c, M: dict, inp, wit) -> np.ndarray:
         return cref.fr_spmv(c.curve_id, M["row_ptr"], M["col"], M["coeff"], self.vec(inp), self.vec(wit))

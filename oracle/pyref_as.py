@@ -49,6 +49,59 @@ class PyOps:
         """`vec![value; n]` (src/hp_as/mod.rs:187-188, src/r1cs_nark_as/mod.rs:378-379)"""
         return [value % c.r] * n
 
+    # ---- the O(len) steps of the IPA opening (ipa_open below): vectors are int lists, keys are Point lists ----
+    @staticmethod
+    def vlen(v) -> int:
+        return len(v)
+
+    @staticmethod
+    def split(v):
+        half = len(v) // 2
+        return v[:half], v[half:]
+
+    @staticmethod
+    def scalar_at(c, v, i: int) -> int:
+        return v[i] % c.r
+
+    @staticmethod
+    def powers(c, point: int, n: int) -> List[int]:
+        out, cur = [], 1
+        for _ in range(n):
+            out.append(cur)
+            cur = cur * point % c.r
+        return out
+
+    @staticmethod
+    def inner_product(c, a, b) -> int:
+        return sum(x * y for x, y in zip(a, b)) % c.r
+
+    @staticmethod
+    def axpy(c, a, coeff: int, b):
+        """a + coeff * b, elementwise (the folds of the coefficient and evaluation vectors)"""
+        return [(x + coeff * y) % c.r for x, y in zip(a, b)]
+
+    @staticmethod
+    def pad(c, v, n: int):
+        return list(v) + [0] * (n - len(v))
+
+    @staticmethod
+    def cm_commit(c, key, v) -> Point:
+        """PedersenCommitment-style `cm_commit(comm_key, scalars, None, None)`: the MSM over the first len(v) generators"""
+        return o.msm_naive(c, key[:len(v)], [x % c.r for x in v])
+
+    @staticmethod
+    def fold_points(c, key_l, key_r, x: int):
+        """`key_l += key_r * x`"""
+        return [o.add(c, P, o.mul(c, x % c.r, Q)) for P, Q in zip(key_l, key_r)]
+
+    @staticmethod
+    def point_at(c, key, i: int) -> Point:
+        return key[i]
+
+    @staticmethod
+    def check_poly_coeffs(c, xi):
+        return check_poly_coeffs(c, xi)
+
 
 ops = PyOps()
 
@@ -356,6 +409,82 @@ def check_poly_evaluate(c, xi: Sequence[int], point: int) -> int:
         out = out * (1 + xi[k - 1 - i] * p) % c.r
         p = p * p % c.r
     return out
+
+
+def ipa_open(c, comm_key, h_gen: Point, s_gen: Point, polynomial, commitment: Point, point: int, challenges: Sequence[int],
+             hiding: Optional[dict] = None) -> dict:
+    """`InnerProductArgPC::open_individual_opening_challenges` for ONE polynomial with opening challenge 1 (ark-poly-commit
+    ipa_pc, branch accumulation-experimental: ext -- restated from the published construction, BCMS20 section 7; the call
+    site is src/ipa_pc_as/mod.rs:454, the accumulation prover's opening of the combined check polynomial).
+
+    comm_key: the d + 1 generators (a power of two); polynomial: its coefficients (<= d + 1, low degree first).
+    challenges: the Fiat-Shamir values IN THE ORDER THE OPENING DRAWS THEM -- [hiding challenge (only with `hiding`), the
+    first round challenge (the multiplier of h), then one per round] -- injected like every challenge in this file.
+    hiding = None | {"polynomial": the random polynomial as drawn (before its value at `point` is taken out), "rand": its
+    commitment's randomness, "poly_rand": the randomness of `commitment`}.
+    Per round, over the CURRENT halves:  L = <c_r, key_l> + <c_r, z_l> h',  R = <c_l, key_r> + <c_l, z_r> h',
+    then  c_l += x^-1 c_r,  z_l += x z_r,  key_l += x key_r  -- the key is folded EVERY round, the definition; the product
+    expresses the rounds over the original key or folds only the first few, with the same points.
+    -> {"l_vec", "r_vec", "final_comm_key", "c", "hiding_comm", "rand"}"""
+    n = ops.vlen(comm_key)
+    assert n & (n - 1) == 0 and ops.vlen(polynomial) <= n
+    ch = list(challenges)
+    coeffs = ops.pad(c, polynomial, n)
+    z = ops.powers(c, point % c.r, n)
+    combined_comm = commitment
+    combined_v = ops.inner_product(c, coeffs, z)
+    hiding_comm, proof_rand = None, None
+    if hiding is not None:
+        hp = ops.pad(c, hiding["polynomial"], n)
+        hv = ops.inner_product(c, hp, z)
+        hp = ops.axpy(c, hp, (-hv) % c.r, ops.pad(c, ops.powers(c, 0, 1), n))  # - hv on the constant term: hp(point) = 0
+        hiding_comm = o.add(c, ops.cm_commit(c, comm_key, hp), o.mul(c, hiding["rand"] % c.r, s_gen))
+        hch = ch.pop(0) % c.r
+        coeffs = ops.axpy(c, coeffs, hch, hp)
+        proof_rand = (hiding["poly_rand"] + hch * hiding["rand"]) % c.r
+        combined_comm = o.add(c, o.add(c, combined_comm, o.mul(c, hch, hiding_comm)), o.mul(c, (-proof_rand) % c.r, s_gen))
+    h_prime = o.mul(c, ch.pop(0) % c.r, h_gen)
+    key = comm_key
+    l_vec, r_vec = [], []
+    x = None
+    while n > 1:
+        c_l, c_r = ops.split(coeffs)
+        z_l, z_r = ops.split(z)
+        k_l, k_r = ops.split(key)
+        l_vec.append(o.add(c, ops.cm_commit(c, k_l, c_r), o.mul(c, ops.inner_product(c, c_r, z_l), h_prime)))
+        r_vec.append(o.add(c, ops.cm_commit(c, k_r, c_l), o.mul(c, ops.inner_product(c, c_l, z_r), h_prime)))
+        x = ch.pop(0) % c.r
+        coeffs = ops.axpy(c, c_l, pow(x, -1, c.r), c_r)
+        z = ops.axpy(c, z_l, x, z_r)
+        key = ops.fold_points(c, k_l, k_r, x)
+        n //= 2
+    assert not ch, "more challenges than the opening draws"
+    return {"l_vec": l_vec, "r_vec": r_vec, "final_comm_key": ops.point_at(c, key, 0), "c": ops.scalar_at(c, coeffs, 0),
+            "hiding_comm": hiding_comm, "rand": proof_rand, "combined_v": combined_v}
+
+
+def ipa_check(c, comm_key, h_gen: Point, s_gen: Point, commitment: Point, point: int, value: int, proof: dict,
+              challenges: Sequence[int]) -> bool:
+    """`InnerProductArgPC::check` for one commitment (ext; call site src/ipa_pc_as/mod.rs:836, the decider): the succinct check
+    -- round commitment  C' + sum_j (x_j^-1 L_j + x_j R_j)  against  c final_key + c h(point) h'  -- and THE (d + 1)-point MSM
+    of the check polynomial's coefficients against the proof's final key.  challenges as in ipa_open."""
+    ch = list(challenges)
+    combined = commitment
+    if proof["hiding_comm"] is not None:
+        hch = ch.pop(0) % c.r
+        combined = o.add(c, o.add(c, combined, o.mul(c, hch, proof["hiding_comm"])), o.mul(c, (-proof["rand"]) % c.r, s_gen))
+    h_prime = o.mul(c, ch.pop(0) % c.r, h_gen)
+    round_comm = o.add(c, combined, o.mul(c, value % c.r, h_prime))
+    xs = [x % c.r for x in ch]
+    if len(xs) != len(proof["l_vec"]) or len(xs) != len(proof["r_vec"]):
+        return False
+    for L, R, x in zip(proof["l_vec"], proof["r_vec"], xs):
+        round_comm = o.add(c, round_comm, o.add(c, o.mul(c, pow(x, -1, c.r), L), o.mul(c, x, R)))
+    v_prime = check_poly_evaluate(c, xs, point) * proof["c"] % c.r
+    check_comm = o.add(c, o.mul(c, proof["c"] % c.r, proof["final_comm_key"]), o.mul(c, v_prime, h_prime))
+    if round_comm != check_comm:
+        return False
+    return ops.cm_commit(c, comm_key, ops.check_poly_coeffs(c, xs)) == proof["final_comm_key"]
 
 
 def ipa_as_combine(c, final_comm_keys: Sequence[Point], chal: Sequence[int], s_gen: Point,

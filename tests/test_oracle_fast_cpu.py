@@ -116,3 +116,40 @@ def test_nark_as_prove_same_on_both_backends(zk, cref):
     assert got["wit"]["hp_witness"]["rand"] == ref["wit"]["hp_witness"]["rand"] and got["wit"]["randomness"] == ref["wit"]["randomness"]
     assert got["proof"]["hp_proof"] == ref["proof"]["hp_proof"]
     assert got["proof"]["randomness"] == ref["proof"]["randomness"]
+
+
+@pytest.mark.parametrize("curve", [o.PALLAS, o.BLS12_381_G1], ids=lambda c: c.name)
+@pytest.mark.parametrize("hiding", [False, True], ids=["no_zk", "zk"])
+def test_ipa_open_and_check_same_on_both_backends(curve, hiding):
+    """oracle/pyref_as.py ipa_open / ipa_check (ark-poly-commit ipa_pc open / check, ext; call sites src/ipa_pc_as/mod.rs:454,
+    :836): the big-int backend (affine law, Python ints) and the array backend (oracle/ark_msm.c: MSMs, `key_l += x key_r` by
+    plain double-and-add, inner products) give the same proof; the check accepts it and rejects a changed one.  The config-size
+    GPU test (tests/test_ipa_open_vs_oracle_gpu.py) uses the array backend."""
+    c = curve
+    n = 32
+    pts = o.rng_points(c, 77, n + 2)
+    key, hg, sg = pts[:n], pts[n], pts[n + 1]
+    poly = [v % c.r for v in o.rng_scalars(78, n - 3)]
+    point = o.rng_scalar(79, 0) % c.r
+    hid = None
+    if hiding:
+        hid = {"polynomial": [v % c.r for v in o.rng_scalars(80, n)], "rand": o.rng_scalar(81, 0) % c.r,
+               "poly_rand": o.rng_scalar(81, 1) % c.r}
+    comm = o.msm_naive(c, key[:len(poly)], poly)
+    if hiding:
+        comm = o.add(c, comm, o.mul(c, hid["poly_rand"], sg))
+    ch = [o.rng_scalar(82, i) % (1 << 128) for i in range((1 if hiding else 0) + 1 + 5)]
+    a = oa.ipa_open(c, key, hg, sg, poly, comm, point, ch, hid)
+    assert a["combined_v"] == sum(v * pow(point, i, c.r) for i, v in enumerate(poly)) % c.r
+    assert oa.ipa_check(c, key, hg, sg, comm, point, a["combined_v"], a, ch)
+    ops = fastref.NumpyOps(c, threads=2)
+    xy, _ = h.points_to_np(c, key)
+    with oa.use_ops(ops):
+        hid2 = None if hid is None else dict(hid, polynomial=ops.mont(hid["polynomial"]))
+        b = oa.ipa_open(c, xy, hg, sg, ops.mont(poly), comm, point, ch, hid2)
+        assert oa.ipa_check(c, xy, hg, sg, comm, point, b["combined_v"], b, ch)
+    assert a == b
+    for field, bad in (("c", (a["c"] + 1) % c.r), ("final_comm_key", o.add(c, a["final_comm_key"], hg)),
+                       ("l_vec", [a["l_vec"][0]] + [a["l_vec"][0]] + a["l_vec"][2:])):
+        assert not oa.ipa_check(c, key, hg, sg, comm, point, a["combined_v"], dict(a, **{field: bad}), ch), field
+    assert not oa.ipa_check(c, key, hg, sg, comm, point, (a["combined_v"] + 1) % c.r, a, ch)
