@@ -180,6 +180,7 @@ struct amsm_ctx {
   int split_log2 = 21;      // MSMs of 2^split_min_log2 pairs and more over a precomputed key run as windows of 2^split_log2
   int split_min_log2 = 22;  // generators (msm_multi_split_xyzz; AMSM_SPLIT_LOG2=0 disables, AMSM_SPLIT_MIN_LOG2)
   bool one_stream = true;  // a lone blocking MSM runs its whole chain on the caller's stream (AMSM_ONE_STREAM=0: per-stage streams, A/B)
+  int tail_quad_hidden_log2 = 17;  // bucket tables up to 2^this take the quad tail inside a batch too (AMSM_TAIL_QUAD_HIDDEN_LOG2; 0: never)
   bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
   bool bpl = true;  // keys of 2^20 generators and more are precomputed for 20-bit windows and their MSMs of (2^19, 2^20] pairs
                     // take the bucket-per-lane pipeline (AMSM_BPL=0: 17-bit windows + the chunked pipeline, round 2's path)
@@ -202,6 +203,7 @@ struct amsm_ctx {
   // window and skips two-valued vectors: r1cs_nark_as 2^16 harness-zk pays 1.73 -> 1.8 ms, uniform work gains (2^16 batches 199 ->
   // 228 M pairs/s, hp_as 2^16 n = 2 prove 0.99 -> 0.84 ms) -- and north_star's workload is the uniform one: 2 is the default
   int bps = 2;  // (late round 3: 2 -- see the comment's last lines)
+  int bps_max_log2 = 17;  // AMSM_BPS_MAX_LOG2: largest MSM (log2 pairs) the bucket-split pipeline takes (experiments)
   unsigned long long n_bps = 0, n_bps_fallbacks = 0;
   bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline
                           // (AMSM_BPL_PROBE=0: find out from the prep's overflow flag only -- the safety net either way)
