@@ -142,6 +142,14 @@ class Context:
         ffi.check(self._lib.amsm_vec_fill(self._h, _ptr(val), n, v.ptr), "amsm_vec_fill")
         return v
 
+    def host_register(self, arr: np.ndarray) -> None:
+        """Page-lock a host array (amsm_host_register): the host-slice entry points then copy from it by DMA.  Keep the
+        array alive and call host_unregister before it is freed."""
+        ffi.check(self._lib.amsm_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes), "amsm_host_register")
+
+    def host_unregister(self, arr: np.ndarray) -> None:
+        ffi.check(self._lib.amsm_host_unregister(C.c_void_p(arr.ctypes.data)), "amsm_host_unregister")
+
     def random_vector(self, seed: int, n: int, mont: bool) -> "FrVector":
         v = FrVector(self, n)
         ffi.check(self._lib.amsm_vec_random(self._h, seed, n, 1 if mont else 0, v.ptr), "amsm_vec_random")
@@ -379,6 +387,15 @@ class CommitterKey:
         """Window width of a precomputed key, 0 for a plain one."""
         return int(self.ctx._lib.amsm_bases_window_bits(self._h))
 
+    def memory(self) -> dict:
+        """device bytes of the key: its table, the C-ABI copy (if made) and the lazily built 17-bit twin (amsm_bases_memory)"""
+        t, a, w = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        ffi.check(self.ctx._lib.amsm_bases_memory(self._h, C.byref(t), C.byref(a), C.byref(w)), "amsm_bases_memory")
+        return {"table": t.value, "abi_copy": a.value, "twin": w.value}
+
+    def prebuild_twin(self) -> None:
+        ffi.check(self.ctx._lib.amsm_bases_prebuild_twin(self.ctx._h, self._h), "amsm_bases_prebuild_twin")
+
     def read(self, off: int = 0, n: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
         n = len(self) - off if n is None else n
         xy = np.empty((n, 2 * self.ctx.fq_limbs), dtype=np.uint64)
@@ -537,9 +554,11 @@ class PedersenCommitment:
             rptrs = (C.c_void_p * max(k, 1))(*[None if r is None else r.ctypes.data for r in keep])
         out = np.zeros((k, 2 * ctx.fq_limbs), dtype=np.uint64)
         inf = np.zeros((k,), dtype=np.uint8)
-        hg = None if rptrs is None else _ptr(np.ascontiguousarray(ck.hiding_generator, dtype=np.uint64))
-        ffi.check(ctx._lib.amsm_pedersen_commit_batch(ctx._h, ck._h, ptrs, ns, k, rptrs, hg, _ptr(out), _ptr(inf)),
+        # (bound to a local: the pointer must not outlive a temporary copy np.ascontiguousarray may make)
+        hg_arr = None if rptrs is None else np.ascontiguousarray(ck.hiding_generator, dtype=np.uint64)
+        ffi.check(ctx._lib.amsm_pedersen_commit_batch(ctx._h, ck._h, ptrs, ns, k, rptrs, _ptr(hg_arr), _ptr(out), _ptr(inf)),
                   "amsm_pedersen_commit_batch")
+        del hg_arr, keep, arrs
         return [(out[i], bool(inf[i])) for i in range(k)]
 
     @staticmethod

@@ -91,6 +91,11 @@ SIGNATURES = {
     "amsm_fr_inv": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_fr_to_mont": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_fr_from_mont": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "amsm_bases_memory": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "amsm_bases_prebuild_twin": (C.c_int, [_vp, _vp]),
+    "amsm_host_register": (C.c_int, [_vp, _sz]),
+    "amsm_host_unregister": (C.c_int, [_vp]),
+    "amsm_host_is_pinned": (C.c_int, [_vp]),
     "amsm_fr_serialized_size": (_sz, [C.c_int]),
     "amsm_point_serialized_size": (_sz, [C.c_int, C.c_int]),
     "amsm_fr_serialize": (C.c_int, [C.c_int, _vp, _sz, _vp]),

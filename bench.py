@@ -180,7 +180,7 @@ def main() -> int:
         ms_host = (time.perf_counter() - t1) / 5 * 1e3
         # ... and the same host slices handed over back to back, the way the reference's provers call `commit`
         # (src/hp_as/mod.rs:372-385): amsm_msm_batch overlaps the upload of vector v + 1 with MSM v
-        ms_host_batch = pipe = plain_rate = None
+        ms_host_batch = pipe = plain_rate = ms_host_batch_pinned = ms_host_pinned = None
         if world == 1:
             h_vecs = [v.download() for v in vecs]
             VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(3)])
@@ -190,6 +190,29 @@ def main() -> int:
             ms_host_batch = (time.perf_counter() - t1) / reps * 1e3
             if "all" in last and not (np.array_equal(hb_pts[:n_distinct], last["all"][0][:n_distinct])):
                 raise SystemExit("host-slice batch differs from the device-resident batch")
+            # the same slices page-locked by the caller (amsm_host_register -- what a Rust adapter does once for the vectors it
+            # commits to repeatedly): DMA copies, two uploads in flight
+            try:
+                for hv in h_vecs:
+                    ctx.host_register(hv)
+                ctx.host_register(h_scalars)
+                VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(3)])
+                t1 = time.perf_counter()
+                hp_pts, _ = VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(reps)])
+                ms_host_batch_pinned = (time.perf_counter() - t1) / reps * 1e3
+                if not np.array_equal(hp_pts, hb_pts):
+                    raise SystemExit("page-locked host-slice batch differs from the pageable one")
+                ffi.check(ctx._lib.amsm_msm(ctx._h, ck._h, 0, _ptr(h_scalars), n, 0, _ptr(out), C.byref(inf)), "amsm_msm")
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    ffi.check(ctx._lib.amsm_msm(ctx._h, ck._h, 0, _ptr(h_scalars), n, 0, _ptr(out), C.byref(inf)), "amsm_msm")
+                ms_host_pinned = (time.perf_counter() - t1) / 5 * 1e3
+            finally:
+                for hv in h_vecs + [h_scalars]:
+                    try:
+                        ctx.host_unregister(hv)
+                    except Exception:
+                        pass
             del h_vecs
             pipe = ctx.pipeline_stats()
             pipe["two_valued"] = ctx.two_valued_msms()  # 0 here: the timed vectors are uniform
@@ -249,12 +272,17 @@ def main() -> int:
                 # host slices, 12 per call (amsm_msm_batch): PCIe-inclusive like the line above, uploads overlapped
                 "ms_per_msm_host_scalars_batch": None if ms_host_batch is None else round(ms_host_batch, 4),
                 "pairs_per_s_host_scalars_batch": None if ms_host_batch is None else round(n / (ms_host_batch * 1e-3), 1),
+                # ... from page-locked caller memory (amsm_host_register): single blocking call / batches of 12
+                "ms_per_msm_host_scalars_pinned": None if ms_host_pinned is None else round(ms_host_pinned, 4),
+                "pairs_per_s_host_scalars_batch_pinned": None if ms_host_batch_pinned is None else round(n / (ms_host_batch_pinned * 1e-3), 1),
                 # no precomputed multiples (one copy of the key, a bucket set per window): the variable-base rate
                 "pairs_per_s_plain_key": None if plain_rate is None else round(plain_rate, 1),
                 "key_bytes": key_bytes(ck, ctx, n),
                 "window_bits": int(ck.window_bits),
                 "pipeline": ("bucket-per-lane (k_prep_local_t + k_accum_bpl; skewed scalars re-run chunked)"
                              if ck.window_bits == 20 else "chunked (k_accum_l0 + k_accum_l1)"),
+                "window_widths": ("9 x 20 + 4 x 19 bits = 256 (MsmGeom::n_narrow)" if ck.window_bits == 20 and os.environ.get("AMSM_NARROW", "1") != "0"
+                                  else None),
                 "pipeline_stats": pipe,
                 "rccl_ranks": None if rank_info is None else (len(rank_info) if args.backend == "nccl" else 0),
                 "ranks": rank_info,
@@ -454,14 +482,13 @@ def alu_hw_roofline(args, ck, n, kernel_ms):
 
 
 def key_bytes(ck, ctx, n):
-    """HBM held by the committer key: W table levels of affine points (the 17-bit twin of a bucket-per-lane key is built
-    only when a skewed vector or a short / grouped MSM needs it)"""
+    """HBM held by the committer key, as the library reports it (amsm_bases_memory): the table's W levels of affine points
+    and the 17-bit twin of a 20-bit key -- built only when a range below a quarter of the key or a skewed vector needs it:
+    0 here unless the run above did"""
     c = int(ck.window_bits)
     levels = (255 // c + 1) if (ck.precomputed and c) else 1
-    out = {"table": n * levels * 16 * ctx.fq_limbs, "levels": levels}
-    if c == 20:
-        out["twin_17_bit_table_if_built"] = n * 16 * 16 * ctx.fq_limbs
-    return out
+    m = ck.memory()
+    return {"table": m["table"], "levels": levels, "twin_17_bit_table": m["twin"]}
 
 
 def source_hash():

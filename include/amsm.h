@@ -132,6 +132,14 @@ int amsm_ctx_synchronize(amsm_ctx* ctx);
  * amsm_ctx_trim synchronises and releases the workspace and the free lists (live buffers and keys stay). */
 int amsm_ctx_memory(const amsm_ctx* ctx, size_t* workspace_bytes, size_t* vectors_live_bytes, size_t* vectors_pooled_bytes);
 int amsm_ctx_trim(amsm_ctx* ctx);
+/* Device memory a key holds: its table (W levels of affine points when precomputed, the generators otherwise), the C-ABI-radix
+ * copy amsm_bases_device_ptr made (0 if never asked), and the 17-bit-window TWIN of a 20-bit key -- built lazily, inside the
+ * first MSM that needs it (a range below a quarter of 2^20 pairs, a vector with skewed digits; round 3 also grouped MSMs),
+ * about as large as the table itself: 0 until then.  amsm_bases_prebuild_twin builds it NOW (at key-creation time, on the
+ * caller's schedule) so that no prove-time call allocates or stalls; AMSM_OK without effect for keys that have none.
+ * Sharded keys report the sum over their shards. */
+int amsm_bases_memory(const amsm_bases* bases, size_t* table_bytes, size_t* abi_copy_bytes, size_t* twin_bytes);
+int amsm_bases_prebuild_twin(amsm_ctx* ctx, const amsm_bases* bases);
 
 /* Per-stage device timings of the LAST msm call (hipEvent pairs on the context's stream).
  * Enable with on != 0; stage names: amsm_stage_name(i), i in [0, amsm_stage_count()). */
@@ -231,6 +239,18 @@ int amsm_partials_combine_batch(amsm_ctx* ctx, const void* d_partials, size_t n_
  * 2^20: ~0.6 ms against ~1.1 ms); results as amsm_msm_batch_device.  The slices need not be pinned. */
 int amsm_msm_batch(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const uint64_t* const* scalars, size_t n_vecs,
                    size_t n, int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+
+/* Round 4: page-lock caller memory so that the host-slice entry points (amsm_msm, amsm_msm_batch, amsm_pedersen_commit[_batch])
+ * copy from it by DMA at the link's rate instead of staging pageable memory through the runtime's bounce buffers (~24 GB/s
+ * measured: 1.4 ms per 2^20 scalars, longer than the MSM).  A Rust adapter registers the `Vec<Fr>` buffers it commits to
+ * repeatedly (accumulator witnesses, the prover's r1cs vectors) once; memory from hipHostMalloc needs no registration.  The
+ * entry points find out by themselves (hipPointerGetAttributes) and then keep two uploads in flight ahead of the MSM being
+ * enqueued.  Process-wide, reference counting is the caller's business: unregister before the memory is freed.
+ * Errors: AMSM_E_INVALID_ARG (null / zero bytes), AMSM_E_HIP (already registered, not page-lockable), AMSM_E_NO_DEVICE. */
+int amsm_host_register(void* ptr, size_t bytes);
+int amsm_host_unregister(void* ptr);
+/* 1: `ptr` is page-locked (registered or hipHostMalloc'ed) and the host-slice entry points will copy from it asynchronously */
+int amsm_host_is_pinned(const void* ptr);
 
 /* Replaces `PedersenCommitment::commit(ck, elems, Some(r))` (ext): MSM over ck.generators[..n] plus
  * r * hiding_generator (single scalar-mul, done on the host like SURVEY.md section 8(a) row a11).

@@ -109,3 +109,97 @@ def test_vectors_longer_than_a_window_of_the_key(cref):
         ck.free()
     finally:
         ctx.close()
+
+
+def test_page_locked_slices_same_results_two_uploads_in_flight(cref):
+    """round 4: amsm_host_register -- the host-slice batch detects page-locked sources and keeps two uploads ahead of the MSM
+    being enqueued (DMA copies).  Same points as from pageable memory; registration is visible through amsm_host_is_pinned and
+    ends with amsm_host_unregister."""
+    import ctypes as C
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    c = o.PALLAS
+    ctx = Context(c.curve_id)
+    try:
+        n = 1 << 17
+        ck = CommitterKey.generate(ctx, 5, n)
+        xy, _ = ck.read()
+        vecs = [np.ascontiguousarray(cref.rng_scalars(70 + j, n)) for j in range(9)]
+        ref, rinf = VariableBaseMSM.multi_scalar_mul_batch_host(ck, vecs)
+        lib = ctx._lib
+        assert lib.amsm_host_is_pinned(C.c_void_p(vecs[0].ctypes.data)) == 0
+        for v in vecs:
+            ctx.host_register(v)
+        try:
+            assert all(lib.amsm_host_is_pinned(C.c_void_p(v.ctypes.data)) == 1 for v in vecs)
+            pts, infs = VariableBaseMSM.multi_scalar_mul_batch_host(ck, vecs)
+            assert np.array_equal(pts, ref) and np.array_equal(infs, rinf)
+            one, one_inf = VariableBaseMSM.multi_scalar_mul(ck, vecs[4])  # amsm_msm from a registered slice
+            assert np.array_equal(one, ref[4]) and bool(one_inf) == bool(rinf[4])
+            mixed = VariableBaseMSM.multi_scalar_mul_batch_host(ck, vecs[:3] + [vecs[3].copy()] + vecs[4:6])  # one pageable among them
+            assert np.array_equal(mixed[0], ref[:6])
+        finally:
+            for v in vecs:
+                ctx.host_unregister(v)
+        assert lib.amsm_host_is_pinned(C.c_void_p(vecs[0].ctypes.data)) == 0
+        got, ginf = cref.msm(c.curve_id, xy, vecs[2], threads=8)
+        assert np.array_equal(ref[2], got) and bool(rinf[2]) == bool(ginf)
+        ck.free()
+    finally:
+        ctx.close()
+
+
+def test_skewed_host_slices_at_bucket_split_sizes(cref):
+    """round-3 ADVICE: host slices of 2^16 .. 2^17 pairs are probed like device vectors -- a constant slice (the zk provers'
+    hiding vectors) goes straight to the chunked pipeline instead of an aborted bucket-split attempt"""
+    import os
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    c = o.PALLAS
+    os.environ["AMSM_TWO_VALUED"] = "0"
+    try:
+        ctx = Context(c.curve_id)
+    finally:
+        del os.environ["AMSM_TWO_VALUED"]
+    try:
+        n = 1 << 16
+        ck = CommitterKey.generate(ctx, 6, n)
+        xy, _ = ck.read()
+        const = np.tile(cref.rng_scalars(80, 1)[0], (n, 1))
+        uni = cref.rng_scalars(81, n)
+        before = ctx.pipeline_stats()
+        pts, infs = VariableBaseMSM.multi_scalar_mul_batch_host(ck, [uni, const, uni])
+        after = ctx.pipeline_stats()
+        assert after["bucket_split"] - before["bucket_split"] == 2 and after["bucket_split_fallbacks"] == before["bucket_split_fallbacks"]
+        for j, v in enumerate((uni, const, uni)):
+            ref, rinf = cref.msm(c.curve_id, xy, v, threads=8)
+            assert bool(infs[j]) == bool(rinf) and np.array_equal(pts[j], ref), j
+        ck.free()
+    finally:
+        ctx.close()
+
+
+def test_key_memory_report_and_prebuilt_twin(cref):
+    """round-3 ADVICE: the 17-bit twin of a 20-bit key is visible (amsm_bases_memory) and can be built ahead of time"""
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    c = o.PALLAS
+    ctx = Context(c.curve_id)
+    try:
+        n = 1 << 20
+        ck = CommitterKey.generate(ctx, 7, n)
+        m = ck.memory()
+        assert ck.window_bits == 20 and m["table"] == 13 * n * 64 and m["twin"] == 0 and m["abi_copy"] == 0
+        sc = cref.rng_scalars(90, 1 << 19)
+        VariableBaseMSM.multi_scalar_mul(ck, sc)            # half the key: still the 20-bit table
+        assert ck.memory()["twin"] == 0
+        ck.prebuild_twin()
+        assert ck.memory()["twin"] == 16 * n * 64
+        xy, _ = ck.read(0, 4099)
+        got, inf = VariableBaseMSM.multi_scalar_mul(ck, sc[:4099])  # a short range: over the twin
+        ref, rinf = cref.msm(c.curve_id, xy, sc[:4099])
+        assert bool(inf) == bool(rinf) and np.array_equal(got, ref)
+        small = CommitterKey.generate(ctx, 8, 1 << 12)
+        small.prebuild_twin()                               # no twin to build: a no-op
+        assert small.memory()["twin"] == 0
+        small.free()
+        ck.free()
+    finally:
+        ctx.close()

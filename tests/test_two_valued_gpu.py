@@ -133,3 +133,37 @@ def test_switch_off(env):
     assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref) and bool(inf[0]) == bool(ref_inf)
     ck.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=["pallas", "bls12_381_g1"])
+def test_scalars_at_or_above_2p255_keep_the_windowed_pipelines_verdict(env, curve):
+    """round-3 ADVICE: a canonical-form (mont = 0) constant vector whose value is 2^255 or more used to come back as
+    (v mod r) * sum with AMSM_OK from the shortcut while the windowed pipelines report AMSM_E_SCALAR_RANGE for it; now both the
+    value and the exceptions are checked.  Values in [r, 2^255) are taken by either path with the same point."""
+    from accumulation_amd import VariableBaseMSM
+    from oracle import pyref as o
+    ctx, pre, _, xy = env[curve]
+    c = o.PALLAS if curve == ffi.AMSM_PALLAS else o.BLS12_381_G1
+    n = 1 << 15
+    big = np.array(o.int_to_limbs((1 << 256) - 12345, 4), dtype=np.uint64)
+    before = ctx.two_valued_msms()
+    with pytest.raises(ffi.AmsmError) as e:
+        VariableBaseMSM.multi_scalar_mul_batch(pre, [ctx.upload(np.tile(big, (n, 1)))] * 2, mont=False)
+    assert e.value.status == ffi.AMSM_E_SCALAR_RANGE and ctx.two_valued_msms() == before
+    # ... as an exception inside an otherwise two-valued vector
+    v = cref.rng_scalars(0x7E60, 1)[0]
+    vec = np.tile(v, (n, 1))
+    vec[n // 2] = big
+    with pytest.raises(ffi.AmsmError) as e:
+        VariableBaseMSM.multi_scalar_mul_batch(pre, [ctx.upload(vec)] * 2, mont=False)
+    assert e.value.status == ffi.AMSM_E_SCALAR_RANGE
+    # r <= value < 2^255: not canonical, but within what the windows take -- same point as value mod r
+    if c.r + 5 < (1 << 255):
+        above = np.array(o.int_to_limbs(c.r + 5, 4), dtype=np.uint64)
+        out, inf = VariableBaseMSM.multi_scalar_mul_batch(pre, [ctx.upload(np.tile(above, (n, 1)))] * 2, mont=False)
+        ref, rinf = cref.msm(curve, xy[:n], np.tile(np.array(o.int_to_limbs(5, 4), dtype=np.uint64), (n, 1)))
+        assert bool(inf[0]) == bool(rinf) and np.array_equal(out[0], ref)
+    # and the context keeps working
+    out, inf = VariableBaseMSM.multi_scalar_mul_batch(pre, [ctx.upload(np.tile(v, (n, 1)))], mont=False)
+    ref, rinf = cref.msm(curve, xy[:n], np.tile(v, (n, 1)))
+    assert bool(inf[0]) == bool(rinf) and np.array_equal(out[0], ref)
