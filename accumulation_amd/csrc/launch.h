@@ -32,12 +32,12 @@ template <class Fq>
 void launch_bucket_reduce(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* out);
 template <class Fq>
 // flags (may be null): two words copied behind the n_sets records (out needs 8 bytes more)
-void launch_fold(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags);
+void launch_fold(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags, u32* host_mirror = nullptr);
 // the same two kernels with a quad of lanes per logical lane (ec.h: xyzz_add_quad): red_blocks = 4x
 template <class Fq>
 void launch_bucket_reduce_quad(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* out);
 template <class Fq>
-void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags);
+void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags, u32* host_mirror = nullptr);
 template <class Fq>
 void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c, u32* xyzz_scratch);
 template <class Fq>

@@ -570,9 +570,12 @@ __global__ void __launch_bounds__(256) k_tv_sum(const u32* __restrict__ table, T
 }
 
 // fold: wave b sums records [b*n, (b+1)*n) (lane-strided + shuffle butterfly) and writes out[b] (C-ABI radix).
+// mirror (may be null): page-locked HOST memory that receives the same record and flag words (round 4: the result used to leave
+// by a 128-byte copy command, which queues behind whatever the copy engines are doing -- a 0.6 ms scalar upload of a host-slice
+// batch -- and held the slot's `done` event back)
 template <class Fq>
 __global__ void __launch_bounds__(64) k_fold(const u32* __restrict__ in, u32 n, u32* __restrict__ out,
-                                             const u32* __restrict__ flags) {
+                                             const u32* __restrict__ flags, u32* __restrict__ mirror) {
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   for (u32 k = threadIdx.x; k < n; k += 64) {
     XYZZ<Fq> p = xyzz_load<Fq>(in, (size_t)blockIdx.x * n + k);
@@ -587,11 +590,17 @@ __global__ void __launch_bounds__(64) k_fold(const u32* __restrict__ in, u32 n, 
     e.zz = fe_export<Fq>(acc.zz);
     e.zzz = fe_export<Fq>(acc.zzz);
     xyzz_store<Fq>(out, blockIdx.x, e);
+    if (mirror) xyzz_store<Fq>(mirror, blockIdx.x, e);
     // the MSM's flag words ride behind the records: one copy takes both to the host
     if (flags && blockIdx.x == 0) {
       out[(size_t)gridDim.x * (4 * Fq::W)] = flags[0];
       out[(size_t)gridDim.x * (4 * Fq::W) + 1] = flags[1];
+      if (mirror) {
+        mirror[(size_t)gridDim.x * (4 * Fq::W)] = flags[0];
+        mirror[(size_t)gridDim.x * (4 * Fq::W) + 1] = flags[1];
+      }
     }
+    if (mirror) __threadfence_system();
   }
 }
 
@@ -623,7 +632,7 @@ __global__ void __launch_bounds__(256)
 }
 template <class Fq>
 __global__ void __launch_bounds__(256) k_fold_quad(const u32* __restrict__ in, u32 n, u32* __restrict__ out,
-                                                   const u32* __restrict__ flags) {
+                                                   const u32* __restrict__ flags, u32* __restrict__ mirror) {
   // round 3: four waves (64 quads) instead of one -- the serial part of the fold drops from n / 16 to n / 64 additions per
   // quad (n = 256 partial records after the reduction of a 2^19-bucket set), then the quad butterfly and one LDS step
   __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
@@ -646,11 +655,17 @@ __global__ void __launch_bounds__(256) k_fold_quad(const u32* __restrict__ in, u
     e.zz = fe_export<Fq>(acc.zz);
     e.zzz = fe_export<Fq>(acc.zzz);
     xyzz_store<Fq>(out, blockIdx.x, e);
+    if (mirror) xyzz_store<Fq>(mirror, blockIdx.x, e);
     // the MSM's flag words ride behind the records: one copy takes both to the host
     if (flags && blockIdx.x == 0) {
       out[(size_t)gridDim.x * (4 * Fq::W)] = flags[0];
       out[(size_t)gridDim.x * (4 * Fq::W) + 1] = flags[1];
+      if (mirror) {
+        mirror[(size_t)gridDim.x * (4 * Fq::W)] = flags[0];
+        mirror[(size_t)gridDim.x * (4 * Fq::W) + 1] = flags[1];
+      }
     }
+    if (mirror) __threadfence_system();
   }
 }
 

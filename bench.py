@@ -190,8 +190,8 @@ def main() -> int:
             ms_host_batch = (time.perf_counter() - t1) / reps * 1e3
             if "all" in last and not (np.array_equal(hb_pts[:n_distinct], last["all"][0][:n_distinct])):
                 raise SystemExit("host-slice batch differs from the device-resident batch")
-            # the same slices page-locked by the caller (amsm_host_register -- what a Rust adapter does once for the vectors it
-            # commits to repeatedly): DMA copies, two uploads in flight
+            # the same slices page-locked by the caller (amsm_host_register -- what a Rust adapter can do once for the vectors it
+            # commits to repeatedly): asynchronous DMA copies
             try:
                 for hv in h_vecs:
                     ctx.host_register(hv)

@@ -136,34 +136,52 @@ def test_switch_off(env):
 
 
 @pytest.mark.parametrize("curve", CURVES, ids=["pallas", "bls12_381_g1"])
-def test_scalars_at_or_above_2p255_keep_the_windowed_pipelines_verdict(env, curve):
-    """round-3 ADVICE: a canonical-form (mont = 0) constant vector whose value is 2^255 or more used to come back as
-    (v mod r) * sum with AMSM_OK from the shortcut while the windowed pipelines report AMSM_E_SCALAR_RANGE for it; now both the
-    value and the exceptions are checked.  Values in [r, 2^255) are taken by either path with the same point."""
-    from accumulation_amd import VariableBaseMSM
+@pytest.mark.parametrize("log_n", [15, 16], ids=["key_2p15_13_bit_windows", "key_2p16_16_bit_windows"])
+def test_scalars_at_or_above_2p255_get_the_windowed_pipelines_verdict(curve, log_n):
+    """round-3 ADVICE: a canonical-form (mont = 0) constant vector whose value is 2^255 or more came back as (v mod r) * sum with
+    AMSM_OK from the shortcut, whatever the windowed pipelines say about such scalars (AMSM_E_SCALAR_RANGE where the key's
+    windows cannot take them -- 16 x 16 bits --, the integer's multiple where they can -- 20 x 13 bits).  Now such values, as the
+    vector's value or among its exceptions, never take the shortcut: the outcome equals that of a context with the shortcut
+    off.  Values in [r, 2^255) give the same point either way."""
+    import os
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
     from oracle import pyref as o
-    ctx, pre, _, xy = env[curve]
     c = o.PALLAS if curve == ffi.AMSM_PALLAS else o.BLS12_381_G1
-    n = 1 << 15
+    n = 1 << log_n
     big = np.array(o.int_to_limbs((1 << 256) - 12345, 4), dtype=np.uint64)
-    before = ctx.two_valued_msms()
-    with pytest.raises(ffi.AmsmError) as e:
-        VariableBaseMSM.multi_scalar_mul_batch(pre, [ctx.upload(np.tile(big, (n, 1)))] * 2, mont=False)
-    assert e.value.status == ffi.AMSM_E_SCALAR_RANGE and ctx.two_valued_msms() == before
-    # ... as an exception inside an otherwise two-valued vector
     v = cref.rng_scalars(0x7E60, 1)[0]
-    vec = np.tile(v, (n, 1))
-    vec[n // 2] = big
-    with pytest.raises(ffi.AmsmError) as e:
-        VariableBaseMSM.multi_scalar_mul_batch(pre, [ctx.upload(vec)] * 2, mont=False)
-    assert e.value.status == ffi.AMSM_E_SCALAR_RANGE
-    # r <= value < 2^255: not canonical, but within what the windows take -- same point as value mod r
-    if c.r + 5 < (1 << 255):
-        above = np.array(o.int_to_limbs(c.r + 5, 4), dtype=np.uint64)
-        out, inf = VariableBaseMSM.multi_scalar_mul_batch(pre, [ctx.upload(np.tile(above, (n, 1)))] * 2, mont=False)
-        ref, rinf = cref.msm(curve, xy[:n], np.tile(np.array(o.int_to_limbs(5, 4), dtype=np.uint64), (n, 1)))
-        assert bool(inf[0]) == bool(rinf) and np.array_equal(out[0], ref)
-    # and the context keeps working
-    out, inf = VariableBaseMSM.multi_scalar_mul_batch(pre, [ctx.upload(np.tile(v, (n, 1)))], mont=False)
-    ref, rinf = cref.msm(curve, xy[:n], np.tile(v, (n, 1)))
-    assert bool(inf[0]) == bool(rinf) and np.array_equal(out[0], ref)
+    exc = np.tile(v, (n, 1))
+    exc[n // 2] = big
+    cases = {"constant": np.tile(big, (n, 1)), "exception": exc}
+    outcome = {}
+    for mode in ("1", "0"):
+        os.environ["AMSM_TWO_VALUED"] = mode
+        try:
+            ctx = Context(curve)
+        finally:
+            os.environ.pop("AMSM_TWO_VALUED", None)
+        ck = CommitterKey.generate(ctx, 0x5EED7E61, n)
+        xy, _ = ck.read()
+        for name, vec in cases.items():
+            try:
+                out, inf = VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(vec)] * 2, mont=False)
+                outcome[(mode, name)] = ("point", out[0].tolist(), bool(inf[0]))
+            except ffi.AmsmError as e:
+                outcome[(mode, name)] = ("error", e.status)
+        if mode == "1":
+            assert ctx.two_valued_msms() == 0  # neither vector took the shortcut
+            if c.r + 5 < (1 << 255):  # r <= value < 2^255: within what the windows take -- the point of value mod r, by the shortcut
+                above = np.array(o.int_to_limbs(c.r + 5, 4), dtype=np.uint64)
+                out, inf = VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(np.tile(above, (n, 1)))] * 2, mont=False)
+                ref, rinf = cref.msm(curve, xy[:n], np.tile(np.array(o.int_to_limbs(5, 4), dtype=np.uint64), (n, 1)))
+                assert bool(inf[0]) == bool(rinf) and np.array_equal(out[0], ref) and ctx.two_valued_msms() == 2
+            # and the context keeps working
+            out, inf = VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(np.tile(v, (n, 1)))], mont=False)
+            ref, rinf = cref.msm(curve, xy[:n], np.tile(v, (n, 1)))
+            assert bool(inf[0]) == bool(rinf) and np.array_equal(out[0], ref)
+        ck.free()
+        ctx.close()
+    for name in cases:
+        assert outcome[("1", name)] == outcome[("0", name)], name
+    if log_n == 16:  # 16 windows of 16 bits: nothing above 2^255 fits
+        assert outcome[("1", "constant")] == ("error", ffi.AMSM_E_SCALAR_RANGE)
