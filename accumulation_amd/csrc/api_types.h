@@ -32,6 +32,7 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   hipEvent_t done = nullptr;
   DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
       sort_tmp, scan_tmp, prep_small, heavy_scratch;
+  DevBuf red2_rc;  // row / column sums of the bucket reduction (k_red2_sums)
   DevBuf bpl_grp, bpl_order;  // bucket-per-lane pipeline: group headers, bucket order (entries live in vals_a / vals_b)
   // the MSM this slot carries, kept until it is collected: a bucket-per-lane MSM whose prep reports a skewed input is
   // re-run from here through the chunked pipeline (msm_collect)
@@ -180,6 +181,7 @@ struct amsm_ctx {
   int split_log2 = 21;      // MSMs of 2^split_min_log2 pairs and more over a precomputed key run as windows of 2^split_log2
   int split_min_log2 = 22;  // generators (msm_multi_split_xyzz; AMSM_SPLIT_LOG2=0 disables, AMSM_SPLIT_MIN_LOG2)
   bool one_stream = true;  // a lone blocking MSM runs its whole chain on the caller's stream (AMSM_ONE_STREAM=0: per-stage streams, A/B)
+  int red2 = 1;  // bucket reduction as row / column sums for sets of 2^18 buckets and more (AMSM_RED2=0: never, 2: from 1024 buckets)
   int tail_quad_hidden_log2 = 17;  // bucket tables up to 2^this take the quad tail inside a batch too (AMSM_TAIL_QUAD_HIDDEN_LOG2; 0: never)
   bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
   bool bpl = true;  // keys of 2^20 generators and more are precomputed for 20-bit windows and their MSMs of (2^19, 2^20] pairs

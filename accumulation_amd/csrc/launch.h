@@ -30,6 +30,10 @@ template <class Fq>
 u32 accum_l2_slices();  // scratch records per heavy bucket
 template <class Fq>
 void launch_bucket_reduce(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* out);
+// round 4: rows / columns form (msm_kernels.h: k_red2_sums, k_red2_weighted): nb a multiple of 1024; rc = n_sets * (nb / 1024 +
+// 1024) scratch records; returns the partial records per set left in `out` (at most 4 * (nb / 1024 + 1024) / 256 + 1)
+template <class Fq>
+u32 launch_bucket_reduce2(hipStream_t st, const u32* buckets, MsmGeom g, bool quad, bool latency, u32* rc, u32* out);
 template <class Fq>
 // flags (may be null): two words copied behind the n_sets records (out needs 8 bytes more)
 void launch_fold(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags, u32* host_mirror = nullptr);

@@ -531,6 +531,93 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)set * gridDim.x + blockIdx.x, total);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: the bucket reduction as ROW and COLUMN sums.  With j = 1024 a + b (A = nb / 1024 rows of 1024 columns),
+//   sum_j (j + 1) B_j = sum_a (1024 a) R_a + sum_b (b + 1) C_b,   R_a = sum_b B_(a,b),  C_b = sum_a B_(a,b):
+// every bucket enters two PLAIN sums -- the same two additions per bucket as the running-sum form above, but plain sums split
+// into strips of any length and finish with a butterfly, so the dependent chain is a strip plus a few exchange levels instead of
+// 2 x 32 additions and a 19-bit multiple per lane (the one-lane k_bucket_reduce + k_fold: 0.8 ms whatever the bucket count, which
+// bounded batches of 2^18 / 2^19-pair MSMs; the quad pair: 0.33 ms exposed at 2^19 buckets).
+//   k_red2_sums      wave = gw-lane groups: a group sums one row (its lanes take strips of `lrow` = 1024 / gw consecutive
+//                    columns) or one column (strips of `srow` = A / gc consecutive rows, gc lanes), strip sequentially, then a
+//                    butterfly over the group -> rc[set][0 .. A) = R_a, rc[set][A .. A + 1024) = C_b
+//   k_red2_weighted  logical lane (a lane, or a quad) = one of the A + 1024 sums: its small multiple (1024 a: a 19-bit
+//                    double-and-add; b + 1), a workgroup reduction -> one partial record per workgroup, folded by k_fold[_quad]
+// ---------------------------------------------------------------------------------------------
+struct Red2Geom {
+  u32 A;      // rows = nb / 1024
+  u32 gw;     // lanes per row group (power of two <= 64): row strips of 1024 / gw columns
+  u32 gc;     // lanes per column group (power of two <= 64, <= A): column strips of A / gc rows
+  u32 row_waves, col_waves;  // waves per set in each mode
+};
+// butterfly over aligned groups of `width` lanes (a power of two, runtime); every lane of a group ends with the group's sum
+template <class Fq>
+AMSM_DEV void group_reduce_xyzz_rt(XYZZ<Fq>& acc, u32 width) {
+#pragma unroll 1
+  for (u32 m = width >> 1; m >= 1u; m >>= 1) {
+    XYZZ<Fq> o;
+#pragma unroll
+    for (int i = 0; i < Fq::L; i++) {
+      o.x.v[i] = __shfl_xor(acc.x.v[i], (int)m, 64);
+      o.y.v[i] = __shfl_xor(acc.y.v[i], (int)m, 64);
+      o.zz.v[i] = __shfl_xor(acc.zz.v[i], (int)m, 64);
+      o.zzz.v[i] = __shfl_xor(acc.zzz.v[i], (int)m, 64);
+    }
+    const bool low = (threadIdx.x & m) == 0;  // both partners add in the same order
+    XYZZ<Fq> a = low ? acc : o;
+    XYZZ<Fq> b2 = low ? o : acc;
+    xyzz_add<Fq>(a, b2);
+    acc = a;
+  }
+}
+template <class Fq>
+__global__ void __launch_bounds__(256) k_red2_sums(const u32* __restrict__ buckets, u32 nb, Red2Geom r, u32* __restrict__ rc) {
+  const u32 set = blockIdx.y;
+  const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  const size_t base = (size_t)set * nb;
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  if (wave < r.row_waves) {  // rows: 64 / gw of them per wave
+    const u32 per = 64u / r.gw, a = wave * per + lane / r.gw, strip = lane % r.gw, lrow = 1024u / r.gw;
+    if (a < r.A) {
+      const size_t j0 = base + (size_t)a * 1024u + (size_t)strip * lrow;
+      acc = xyzz_load<Fq>(buckets, j0);
+      for (u32 k = 1; k < lrow; k++) {
+        XYZZ<Fq> b = xyzz_load<Fq>(buckets, j0 + k);
+        xyzz_add<Fq>(acc, b);
+      }
+    }
+    group_reduce_xyzz_rt<Fq>(acc, r.gw);
+    if (a < r.A && strip == 0u) xyzz_store<Fq>(rc, (size_t)set * (r.A + 1024u) + a, acc);
+  } else if (wave < r.row_waves + r.col_waves) {  // columns: 64 / gc of them per wave
+    const u32 w = wave - r.row_waves, per = 64u / r.gc, b = w * per + lane / r.gc, strip = lane % r.gc, srow = r.A / r.gc;
+    if (b < 1024u) {
+      const size_t j0 = base + (size_t)strip * srow * 1024u + b;
+      acc = xyzz_load<Fq>(buckets, j0);
+      for (u32 k = 1; k < srow; k++) {
+        XYZZ<Fq> x = xyzz_load<Fq>(buckets, j0 + (size_t)k * 1024u);
+        xyzz_add<Fq>(acc, x);
+      }
+    }
+    group_reduce_xyzz_rt<Fq>(acc, r.gc);
+    if (b < 1024u && strip == 0u) xyzz_store<Fq>(rc, (size_t)set * (r.A + 1024u) + r.A + b, acc);
+  }
+}
+template <class Fq, bool QUAD>
+__global__ void __launch_bounds__(256) k_red2_weighted(const u32* __restrict__ rc, u32 A, u32* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
+  const u32 set = blockIdx.y, items = A + 1024u;
+  const u32 t = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);  // logical lane = item
+  XYZZ<Fq> total = xyzz_inf<Fq>();
+  if (t < items) {
+    const XYZZ<Fq> v = xyzz_load<Fq>(rc, (size_t)set * items + t);
+    const u32 w = t < A ? t * 1024u : (t - A) + 1u;
+    total = QUAD ? xyzz_mul_small_quad<Fq>(v, w) : xyzz_mul_small<Fq>(v, w);
+  }
+  if (QUAD) block_reduce_xyzz_quad<Fq>(total, lds);
+  else block_reduce_xyzz<Fq>(total, lds);
+  if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)set * gridDim.x + blockIdx.x, total);
+}
+
 // Sum of the generators whose scalar equals v: the MSM of a two-valued vector up to one scalar multiplication and its (at most
 // eight) exceptions (vec_kernels.h: k_tv_probe found v and listed them).  Lane-strided mixed additions, one partial record per
 // workgroup (k_fold sums them).  blockIdx.y = which of up to TV_BATCH vectors of a call (one launch for all: each is a
