@@ -21,9 +21,13 @@ rs = np.random.RandomState(seed)
 t_end = time.time() + budget
 n_cases = 0
 ctxs = {c.name: Context(c.curve_id) for c in (o.PALLAS, o.BLS12_381_G1)}
-BIG = 1 << 18  # a few cases per minute at sizes where skewed scalars make heavy prep partitions and keys fold in batches
+BIG = 1 << int(os.environ.get("FUZZ_BIG_LOG2", "18"))  # a few cases per minute at sizes where skewed scalars make heavy prep partitions and keys fold in batches
 pools = {c.name: cref.rng_points(c.curve_id, 1000 + seed, BIG) for c in (o.PALLAS, o.BLS12_381_G1)}
-n_big = n_fold = n_adv = 0
+n_big = n_fold = n_adv = n_bpl = 0
+# round 4: share of cases that exercise the bucket-per-lane pipeline's new geometries -- plain keys of 2^16 .. 2^20 pairs (14- /
+# 15- / 16-bit windows whose widths add up to 256 bits, the top window split over two sets), ranges and grouped MSMs over a
+# 20-bit precomputed key (FUZZ_BIG_LOG2=20) -- on mostly uniform scalars with edge values sprinkled in
+BPL_FRACTION = float(os.environ.get("FUZZ_BPL_FRACTION", "0.0"))
 PALLAS_FRACTION = float(os.environ.get("FUZZ_PALLAS_FRACTION", "0.7"))  # the rest of the cases run on BLS12-381
 # points with extreme coordinates in the device's internal Montgomery radix (tests/golden/adversarial_points.json) and their
 # negatives: mixed into a third of the keys, with repetitions, so that equal / opposite / edge-valued operands meet in buckets
@@ -58,6 +62,35 @@ while time.time() < t_end:
     c = o.PALLAS if rs.rand() < PALLAS_FRACTION else o.BLS12_381_G1
     ctx = ctxs[c.name]
     roll = rs.rand()
+    if rs.rand() < BPL_FRACTION:
+        n_key = int(rs.randint((1 << 16) + 1, BIG + 1)) if rs.rand() < 0.7 else BIG
+        flags = int(rs.choice([1, 2, 2]))
+        xy = pools[c.name][:n_key]
+        ck = CommitterKey.load(ctx, xy, None, flags)
+        off = int(rs.randint(0, n_key // 2)) if rs.rand() < 0.3 else 0
+        n = n_key - off if rs.rand() < 0.5 else int(rs.randint((n_key - off) // 4 + 1, n_key - off + 1))
+        sc = cref.rng_scalars(int(rs.randint(1 << 30)), n)
+        k = int(rs.randint(0, 40))
+        if k:
+            edge = h.scalars_to_np([c.r - 1, c.r - 2, (1 << 254) - 1 if c.r > (1 << 254) else (1 << 253), 1, 0, 2, (1 << 128) - 1,
+                                    (c.r - 1) // 2, (c.r + 1) // 2, 1 << 240, (1 << 240) - 1, 1 << 224, (1 << 15) + 1, 1 << 19])
+            sc[rs.randint(0, n, size=k)] = edge[rs.randint(0, len(edge), size=k)]
+        tag = ("bpl", c.name, n_key, flags, off, n)
+        if rs.rand() < 0.7:
+            out, inf = VariableBaseMSM.multi_scalar_mul(ck, ctx.upload(sc), base_off=off)
+            ref, rinf = cref.msm(c.curve_id, xy[off:off + n], sc, threads=8)
+            assert bool(inf) == bool(rinf) and np.array_equal(out, ref), tag
+        else:
+            shift = int(rs.randint(0, 20))
+            outs, infs = VariableBaseMSM.multi_scalar_mul_grouped(ck, ctx.upload(sc), shift, mont=False, base_off=off)
+            cls = (np.arange(n) >> shift) & 1
+            for g in (0, 1):
+                ref, rinf = cref.msm(c.curve_id, xy[off:off + n][cls == g], sc[cls == g], threads=8) if (cls == g).any() else (None, True)
+                assert bool(infs[g]) == bool(rinf) and (rinf or np.array_equal(outs[g], ref)), (tag, shift, g)
+        ck.free()
+        n_bpl += 1
+        n_cases += 1
+        continue
     if roll < 0.02:
         # large and skewed: constant / few-valued / mostly-constant scalars over >= 2^17 points (heavy prep partitions,
         # batched affine conversion of the precomputed levels)
@@ -159,4 +192,5 @@ while time.time() < t_end:
     ck.free()
     ctx.set_window(0)
     n_cases += 1
-print(f"fuzz ok: {n_cases} cases ({n_big} large skewed, {n_fold} key folds, {n_adv} keys with adversarial points) in {budget:.0f} s (seed {seed})")
+print(f"fuzz ok: {n_cases} cases ({n_big} large skewed, {n_fold} key folds, {n_adv} keys with adversarial points, {n_bpl} bucket-per-lane geometries) "
+      f"in {budget:.0f} s (seed {seed}); pipeline stats: " + ", ".join(f"{k} {v.pipeline_stats()}" for k, v in ctxs.items()))
