@@ -25,11 +25,13 @@ def emit(**kw):
     print(json.dumps(kw), flush=True)
 
 
-def bench_msm(curve, log2n, reps=40):
+def bench_msm(curve, log2n, reps=40, plain=False):
+    """plain: no precomputed multiples -- the true VariableBaseMSM shape (bases as handed over per call by an ark-ec patch; the
+    folded keys of the IPA rounds)"""
     ctx = Context(curve)
     n = 1 << log2n
     t0 = time.time()
-    ck = CommitterKey.generate(ctx, 0x5EED1001, n, ffi.AMSM_BASES_PRECOMPUTE)
+    ck = CommitterKey.generate(ctx, 0x5EED1001, n, ffi.AMSM_BASES_NO_PRECOMPUTE if plain else ffi.AMSM_BASES_PRECOMPUTE)
     t_key = time.time() - t0
     vecs = [ctx.random_vector(0x5EED0001 + j, n, mont=False) for j in range(4)]
     VariableBaseMSM.multi_scalar_mul_batch(ck, [vecs[i % 4] for i in range(3)], mont=False)
@@ -41,8 +43,9 @@ def bench_msm(curve, log2n, reps=40):
     for i in range(4):
         VariableBaseMSM.multi_scalar_mul(ck, vecs[i])
     dt_sync = (time.perf_counter() - t0) / 4
-    emit(kind="msm", curve="pallas" if curve == 0 else "bls12_381_g1", log2n=log2n, pairs_per_s=n / dt,
-         ms_per_msm_pipelined=dt * 1e3, ms_per_msm_sync=dt_sync * 1e3, key_setup_s=round(t_key, 3))
+    emit(kind="msm_plain_key" if plain else "msm", curve="pallas" if curve == 0 else "bls12_381_g1", log2n=log2n, pairs_per_s=n / dt,
+         ms_per_msm_pipelined=dt * 1e3, ms_per_msm_sync=dt_sync * 1e3, key_setup_s=round(t_key, 3), window_bits=ck.window_bits,
+         pipeline_stats=ctx.pipeline_stats())
     ck.free()
     ctx.close()
 
@@ -296,6 +299,12 @@ if __name__ == "__main__":
         bench_msm(ffi.AMSM_BLS12_381_G1, 16 if quick else 20)
         if not quick:
             bench_msm(ffi.AMSM_PALLAS, 22, reps=6)
+            bench_msm(ffi.AMSM_PALLAS, 17)
+            bench_msm(ffi.AMSM_PALLAS, 19)
+            bench_msm(ffi.AMSM_BLS12_381_G1, 18)
+            for lg in (17, 18, 19, 20, 22):  # round 4: plain keys on the bucket-per-lane pipeline
+                bench_msm(ffi.AMSM_PALLAS, lg, plain=True, reps=6 if lg == 22 else 40)
+            bench_msm(ffi.AMSM_BLS12_381_G1, 20, plain=True)
     bench_vec(20 if quick else 22)
     if "--vec-only" in sys.argv:
         sys.exit(0)
