@@ -61,6 +61,8 @@ def main() -> int:
                     help="gloo + --one-gpu: functional check of the N > 1 path with every rank on GPU 0 (numbers meaningless)")
     ap.add_argument("--one-gpu", action="store_true")
     ap.add_argument("--sync", action="store_true", help="one synchronous MSM call per step (no MSMs overlapped)")
+    ap.add_argument("--torch-stream", action="store_true",
+                    help="hand the context a torch stream as its main stream (rounds 1-3; 8-10 %% slower: hardware-queue aliasing)")
     ap.add_argument("--strong", action="store_true",
                     help="N > 1: strong scaling -- ONE 2^log2n-pair MSM per step split over the ranks (2^log2n / N pairs each) "
                          "instead of 2^log2n pairs per rank; `scaling` says which")
@@ -110,9 +112,15 @@ def main() -> int:
         dist.all_gather_object(rank_info, {"rank": rank, "device": int(torch.cuda.current_device()),
                                            "pci_bus_id": str(getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", "")),
                                            "pairs": n})
-    stream = torch.cuda.Stream()
-    with torch.cuda.stream(stream):
-        ctx = Context(curve_id, device=local_rank, stream=stream.cuda_stream)
+    # The context creates its own streams (main, prep, tail -- in that order, so that each gets a hardware queue of its own).
+    # Rounds 1-3 handed it a torch stream as its main stream: torch's stream pool had taken hardware queues before the library's
+    # prep / tail streams were created, the accumulation shared a queue with one of them, and the SAME batch ran 8-10 % slower
+    # than through a context that owns its stream (round 4, same box, 20 MSMs per call: 1.18-1.20 against 1.09 ms per MSM;
+    # --torch-stream restores the old behaviour).  torch.cuda.synchronize() in sync_all() covers every stream of the device.
+    stream = torch.cuda.Stream() if args.torch_stream else None
+    import contextlib
+    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+        ctx = Context(curve_id, device=local_rank, stream=stream.cuda_stream if stream is not None else None)
         flags = ffi.AMSM_BASES_NO_PRECOMPUTE if args.no_precompute else ffi.AMSM_BASES_PRECOMPUTE
         t0 = time.time()
         ck = CommitterKey.generate(ctx, SEED_POINTS + rank, n, flags)
