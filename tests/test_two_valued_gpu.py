@@ -169,7 +169,7 @@ def test_scalars_at_or_above_2p255_get_the_windowed_pipelines_verdict(curve, log
             except ffi.AmsmError as e:
                 outcome[(mode, name)] = ("error", e.status)
         if mode == "1":
-            assert ctx.two_valued_msms() == 0  # neither vector took the shortcut
+            assert ctx.two_valued_msms() == 0  # neither vector's result came from the shortcut
             if c.r + 5 < (1 << 255):  # r <= value < 2^255: within what the windows take -- the point of value mod r, by the shortcut
                 above = np.array(o.int_to_limbs(c.r + 5, 4), dtype=np.uint64)
                 out, inf = VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(np.tile(above, (n, 1)))] * 2, mont=False)
