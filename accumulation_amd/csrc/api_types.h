@@ -190,6 +190,7 @@ struct amsm_ctx {
   // precomputed that way and take the bucket-per-lane pipeline for any range that fills a quarter of their buckets, grouped
   // MSMs included (AMSM_NARROW=0: round 3's tables -- 20-bit windows with a spread top window from 2^20, 16 bits below)
   bool narrow = true;
+  int radix = 0;  // AMSM_RADIX: 1 = mixed-radix tables (R = 13 * 2^16 from 2^20 generators, 5 * 2^16 for 2^18 / 2^19), 0 = off
   bool narrow_mid = false;  // AMSM_NARROW=2: also keys of 2^18 / 2^19 generators (c = 18 / 19; measured slower, api_pipeline.inc)
   // round 4: plain keys (no precomputed multiples) of 2^16 .. 2^20 pairs take the bucket-per-lane pipeline with one bucket set
   // per window, longer ones as ranges of 2^20 (AMSM_BPL_PLAIN=0: the chunked pipeline, round 3's path)
@@ -279,6 +280,7 @@ struct amsm_bases {
   int bpl = 0;
   int top_shift = 0;  // MsmGeom::top_shift of the table (level W - 1 = 2^(c (W - 1) - top_shift) G)
   int n_narrow = 0;   // MsmGeom::n_narrow of the table (level w = 2^(window_exponent) G)
+  int radix_m = 0, radix_k = 0;  // MsmGeom::radix_m / radix_k of the table (level w = (m 2^k)^w G); 0: power-of-two windows
   mutable amsm_bases* alt = nullptr;
   mutable std::mutex alt_mu;
   // sharded key of a multi-device context: shard g (a single-device key on shard_ctx[g]'s device) holds generators

@@ -446,10 +446,9 @@ void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
                          vals, err);                                                                                 \
   }                                                                                                                  \
   template <>                                                                                                        \
-  void launch_skew_probe<FR>(hipStream_t st, const u32* scalars, int mont, u32 n, u32 c, u32 W, u32 n_narrow,        \
-                             u32* d_flag, const u32* d_tv_words) {                                                  \
-    hipLaunchKernelGGL((k_skew_probe<FR>), dim3(1), dim3(1024), 0, st, scalars, mont, n, c, W, n_narrow, d_flag,     \
-                       d_tv_words);                                                                                  \
+  void launch_skew_probe<FR>(hipStream_t st, const u32* scalars, int mont, u32 n, DigitWalk walk, u32* d_flag,       \
+                             const u32* d_tv_words) {                                                               \
+    hipLaunchKernelGGL((k_skew_probe<FR>), dim3(1), dim3(1024), 0, st, scalars, mont, n, walk, d_flag, d_tv_words);  \
   }                                                                                                                  \
   template <>                                                                                                        \
   void launch_vec_random<FR>(hipStream_t st, u32* out, u64 seed, u32 n, int mont) {                                  \

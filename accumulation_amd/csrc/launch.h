@@ -43,7 +43,8 @@ void launch_bucket_reduce_quad(hipStream_t st, u32 red_blocks, const u32* bucket
 template <class Fq>
 void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags, u32* host_mirror = nullptr);
 template <class Fq>
-void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c, u32* xyzz_scratch);
+// level = 2^c * mul_m * (level - 1); mul_m = 0 / 1: no small multiple (power-of-two windows)
+void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c, u32* xyzz_scratch, u32 mul_m = 0);
 template <class Fq>
 void launch_apply_inf(hipStream_t st, u32* table, const uint8_t* is_inf, u32 n);
 template <class Fq>
@@ -71,8 +72,9 @@ void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const
 // window_exponent_of(c, W, n_narrow, 0, w); levels 0 .. levels-1 usable): out[i] = table[i] + x * table[n + i], i < n.  False
 // (nothing launched) when x does not fit the usable levels.
 template <class Fq>
+// radix_m > 0: mixed-radix levels (level w = (radix_m 2^radix_k)^w G): x is cut into radix-R digits instead
 bool launch_points_fold_tab(hipStream_t st, const u32* table, u32 stride, u32 c, u32 W, u32 n_narrow, u32 levels, u32 n,
-                            const u32 x_canon[8], u32 nbits, u32* out, u32* xyzz_scratch);
+                            const u32 x_canon[8], u32 nbits, u32* out, u32* xyzz_scratch, u32 radix_m = 0, u32 radix_k = 0);
 
 // two-valued vectors (vec_kernels.h k_tv_probe, msm_kernels.h k_tv_sum): exact probe into TV_PROBE_WORDS zeroed words, and the
 // sum of the generators with non-zero scalars as `blocks` partial records
@@ -133,7 +135,7 @@ int launch_prep(hipStream_t st, const u32* scalars, int mont, MsmGeom g, const P
 
 // *d_flag (zeroed by the caller) = 1 when the vector's c-bit digits look skewed (vec_kernels.h: k_skew_probe)
 template <class Fr>
-void launch_skew_probe(hipStream_t st, const u32* scalars, int mont, u32 n, u32 c, u32 W, u32 n_narrow, u32* d_flag,
+void launch_skew_probe(hipStream_t st, const u32* scalars, int mont, u32 n, DigitWalk walk, u32* d_flag,
                        const u32* d_tv_words = nullptr);
 template <class Fr>
 void launch_vec_random(hipStream_t st, u32* out, u64 seed, u32 n, int mont);

@@ -806,14 +806,25 @@ __global__ void __launch_bounds__(256) k_batch_to_affine(const u32* __restrict__
 // unconverted in xyzz_out[i] for k_batch_to_affine (large keys: the per-point inversion is 2/3 of this kernel).
 template <class Fq, bool XYZZ_OUT>
 __global__ void __launch_bounds__(256)
-    k_precompute_level(u32* __restrict__ table, u32 stride, u32 level, u32 c, u32* __restrict__ xyzz_out) {
+    k_precompute_level(u32* __restrict__ table, u32 stride, u32 level, u32 c, u32* __restrict__ xyzz_out, u32 mul_m) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= stride) return;
   Affine<Fq> p = affine_load<Fq>(table, (size_t)(level - 1) * stride + i);
   XYZZ<Fq> a = xyzz_inf<Fq>();
   if (!affine_is_inf<Fq>(p)) {
-    a = xyzz_dbl_affine<Fq>(p);
-    for (u32 k = 1; k < c; k++) a = xyzz_dbl<Fq>(a);
+    if (mul_m > 1u) {  // mixed radix: first the small odd multiple m p (double-and-add over m's bits, mixed additions of p) ...
+      a = xyzz_dbl_affine<Fq>(p);  // the top bit of m, doubled once: m >= 2
+      const int top = 31 - __clz(mul_m);
+      if ((mul_m >> (top - 1)) & 1u) xyzz_madd<Fq>(a, p);
+      for (int b = top - 2; b >= 0; b--) {
+        a = xyzz_dbl<Fq>(a);
+        if ((mul_m >> b) & 1u) xyzz_madd<Fq>(a, p);
+      }
+      for (u32 k = 0; k < c; k++) a = xyzz_dbl<Fq>(a);  // ... then 2^c
+    } else {
+      a = xyzz_dbl_affine<Fq>(p);
+      for (u32 k = 1; k < c; k++) a = xyzz_dbl<Fq>(a);
+    }
   }
   if (XYZZ_OUT) {
     xyzz_store<Fq>(xyzz_out, i, a);

@@ -54,6 +54,11 @@ struct MsmGeom {
                      // A narrow window's signed digit is DOUBLED (it lands on the even buckets of the full range) and what it
                      // multiplies stands one doubling short: table level w = 2^(e_w) G (precomputed key) / the set's sum counts
                      // 2^(e_w) (plain key), e_w = window_exponent().  0: the legacy walk (equal widths, top_shift)
+  u32 radix_m;       // round 4, mixed radix: m > 0 -- the W digits are taken in radix R = radix_m * 2^radix_k (m small and odd: 5, 13), NOT
+  u32 radix_k;       // a power of two: R^W just covers 2^256, so all W digits are uniform over (-R/2, R/2] and every one of the
+  u32 radix_magic;   // nb = R / 2 buckets is fed alike by every window (no narrow / doubled / spread window).  Table level w =
+                     // R^w G.  radix_magic = floor(2^32 / m) + 1 (division by m as a multiply-high, vec_kernels.h: digit_step).
+                     // c = ceil(log2 R) then only sizes words; n_narrow = top_shift = 0
   u32 bpl;           // 1: bucket-per-lane pipeline (k_prep_local_t + k_accum_bpl; 20-bit windows), 2: bucket-split pipeline
                      // (k_prep_local_s + k_accum_bps; small and medium MSMs), 0: chunked pipeline
   u32 bps_log2_l;    // bucket-split: log2 of the lanes per bucket
@@ -79,6 +84,21 @@ AMSM_GEOM_FN u32 window_exponent_of(u32 c, u32 W, u32 n_narrow, u32 top_shift, u
   return window_position_of(c, W, n_narrow, w) - ((w + n_narrow >= W) ? 1u : 0u) - ((w == W - 1u) ? top_shift : 0u);
 }
 AMSM_GEOM_FN u32 window_exponent(const MsmGeom& g, u32 w) { return window_exponent_of(g.c, g.W, g.n_narrow, g.top_shift, w); }
+// the parameters of the signed-digit walk (vec_kernels.h: digit_step), as every kernel that walks scalars receives them
+struct DigitWalk {
+  u32 c, W, n_narrow, top_shift, radix_m, radix_k, radix_magic;
+};
+AMSM_GEOM_FN DigitWalk digit_walk_of(const MsmGeom& g) {
+  DigitWalk d;
+  d.c = g.c;
+  d.W = g.W;
+  d.n_narrow = g.n_narrow;
+  d.top_shift = g.top_shift;
+  d.radix_m = g.radix_m;
+  d.radix_k = g.radix_k;
+  d.radix_magic = g.radix_magic;
+  return d;
+}
 // narrow windows a width-c walk over 256 bits needs (0 when the widths divide evenly; ~0u when c - 1 is not narrow enough)
 AMSM_GEOM_FN u32 narrow_windows_for(u32 c) {
   const u32 W = 255u / c + 1u, nn = W * c - 256u;

@@ -93,7 +93,7 @@ AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const Msm
   u32 carry = 0;
   for (u32 w = 0; w < g.W; w++) {
     u32 neg;
-    const u32 d = digit_step<Fr>(s, g.c, g.W, g.n_narrow, g.top_shift, w, carry, neg);
+    const u32 d = digit_step<Fr>(s, digit_walk_of(g), w, carry, neg);
     u32 set = set0 + window_set(g, w, i);
     u32 idx = g.idx_rel_bits ? ((w << g.idx_rel_bits) | i) : g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
     if (d != 0) f(set * g.nb + (d - 1), idx | (neg << 31));
@@ -110,13 +110,14 @@ AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const Msm
 // Returns non-zero when the scalar does not fit W windows, like scalar_entries (callers that walk twice ignore it once).
 template <class Fr, int MAXW, class F>
 AMSM_DEV u32 scalar_entries_unrolled_reg(Fe<Fr> s, const MsmGeom& g, u32 i, F&& f) {
+  const DigitWalk dw = digit_walk_of(g);
   const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * sets_per_group(g);
   u32 carry = 0;
 #pragma unroll
   for (int w = 0; w < MAXW; w++) {
     if ((u32)w < g.W) {
       u32 neg;
-      const u32 d = digit_step<Fr>(s, g.c, g.W, g.n_narrow, g.top_shift, (u32)w, carry, neg);
+      const u32 d = digit_step<Fr>(s, dw, (u32)w, carry, neg);
       u32 set = set0 + window_set(g, (u32)w, i);
       u32 idx = g.idx_rel_bits ? (((u32)w << g.idx_rel_bits) | i) : g.base_off + i + (g.precomp ? (u32)w * g.table_stride : 0u);
       if (d != 0) f(w, set * g.nb + (d - 1), idx | (neg << 31));

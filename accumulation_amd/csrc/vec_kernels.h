@@ -18,9 +18,42 @@ namespace amsm {
 // recoding's carry for the next window and shifts s.  Window w is c bits wide, or c - 1 (MsmGeom::n_narrow: the top windows,
 // digit doubled); the legacy short top window of a top_shift key is spread by its shift.  A scalar that does not fit the
 // windows (non-canonical: >= 2^255) leaves carry = 1 behind the last window -- the callers' `rest`.
+// Mixed radix (DigitWalk::radix_m > 0, round 4): the digit is s mod R, R = m 2^k, and s becomes s div R -- the low k bits, then a
+// division of the remaining 256-bit number by the small odd m, sixteen bits at a time from the top: the running remainder stays
+// below m, so every step divides a number below m 2^16 <= 2^21, for which q = mulhi(x, floor(2^32 / m) + 1) is exact (the
+// multiplier overshoots 2^32 / m by less than 2^-32 relative, x / m has a fractional part of at most (m - 1) / m).
 template <class Fr>
-AMSM_DEV u32 digit_step(Fe<Fr>& s, u32 c, u32 W, u32 n_narrow, u32 top_shift, u32 w, u32& carry, u32& neg) {
-  const u32 narrow = (w + n_narrow >= W) ? 1u : 0u;  // uniform over the grid
+AMSM_DEV u32 digit_step(Fe<Fr>& s, const DigitWalk& dw, u32 w, u32& carry, u32& neg) {
+  if (dw.radix_m) {  // uniform over the grid
+    const u32 k = dw.radix_k, m = dw.radix_m, mg = dw.radix_magic;
+    const u32 low = s.v[0] & ((1u << k) - 1u);
+#pragma unroll
+    for (int i = 0; i < 7; i++) s.v[i] = (s.v[i] >> k) | (s.v[i + 1] << (32 - k));
+    s.v[7] >>= k;
+    u32 rem = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+      const u32 x1 = (rem << 16) | (s.v[i] >> 16);
+      const u32 q1 = __umulhi(x1, mg);
+      const u32 r1 = x1 - q1 * m;
+      const u32 x2 = (r1 << 16) | (s.v[i] & 0xffffu);
+      const u32 q2 = __umulhi(x2, mg);
+      rem = x2 - q2 * m;
+      s.v[i] = (q1 << 16) | q2;
+    }
+    const u32 raw = (rem << k) + low + carry, R = m << k;
+    neg = 0;
+    carry = 0;
+    u32 d = raw;
+    if (raw > (R >> 1)) {
+      d = R - raw;
+      neg = 1;
+      carry = 1;
+    }
+    return d;
+  }
+  const u32 c = dw.c, W = dw.W;
+  const u32 narrow = (w + dw.n_narrow >= W) ? 1u : 0u;  // uniform over the grid
   const u32 cw = c - narrow;
   const u32 raw = (s.v[0] & ((1u << cw) - 1u)) + carry;
 #pragma unroll
@@ -29,9 +62,9 @@ AMSM_DEV u32 digit_step(Fe<Fr>& s, u32 c, u32 W, u32 n_narrow, u32 top_shift, u3
   neg = 0;
   carry = 0;
   u32 d = raw;
-  if (top_shift && w == W - 1u) {
-    d = raw << (narrow + top_shift);  // MsmGeom::top_shift: the top window (never negative), spread over the bucket range
-    if (d > (1u << (c - 1))) {         // only a non-canonical scalar gets here: reported, no entry
+  if (dw.top_shift && w == W - 1u) {
+    d = raw << (narrow + dw.top_shift);  // MsmGeom::top_shift: the top window (never negative), spread over the bucket range
+    if (d > (1u << (c - 1))) {            // only a non-canonical scalar gets here: reported, no entry
       carry = 1;
       d = 0;
     }
@@ -522,7 +555,7 @@ constexpr u32 PROBE_SAMPLES = 1024, PROBE_BINS = 2048, PROBE_LIMIT = 24;
 template <class Fr>
 // tv (may be null): the vector's k_tv_probe words, written earlier on the same stream -- a two-valued vector never reaches the
 // pipelines this probe protects, so there is nothing to look at
-__global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ scalars, int mont, u32 n, u32 c, u32 W, u32 n_narrow,
+__global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ scalars, int mont, u32 n, DigitWalk dw,
                                                       u32* __restrict__ flag, const u32* __restrict__ tv) {
   __shared__ u32 bins[PROBE_BINS];
   __shared__ u32 worst;
@@ -533,12 +566,12 @@ __global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ sca
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
   if (mont) s = fe_from_mont<Fr>(s);
   u32 carry = 0;
-  for (u32 w = 0; w < W; w++) {
+  dw.top_shift = 0;  // (the legacy short top window is looked at unshifted: the histogram only asks how many samples share a digit)
+  for (u32 w = 0; w < dw.W; w++) {
     for (u32 k = t; k < PROBE_BINS; k += blockDim.x) bins[k] = 0;
     __syncthreads();
     u32 neg;
-    // (the legacy short top window is looked at unshifted: the histogram only asks how many samples share a digit)
-    const u32 d = digit_step<Fr>(s, c, W, n_narrow, 0u, w, carry, neg);
+    const u32 d = digit_step<Fr>(s, dw, w, carry, neg);
     u32 seen = 0;
     if (d != 0 && t < n) seen = atomicAdd(&bins[(d * 2654435761u) >> 21], 1u) + 1u;
     if (seen >= PROBE_LIMIT) atomicMax(&worst, seen);
@@ -678,7 +711,7 @@ __global__ void __launch_bounds__(256)
   u32 carry = 0;
   for (u32 w = 0; w < g.W; w++) {
     u32 neg;
-    const u32 d = digit_step<Fr>(s, g.c, g.W, g.n_narrow, g.top_shift, w, carry, neg);
+    const u32 d = digit_step<Fr>(s, digit_walk_of(g), w, carry, neg);
     u32 set = set0 + window_set(g, w, i);
     u32 idx = g.base_off + i + (g.precomp ? w * g.table_stride : 0u);
     keys[(size_t)w * g.n + i] = (KeyT)(d == 0 ? g.B : set * g.nb + (d - 1));

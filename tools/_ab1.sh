@@ -1,7 +1,8 @@
-mkdir -p gpurun_out/r4u
-for i in 1 2; do
-for cfg in "AMSM_NARROW=1" "AMSM_NARROW=0 AMSM_RED2=0"; do
-  v=$(env $cfg python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-schemes 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,1), round(d['ms_per_step'],4), d['config']['ms_per_msm_synchronous_call'])")
-  echo "$cfg: $v"
-done; done > gpurun_out/r4u/b.log 2>&1
-cat gpurun_out/r4u/b.log
+mkdir -p gpurun_out/r4w
+(for cfg in "AMSM_RADIX=1" "AMSM_RADIX=0"; do
+  echo "== $cfg"
+  env $cfg python tools/r4_check.py --sizes 18,19,20 --curves pallas,bls --kinds precomp 2>&1 | grep batch | cut -c1-175
+done
+echo "== tests under AMSM_RADIX=1"
+AMSM_RADIX=1 python -m pytest tests/test_narrow_gpu.py tests/test_fold_gpu.py tests/test_bpl_gpu.py -q -m gpu -x -k "grouped or fold or uniform or sizes_inside or ranges or non_canonical or bls12_381_at or windows_of" 2>&1 | tail -15) > gpurun_out/r4w/radix.log 2>&1
+cat gpurun_out/r4w/radix.log
