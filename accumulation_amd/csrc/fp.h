@@ -249,6 +249,17 @@ AMSM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
   else return fe_mul_ref<P>(a, b);
 }
 
+// a0 b0 + a1 b1 (+ a2 b2): the definition; the scalar fields get generated schedules that accumulate the products of a column
+// before ONE Montgomery reduction (fp_mul_gfx950.h; canonical operands in, canonical result out: bit-identical)
+template <class P>
+AMSM_DEV Fe<P> fe_dot2(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<P>& b1) {
+  return fe_add<P>(fe_mul<P>(a0, b0), fe_mul<P>(a1, b1));
+}
+template <class P>
+AMSM_DEV Fe<P> fe_dot3(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<P>& b1, const Fe<P>& a2, const Fe<P>& b2) {
+  return fe_add<P>(fe_add<P>(fe_mul<P>(a0, b0), fe_mul<P>(a1, b1)), fe_mul<P>(a2, b2));
+}
+
 }  // namespace amsm
 #if !defined(AMSM_NO_ASM_MUL) && defined(__HIP_DEVICE_COMPILE__)
 #include "fp_mul_gfx950.h"

@@ -244,10 +244,12 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
 }
 
 // ---- host-side coefficient preparation for the 9 x 29-limb vector kernels (vec_kernels.h, round 3) ----
-static bool vec_sat() {  // AMSM_VEC_SAT=1: round 2's kernels on the generated 8 x 32 multiplier (A/B)
+// AMSM_VEC_SAT=0: combinations with arbitrary coefficients on round 3's 9 x 29-limb kernels (k_vec_combine_u) -- the default
+// since round 4 is the generated 8 x 32 multiplier everywhere, whose fe_dot2 / fe_dot3 share one reduction between products too
+static bool vec_sat() {
   static const bool on = [] {
     const char* e = getenv("AMSM_VEC_SAT");
-    return e && atoi(e) != 0;
+    return !e || atoi(e) != 0;
   }();
   return on;
 }

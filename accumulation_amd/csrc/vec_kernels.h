@@ -119,6 +119,18 @@ __global__ void __launch_bounds__(256)
 }
 
 
+// sum_{t < NP} pa[t] pb[t] on the 8 x 32 schedule, up to three products per Montgomery reduction (fe_dot2 / fe_dot3, fp.h)
+template <class Fr, int NP, int G = 0>
+AMSM_DEV Fe<Fr> fe_dot_n(const Fe<Fr>* pa, const Fe<Fr>* pb) {
+  constexpr int K = NP - G;
+  static_assert(K >= 1, "at least one product");
+  if constexpr (K == 1) return fe_mul<Fr>(pa[G], pb[G]);
+  else if constexpr (K == 2) return fe_dot2<Fr>(pa[G], pb[G], pa[G + 1], pb[G + 1]);
+  else if constexpr (K == 3) return fe_dot3<Fr>(pa[G], pb[G], pa[G + 1], pb[G + 1], pa[G + 2], pb[G + 2]);
+  else if constexpr (K == 4) return fe_add<Fr>(fe_dot2<Fr>(pa[G], pb[G], pa[G + 1], pb[G + 1]), fe_dot_n<Fr, NP, G + 2>(pa, pb));
+  else return fe_add<Fr>(fe_dot3<Fr>(pa[G], pb[G], pa[G + 1], pb[G + 1], pa[G + 2], pb[G + 2]), fe_dot_n<Fr, NP, G + 3>(pa, pb));
+}
+
 // is the kernel-argument coefficient the field's one (Montgomery form)?  Uniform over the grid: the first challenge of every
 // linear combination of the schemes is 1 (mu_0, nu^0, beta_0: src/hp_as/mod.rs:241,266, src/r1cs_nark_as/mod.rs:444), and
 // skipping its multiplication takes a third off the arithmetic of the common two-vector combination.
@@ -151,16 +163,25 @@ __global__ void __launch_bounds__(256) k_vec_combine(CombineArgs a, u32* __restr
     const bool more = nx < a.n;
     Fe<Fr> x2[NV], h2;
     if (more) load(nx, x2, h2);
+    // a unit FIRST coefficient (the schemes' combinations: see coeff_is_one) is an addition; the other products share
+    // Montgomery reductions three at a time
+    if (coeff_is_one<Fr>(a.coeff[0])) {
+      acc = fe_add<Fr>(acc, x[0]);
+      if constexpr (NV > 1) {
+        Fe<Fr> cf[NV - 1];
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-      if (coeff_is_one<Fr>(a.coeff[j])) {
-        acc = fe_add<Fr>(acc, x[j]);
-      } else {
-        Fe<Fr> cf;
+        for (int j = 1; j < NV; j++)
 #pragma unroll
-        for (int k = 0; k < 8; k++) cf.v[k] = a.coeff[j][k];
-        acc = fe_add<Fr>(acc, fe_mul<Fr>(cf, x[j]));
+          for (int k = 0; k < 8; k++) cf[j - 1].v[k] = a.coeff[j][k];
+        acc = fe_add<Fr>(acc, fe_dot_n<Fr, NV - 1>(cf, x + 1));
       }
+    } else {
+      Fe<Fr> cf[NV];
+#pragma unroll
+      for (int j = 0; j < NV; j++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) cf[j].v[k] = a.coeff[j][k];
+      acc = fe_add<Fr>(acc, fe_dot_n<Fr, NV>(cf, x));
     }
     // in-place chunked combination (more than VEC_MAX vectors) re-reads `out` as the hiding addend: plain store there
     if (a.hiding == out) fe_store<Fr>(out + (size_t)i * 8, acc);
@@ -225,11 +246,24 @@ __global__ void __launch_bounds__(256) k_hp_t_vecs(TVecArgs a) {
 #pragma unroll
     for (int k = 0; k < 2 * N - 1; k++) {
       if (a.t[k] == nullptr) continue;  // uniform branch: coefficient N-1 is never committed
+      // coefficient k = sum_{i + j = k} ac[i] bc[j]: i from lo, CNT terms, ONE reduction per three products
+      const int lo = k < N ? 0 : k - (N - 1), cnt = (k < N ? k : N - 1) - lo + 1;
+      Fe<Fr> pa[N], pb[N];
+#pragma unroll
+      for (int t = 0; t < N; t++) {
+        pa[t] = ac[t < cnt ? lo + t : 0];
+        pb[t] = bc[t < cnt ? k - lo - t : 0];
+      }
       Fe<Fr> s = fe_zero<Fr>();
 #pragma unroll
-      for (int i = 0; i < N; i++) {
-        int j = k - i;
-        if (j >= 0 && j < N) s = fe_add<Fr>(s, fe_mul<Fr>(ac[i], bc[j]));
+      for (int g = 0; g < N; g += 3) {
+        if (g >= cnt) continue;
+        const int rem = cnt - g, g1 = g + 1 < N ? g + 1 : N - 1, g2 = g + 2 < N ? g + 2 : N - 1;
+        Fe<Fr> part;
+        if (rem >= 3) part = fe_dot3<Fr>(pa[g], pb[g], pa[g1], pb[g1], pa[g2], pb[g2]);
+        else if (rem == 2) part = fe_dot2<Fr>(pa[g], pb[g], pa[g1], pb[g1]);
+        else part = fe_mul<Fr>(pa[g], pb[g]);
+        s = g == 0 ? part : fe_add<Fr>(s, part);
       }
       fe_store_nt<Fr>(a.t[k] + (size_t)li * 8, s);
     }

@@ -190,6 +190,15 @@ def test_scalar_field_kernels_on_edge_values(ctxs, c):
         coeffs = h.scalars_to_np([ca, cb])
         got = h.np_to_ints(combine_vectors(ctx, [dA, dB], coeffs).download())
         assert got == [(mont_mul(a, ca) + mont_mul(b, cb)) % r for a, b in zip(A, B)], (hex(ca), hex(cb))
+    # a unit first coefficient keeps the combination on the 8 x 32 schedule, where two / three products share ONE Montgomery
+    # reduction (fe_dot2 / fe_dot3, fp_mul_gfx950.h): sums just below 2 r and 3 r before the final subtractions
+    one = R % r
+    for cs in ((r - 1, r - 1), (r - 1, r - 2, r - 1), (vals[3], vals[-1], vals[-2]), (0, r - 1, 1), (r - 1, r - 1, r - 1, r - 1)):
+        vs = [dA, dB, dA, dB, dB][:len(cs) + 1]
+        hv = [A, B, A, B, B][:len(cs) + 1]
+        got = h.np_to_ints(combine_vectors(ctx, vs, h.scalars_to_np([one] + list(cs))).download())
+        exp = [(row[0] + sum(mont_mul(x, cf) for x, cf in zip(row[1:], cs))) % r for row in zip(*hv)]
+        assert got == exp, [hex(x) for x in cs]
     ip = np.zeros(4, dtype=np.uint64)
     from accumulation_amd import ffi
     from accumulation_amd.engine import _ptr

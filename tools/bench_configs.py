@@ -187,7 +187,7 @@ def bench_vec(log2n):
     # the reference harness's shape (examples/scaling-as.rs:91-104): one input + two old accumulators = three (a, b) pairs
     a3 = a + [ctx.random_vector(12, n, mont=True)]
     b3 = b + [ctx.random_vector(22, n, mont=True)]
-    for label, chs, mults_c, mults_t in (("arbitrary", [3, 5, 7], 3, 12), ("mu_0 = 1 as in prove", [1, 5, 7], 2, 11)):
+    for label, chs, mults_c, mults_t in (("arbitrary", [3, 5, 7], 3, 9), ("mu_0 = 1 as in prove", [1, 5, 7], 2, 8)):
         c3 = fr.to_limbs_many(chs)
         t = timed(ctx, lambda: combine_vectors(ctx, a3, c3))
         emit(kind="vec", op=f"combine_vectors(n=3, {label})", log2n=log2n, ms=t * 1e3, GBps=128 * n / t / 1e9,

@@ -78,13 +78,24 @@ def emit_column_stmt(terms, first):
     return f'  asm volatile("{body}"\n               : {outs}\n               : {", ".join(ops_in)}\n               : "vcc");\n'
 
 
-def gen_field(name):
+def gen_field(name, T=1):
+    """T = 1: fe_mul(a, b).  T = 2, 3: fe_dot2 / fe_dot3 -- sum_t a_t b_t with ONE Montgomery reduction: the T products of a
+    column are accumulated before the column's m_k is derived; the value before the final subtractions is below
+    (T p^2 + 2^(32 L) p) / 2^(32 L), i.e. needs ceil(T p / 2^(32 L)) conditional subtractions."""
     L, mod, inv = FIELDS[name]
     p = [(mod >> (32 * i)) & 0xFFFFFFFF for i in range(L)]
     out = []
-    out.append(f"// ---- {name}: L = {L}, INV = 0x{inv:08x} ----")
-    out.append("template <>")
-    out.append(f"AMSM_DEV Fe<{name}> fe_mul<{name}>(const Fe<{name}>& a, const Fe<{name}>& b) {{")
+    if T == 1:
+        out.append(f"// ---- {name}: L = {L}, INV = 0x{inv:08x} ----")
+        out.append("template <>")
+        out.append(f"AMSM_DEV Fe<{name}> fe_mul<{name}>(const Fe<{name}>& a, const Fe<{name}>& b) {{")
+        pairs = [("a", "b")]
+    else:
+        pairs = [(f"a{t}", f"b{t}") for t in range(T)]
+        args = ", ".join(f"const Fe<{name}>& {x}, const Fe<{name}>& {y}" for x, y in pairs)
+        out.append(f"// ---- {name}: sum of {T} products, one reduction ----")
+        out.append("template <>")
+        out.append(f"AMSM_DEV Fe<{name}> fe_dot{T}<{name}>({args}) {{")
     out.append("  u64 acc = 0, s0, s1, s2;")
     out.append("  u32 c2;")
     out.append(f"  u32 m[{L}];")
@@ -92,10 +103,11 @@ def gen_field(name):
     # modulus constants as SGPR operands (wave-uniform), skip 0 and handle p0 in epilogue
     for k in range(2 * L):
         terms = []
-        for i in range(L):
-            j = k - i
-            if 0 <= j < L:
-                terms.append((f"a.v[{i}]", "v", f"b.v[{j}]", "v"))
+        for x, y in pairs:
+            for i in range(L):
+                j = k - i
+                if 0 <= j < L:
+                    terms.append((f"{x}.v[{i}]", "v", f"{y}.v[{j}]", "v"))
         for i in range(min(k, L)):
             j = k - i
             if 1 <= j < L and p[j] != 0:
@@ -130,7 +142,11 @@ def gen_field(name):
             out.append(f"  r.v[{k - L}] = (u32)acc;")
             if k < 2 * L - 1:
                 out.append("  acc = ((u64)c2 << 32) | (u32)(acc >> 32);")
+    n_sub = -(-(T * mod) // (1 << (32 * L)))  # ceil(T p / R)
+    assert (T * mod * mod + (mod << (32 * L))) >> (32 * L) < (1 << (32 * L + 32))
     out.append(f"  fe_cond_sub<{name}>(r, (u32)(acc >> 32));")
+    for _ in range(n_sub - 1):
+        out.append(f"  fe_cond_sub<{name}>(r, 0);")
     out.append("  return r;")
     out.append("}")
     return "\n".join(out)
@@ -145,6 +161,10 @@ def main():
     for name in FIELDS:
         hdr.append(gen_field(name))
         hdr.append("")
+    for name in ("PallasFr", "Bls12381Fr"):  # the scalar-field vector kernels (vec_kernels.h)
+        for T in (2, 3):
+            hdr.append(gen_field(name, T))
+            hdr.append("")
     hdr.append("}  // namespace amsm")
     sys.stdout.write("\n".join(hdr) + "\n")
 
