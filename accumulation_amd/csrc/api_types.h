@@ -33,6 +33,7 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
       sort_tmp, scan_tmp, prep_small, heavy_scratch;
   DevBuf red2_rc;  // row / column sums of the bucket reduction (k_red2_sums)
+  DevBuf ds_flags;  // the direct sum's two flag words (zeroed at allocation, left clear by k_fold_quad)
   DevBuf bpl_grp, bpl_order;  // bucket-per-lane pipeline: group headers, bucket order (entries live in vals_a / vals_b)
   // the MSM this slot carries, kept until it is collected: a bucket-per-lane MSM whose prep reports a skewed input is
   // re-run from here through the chunked pipeline (msm_collect)
@@ -208,6 +209,10 @@ struct amsm_ctx {
   int bps = 2;  // (late round 3: 2 -- see the comment's last lines)
   int bps_max_log2 = 17;  // AMSM_BPS_MAX_LOG2: largest MSM (log2 pairs) the bucket-split pipeline takes (experiments)
   unsigned long long n_bps = 0, n_bps_fallbacks = 0;
+  unsigned long long n_direct = 0;  // MSMs summed straight from a small key's 512-points-per-generator table (k_direct_sum)
+  int direct_max_log2 = 14;         // keys of up to 2^this generators carry that table (AMSM_DIRECT_SUM_MAX_LOG2; 0: none)
+  int direct_m = 0;                 // windows per lane of k_direct_sum (AMSM_DIRECT_M; 0: by size)
+  unsigned direct_rr = 0;           // which stream the next direct sum of a batch takes
   bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline
                           // (AMSM_BPL_PROBE=0: find out from the prep's overflow flag only -- the safety net either way)
   unsigned long long n_bpl = 0, n_bpl_fallbacks = 0;  // MSMs that took it / that were re-run chunked (skewed digits)
@@ -281,6 +286,9 @@ struct amsm_bases {
   int top_shift = 0;  // MsmGeom::top_shift of the table (level W - 1 = 2^(c (W - 1) - top_shift) G)
   int n_narrow = 0;   // MsmGeom::n_narrow of the table (level w = 2^(window_exponent) G)
   int radix_m = 0, radix_k = 0;  // MsmGeom::radix_m / radix_k of the table (level w = (m 2^k)^w G); 0: power-of-two windows
+  // small keys (round 4): j 2^(4 w) G_i for j = 1 .. 8, w = 0 .. 63 at [((j - 1) 64 + w) n + i] -- every MSM over such a key that is
+  // not grouped is a plain sum of table points (msm_kernels.h k_direct_sum); null: none
+  u32* d_small = nullptr;
   mutable amsm_bases* alt = nullptr;
   mutable std::mutex alt_mu;
   // sharded key of a multi-device context: shard g (a single-device key on shard_ctx[g]'s device) holds generators

@@ -656,6 +656,90 @@ __global__ void __launch_bounds__(256) k_tv_sum(const u32* __restrict__ table, T
   if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)v * gridDim.x + blockIdx.x, acc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct sum (round 4): the latency regime.  An MSM of up to 2^14 pairs is a chain of ~14 launches on the sorted pipelines
+// (0.28 ms at 2^12 pairs, 0.34 at 2^14) for arithmetic the chip does in 20 us; what it needs is the SHORTEST dependent chain, not
+// the fewest additions.  Keys of up to 2^14 generators therefore also carry every multiple a 4-bit signed digit can ask for --
+// table[(j - 1) * 64 + w][i] = j 2^(4 w) G_i, j = 1 .. 8, w = 0 .. 63 (512 affine points per generator) -- so that an MSM is a
+// plain SUM of n * 64 * 15/16 table points: no buckets, hence no sort, no bucket reduction with its 2^(c-1)-fold weights, and no
+// dependence on the digit distribution (a constant vector costs what a uniform one does).  One launch sums them -- lane (g, i)
+// adds the points of scalar i's windows [g m, (g + 1) m) by mixed additions, two butterfly levels leave every quad of lanes
+// with its sum, the quad-cooperative tree (ec.h) takes the workgroup's 64 quads to one record -- and k_fold_quad adds the
+// workgroups' records.  Digits without a carry chain: s' = s + 0x0888...8 (an 8 under each of the 63 low windows), then digit
+// w = nibble w of s' - 8 in [-8, 7], the top window's nibble taken as it is (0 .. 8 for every s < 8.47 * 2^252, which covers
+// the canonical scalars of both fields; anything above is reported like a scalar that does not fit the other pipelines' windows).
+template <class Fq>
+__global__ void __launch_bounds__(256) k_ds_levels(const u32* __restrict__ gens, u32 n, u32* __restrict__ xyzz_out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  XYZZ<Fq> a = xyzz_from_affine<Fq>(affine_load<Fq>(gens, i));
+  xyzz_store<Fq>(xyzz_out, i, a);
+  for (u32 w = 1; w < DS_W; w++) {
+    for (int k = 0; k < 4; k++) a = xyzz_dbl<Fq>(a);
+    xyzz_store<Fq>(xyzz_out, (size_t)w * n + i, a);
+  }
+}
+// plane j - 1 (count records each) = j * plane 0, j = 2 .. 8
+template <class Fq>
+__global__ void __launch_bounds__(256) k_ds_multiples(u32* __restrict__ xyzz, u32 count) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const XYZZ<Fq> p1 = xyzz_load<Fq>(xyzz, i);
+  XYZZ<Fq> p2 = xyzz_dbl<Fq>(p1), p3 = p2, p4 = xyzz_dbl<Fq>(p2);
+  xyzz_add<Fq>(p3, p1);
+  XYZZ<Fq> p5 = p4, p6 = xyzz_dbl<Fq>(p3), p8 = xyzz_dbl<Fq>(p4);
+  xyzz_add<Fq>(p5, p1);
+  XYZZ<Fq> p7 = p6;
+  xyzz_add<Fq>(p7, p1);
+  xyzz_store<Fq>(xyzz, (size_t)1 * count + i, p2);
+  xyzz_store<Fq>(xyzz, (size_t)2 * count + i, p3);
+  xyzz_store<Fq>(xyzz, (size_t)3 * count + i, p4);
+  xyzz_store<Fq>(xyzz, (size_t)4 * count + i, p5);
+  xyzz_store<Fq>(xyzz, (size_t)5 * count + i, p6);
+  xyzz_store<Fq>(xyzz, (size_t)6 * count + i, p7);
+  xyzz_store<Fq>(xyzz, (size_t)7 * count + i, p8);
+}
+template <class Fq, class Fr>
+__global__ void __launch_bounds__(256)
+    k_direct_sum(const u32* __restrict__ table, u32 key_n, u32 base_off, const u32* __restrict__ scalars, int mont, u32 n, u32 m,
+                 u32* __restrict__ flags, u32* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
+  const u32 L = blockIdx.x * 256u + threadIdx.x;
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  if (L < n * (DS_W / m)) {
+    const u32 g = L / n, i = L - g * n;
+    Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
+    if (mont) s = fe_from_mont<Fr>(s);
+    u32 cy = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s.v[k] = __builtin_addc(s.v[k], k < 7 ? 0x88888888u : 0x08888888u, cy, &cy);
+    if ((cy | ((s.v[7] >> 28) > 8u ? 1u : 0u)) && g == 0u) atomicOr(flags, 1u);
+    const size_t col = (size_t)base_off + i;
+    const u32 w0 = g * m;
+    auto digit = [&](u32 w) -> int {
+      const int nib = (int)((s.v[w >> 3] >> ((w & 7u) * 4u)) & 15u);
+      return w == DS_W - 1u ? (nib > 8 ? 0 : nib) : nib - 8;  // (a top nibble above 8: reported above, never looked up)
+    };
+    auto fetch = [&](u32 w, int d) -> Affine<Fq> {
+      const u32 mag = (u32)(d < 0 ? -d : d);
+      return affine_load<Fq>(table, ((size_t)(mag ? mag - 1u : 0u) * DS_W + w) * key_n + col);  // (d = 0: loaded, not added)
+    };
+    int d = digit(w0);
+    Affine<Fq> pt = fetch(w0, d);
+    for (u32 k = 0; k < m; k++) {
+      const u32 wn = w0 + (k + 1u < m ? k + 1u : k);
+      const int dn = digit(wn);
+      const Affine<Fq> nx = fetch(wn, dn);  // the next point is requested before this one's addition
+      if (d != 0) xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, d < 0));
+      d = dn;
+      pt = nx;
+    }
+  }
+  group_reduce_xyzz<Fq, 4>(acc);  // one-lane additions: afterwards the four lanes of a quad hold the same sum
+  block_reduce_xyzz_quad<Fq>(acc, lds);
+  if (threadIdx.x == 0) xyzz_store<Fq>(partials, blockIdx.x, acc);
+}
+
 // fold: wave b sums records [b*n, (b+1)*n) (lane-strided + shuffle butterfly) and writes out[b] (C-ABI radix).
 // mirror (may be null): page-locked HOST memory that receives the same record and flag words (round 4: the result used to leave
 // by a 128-byte copy command, which queues behind whatever the copy engines are doing -- a 0.6 ms scalar upload of a host-slice
@@ -719,7 +803,7 @@ __global__ void __launch_bounds__(256)
 }
 template <class Fq>
 __global__ void __launch_bounds__(256) k_fold_quad(const u32* __restrict__ in, u32 n, u32* __restrict__ out,
-                                                   const u32* __restrict__ flags, u32* __restrict__ mirror) {
+                                                   const u32* __restrict__ flags, u32* __restrict__ mirror, u32 clear_flags) {
   // round 3: four waves (64 quads) instead of one -- the serial part of the fold drops from n / 16 to n / 64 additions per
   // quad (n = 256 partial records after the reduction of a 2^19-bucket set), then the quad butterfly and one LDS step
   __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
@@ -745,11 +829,16 @@ __global__ void __launch_bounds__(256) k_fold_quad(const u32* __restrict__ in, u
     if (mirror) xyzz_store<Fq>(mirror, blockIdx.x, e);
     // the MSM's flag words ride behind the records: one copy takes both to the host
     if (flags && blockIdx.x == 0) {
-      out[(size_t)gridDim.x * (4 * Fq::W)] = flags[0];
-      out[(size_t)gridDim.x * (4 * Fq::W) + 1] = flags[1];
+      const u32 f0 = flags[0], f1 = flags[1];
+      out[(size_t)gridDim.x * (4 * Fq::W)] = f0;
+      out[(size_t)gridDim.x * (4 * Fq::W) + 1] = f1;
       if (mirror) {
-        mirror[(size_t)gridDim.x * (4 * Fq::W)] = flags[0];
-        mirror[(size_t)gridDim.x * (4 * Fq::W) + 1] = flags[1];
+        mirror[(size_t)gridDim.x * (4 * Fq::W)] = f0;
+        mirror[(size_t)gridDim.x * (4 * Fq::W) + 1] = f1;
+      }
+      if (clear_flags) {  // the direct sum's flag words: left zeroed for the slot's next MSM (no fill command per MSM)
+        const_cast<u32*>(flags)[0] = 0;
+        const_cast<u32*>(flags)[1] = 0;
       }
     }
     if (mirror) __threadfence_system();

@@ -144,4 +144,7 @@ struct TVecArgs {
   u32 len;
 };
 
+// direct sum over a small key's table of digit multiples (msm_kernels.h k_direct_sum): 64 four-bit windows, multiples 1 .. 8
+constexpr u32 DS_W = 64, DS_MULT = 8;
+
 }  // namespace amsm
