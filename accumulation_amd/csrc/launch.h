@@ -46,10 +46,11 @@ void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, 
 template <class Fq>
 // level = 2^c * mul_m * (level - 1); mul_m = 0 / 1: no small multiple (power-of-two windows)
 void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c, u32* xyzz_scratch, u32 mul_m = 0);
-// Direct sum (msm_kernels.h k_direct_sum): the 512-points-per-generator table of a small key from its n generators (affine, device
-// radix; xyzz_scratch: 512 n records), and one MSM as cdiv(n * 64 / m, 256) partial records (returned) for launch_fold_quad
+// Direct sum (msm_kernels.h k_direct_sum): the 512-points-per-generator table of a small key from its window table (W levels of
+// plain c-bit windows, device radix; xyzz_scratch: 512 n records), and one MSM as cdiv(n * 64 / m, 256) partial records
+// (returned) for launch_fold_quad
 template <class Fq>
-void launch_ds_table(hipStream_t st, const u32* gens, u32 n, u32* xyzz_scratch, u32* table);
+void launch_ds_table(hipStream_t st, const u32* win_table, u32 n, u32 c, u32 W, u32* xyzz_scratch, u32* table);
 template <class Fq>
 u32 launch_direct_sum(hipStream_t st, const u32* table, u32 key_n, u32 base_off, const u32* scalars, int mont, u32 n, u32 m, u32* flags,
                       u32* partials);

@@ -668,16 +668,19 @@ __global__ void __launch_bounds__(256) k_tv_sum(const u32* __restrict__ table, T
 // workgroups' records.  Digits without a carry chain: s' = s + 0x0888...8 (an 8 under each of the 63 low windows), then digit
 // w = nibble w of s' - 8 in [-8, 7], the top window's nibble taken as it is (0 .. 8 for every s < 8.47 * 2^252, which covers
 // the canonical scalars of both fields; anything above is reported like a scalar that does not fit the other pipelines' windows).
+// level w = 2^(4 w) G from the key's WINDOW table (levels 2^(c l) G, plain c-bit windows): the level at or below bit 4 w, then
+// at most c - 1 doublings -- every (w, i) on its own lane (a chain of 252 doublings per generator from the generators alone)
 template <class Fq>
-__global__ void __launch_bounds__(256) k_ds_levels(const u32* __restrict__ gens, u32 n, u32* __restrict__ xyzz_out) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  XYZZ<Fq> a = xyzz_from_affine<Fq>(affine_load<Fq>(gens, i));
-  xyzz_store<Fq>(xyzz_out, i, a);
-  for (u32 w = 1; w < DS_W; w++) {
-    for (int k = 0; k < 4; k++) a = xyzz_dbl<Fq>(a);
-    xyzz_store<Fq>(xyzz_out, (size_t)w * n + i, a);
-  }
+__global__ void __launch_bounds__(256) k_ds_levels(const u32* __restrict__ win_table, u32 n, u32 c, u32 W, u32* __restrict__ xyzz_out) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * DS_W) return;
+  const u32 w = t / n, i = t - w * n;
+  u32 l = (4u * w) / c;
+  if (l >= W) l = W - 1u;
+  const u32 dbl = 4u * w - c * l;
+  XYZZ<Fq> a = xyzz_from_affine<Fq>(affine_load<Fq>(win_table, (size_t)l * n + i));
+  for (u32 k = 0; k < dbl; k++) a = xyzz_dbl<Fq>(a);
+  xyzz_store<Fq>(xyzz_out, t, a);
 }
 // plane j - 1 (count records each) = j * plane 0, j = 2 .. 8
 template <class Fq>

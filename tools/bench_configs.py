@@ -305,6 +305,9 @@ if __name__ == "__main__":
             for lg in (17, 18, 19, 20, 22):  # round 4: plain keys on the bucket-per-lane pipeline
                 bench_msm(ffi.AMSM_PALLAS, lg, plain=True, reps=6 if lg == 22 else 40)
             bench_msm(ffi.AMSM_BLS12_381_G1, 20, plain=True)
+            for lg in (8, 12, 14):  # round 4: small keys are direct sums
+                bench_msm(ffi.AMSM_PALLAS, lg)
+            bench_msm(ffi.AMSM_BLS12_381_G1, 12)
     bench_vec(20 if quick else 22)
     if "--vec-only" in sys.argv:
         sys.exit(0)
