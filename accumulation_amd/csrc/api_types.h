@@ -210,7 +210,7 @@ struct amsm_ctx {
   int bps_max_log2 = 17;  // AMSM_BPS_MAX_LOG2: largest MSM (log2 pairs) the bucket-split pipeline takes (experiments)
   unsigned long long n_bps = 0, n_bps_fallbacks = 0;
   unsigned long long n_direct = 0;  // MSMs summed straight from a small key's 512-points-per-generator table (k_direct_sum)
-  int direct_max_log2 = 14;         // keys of up to 2^this generators carry that table (AMSM_DIRECT_SUM_MAX_LOG2; 0: none)
+  int direct_max_log2 = 15;         // keys of up to 2^this generators carry that table (AMSM_DIRECT_SUM_MAX_LOG2; 0: none)
   int direct_m = 0;                 // windows per lane of k_direct_sum (AMSM_DIRECT_M; 0: by size)
   unsigned direct_rr = 0;           // which stream the next direct sum of a batch takes
   bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline

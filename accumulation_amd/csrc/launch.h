@@ -52,8 +52,10 @@ void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, 
 template <class Fq>
 void launch_ds_table(hipStream_t st, const u32* win_table, u32 n, u32 c, u32 W, u32* xyzz_scratch, u32* table);
 template <class Fq>
-u32 launch_direct_sum(hipStream_t st, const u32* table, u32 key_n, u32 base_off, const u32* scalars, int mont, u32 n, u32 m, u32* flags,
-                      u32* partials);
+// group_shift >= 0: two sums by that bit of the scalar's index (n a multiple of 512 and of 2 << group_shift): class c's records
+// are partials[c * blocks / 2 ...]
+u32 launch_direct_sum(hipStream_t st, const u32* table, u32 key_n, u32 base_off, const u32* scalars, int mont, u32 n, u32 m,
+                      int group_shift, u32* flags, u32* partials);
 template <class Fq>
 void launch_apply_inf(hipStream_t st, u32* table, const uint8_t* is_inf, u32 n);
 template <class Fq>

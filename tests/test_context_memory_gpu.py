@@ -15,7 +15,7 @@ def test_workspace_allocator_and_trim(cref):
         lib = ctx._lib
         m0 = ctx.memory()
         assert m0["workspace_bytes"] == 0 and m0["vectors_live_bytes"] == 0
-        n = 1 << 15  # (keys of up to 2^14 generators are summed straight from their table: a few KiB of workspace)
+        n = 1 << 16  # (keys of up to 2^15 generators are summed straight from their table: a few KiB of workspace)
         ck = CommitterKey.generate(ctx, 3, n)
         v = ctx.random_vector(5, n, mont=False)
         ref, ref_inf = VariableBaseMSM.multi_scalar_mul(ck, v)

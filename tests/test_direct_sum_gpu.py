@@ -1,4 +1,4 @@
-"""Round 4, the latency regime: precomputed keys of up to 2^14 generators also hold every multiple a 4-bit signed digit can ask
+"""Round 4, the latency regime: precomputed keys of up to 2^15 generators also hold every multiple a 4-bit signed digit can ask
 for (j 2^(4w) G_i, j = 1 .. 8, w = 0 .. 63) and an MSM over them is ONE launch that sums table points plus the quad fold
 (msm_kernels.h `k_direct_sum`): no buckets, no sort, no dependence on the digit distribution.  Against the CPU restatement
 oracle/ark_msm.c and the big-int oracle, bit for bit: every size class, ranges, the digit recoding's corner values (s + 0x0888..8
@@ -178,22 +178,42 @@ def test_scalars_that_do_not_fit_are_reported(env, cref):
     _msm(c, ctx, ck, xy, cref.rng_scalars(0xC501, n), cref)  # the slot's flag words were left clear
 
 
-def test_grouped_msm_keeps_the_windowed_pipelines(env, cref):
+@pytest.mark.parametrize("n,shift", [(512, 0), (512, 7), (1024, 8), (1024, 9), (4096, 3), (4096, 0), (8192, 12), (16384 - 512, 8), (16384 - 512, 5)])
+def test_grouped_msm_as_two_direct_sums(env, cref, n, shift):
+    """amsm_msm_grouped_device (the IPA rounds: two sums by one bit of the scalar's index) over a small key: one launch whose
+    workgroups each sum ONE class, a two-record fold -- whenever both classes fill whole workgroups (n a multiple of 512 and of
+    2 << shift)"""
     from accumulation_amd import VariableBaseMSM
     c, ctx, ck, xy, N = env
-    n = 4096
-    sc = cref.rng_scalars(0xC600, n)
+    sc = cref.rng_scalars(0xC600 + n + shift, n)
+    if n == 4096 and shift == 0:
+        sc[5] = 0
+        sc[6:200] = sc[7]  # runs of equal scalars on neighbouring generators
     before = ctx.pipeline_stats()["direct_sum"]
-    pts, infs = VariableBaseMSM.multi_scalar_mul_grouped(ck, ctx.upload(sc), 3, mont=False)
-    assert ctx.pipeline_stats()["direct_sum"] == before
-    cls = (np.arange(n) >> 3) & 1
+    pts, infs = VariableBaseMSM.multi_scalar_mul_grouped(ck, ctx.upload(sc), shift, mont=False)
+    assert ctx.pipeline_stats()["direct_sum"] - before == (1 if n % (2 << shift) == 0 else 0)
+    cls = (np.arange(n) >> shift) & 1
     for g in (0, 1):
         ref, rinf = cref.msm(c.curve_id, xy[:n][cls == g], sc[cls == g], threads=8)
-        assert bool(infs[g]) == bool(rinf) and np.array_equal(pts[g], ref)
+        assert bool(infs[g]) == bool(rinf) and np.array_equal(pts[g], ref), g
+
+
+def test_grouped_msm_of_other_lengths_keeps_the_windowed_pipelines(env, cref):
+    from accumulation_amd import VariableBaseMSM
+    c, ctx, ck, xy, N = env
+    for n, shift in ((4000, 3), (300, 2), (1024, 10)):
+        sc = cref.rng_scalars(0xC680 + n, n)
+        before = ctx.pipeline_stats()["direct_sum"]
+        pts, infs = VariableBaseMSM.multi_scalar_mul_grouped(ck, ctx.upload(sc), shift, mont=False)
+        assert ctx.pipeline_stats()["direct_sum"] == before
+        cls = (np.arange(n) >> shift) & 1
+        for g in (0, 1):
+            ref, rinf = cref.msm(c.curve_id, xy[:n][cls == g], sc[cls == g], threads=8)
+            assert bool(infs[g]) == bool(rinf) and (rinf or np.array_equal(pts[g], ref)), (n, shift, g)
 
 
 def test_switched_off_and_larger_keys(cref):
-    """AMSM_DIRECT_SUM_MAX_LOG2=0: no table, the windowed pipelines, the same points; a key of 2^14 + 1 generators has none either;
+    """AMSM_DIRECT_SUM_MAX_LOG2=0: no table, the windowed pipelines, the same points; a key of 2^15 + 1 generators has none either;
     amsm_bases_memory counts the table"""
     from accumulation_amd import CommitterKey, Context, VariableBaseMSM
     c = o.PALLAS
@@ -218,8 +238,31 @@ def test_switched_off_and_larger_keys(cref):
     for r in res[1:]:
         assert np.array_equal(r[0], res[0][0]) and r[1] == res[0][1]
     ctx = Context(c.curve_id)
-    ck = CommitterKey.generate(ctx, 0x5EED6005, (1 << 14) + 1, PRECOMP)
+    ck = CommitterKey.generate(ctx, 0x5EED6005, (1 << 15) + 1, PRECOMP)
     VariableBaseMSM.multi_scalar_mul(ck, cref.rng_scalars(0xC701, 100))
     assert ctx.pipeline_stats()["direct_sum"] == 0
     ck.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_largest_default_key(cref, c):
+    """2^15 generators (a 1 / 1.5 GiB table): the whole key, a ragged range, a grouped MSM"""
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    ctx = Context(c.curve_id)
+    try:
+        n = 1 << 15
+        ck = CommitterKey.generate(ctx, 0x5EED6006, n, PRECOMP)
+        xy, _ = ck.read()
+        _msm(c, ctx, ck, xy, cref.rng_scalars(0xC800, n), cref)
+        _msm(c, ctx, ck, xy, cref.rng_scalars(0xC801, 20001), cref, off=12000)
+        sc = cref.rng_scalars(0xC802, n)
+        pts, infs = VariableBaseMSM.multi_scalar_mul_grouped(ck, ctx.upload(sc), 14, mont=False)
+        assert ctx.pipeline_stats()["direct_sum"] == 3
+        cls = (np.arange(n) >> 14) & 1
+        for g in (0, 1):
+            ref, rinf = cref.msm(c.curve_id, xy[cls == g], sc[cls == g], threads=8)
+            assert bool(infs[g]) == bool(rinf) and np.array_equal(pts[g], ref), g
+        ck.free()
+    finally:
+        ctx.close()
