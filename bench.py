@@ -161,7 +161,7 @@ def main() -> int:
                 dist.barrier()
             torch.cuda.synchronize()
 
-        # Clock ramp (round 4, measured: tools/_fill4.py in profiles/r04_experiments.md section 9): after ANY idle of the device --
+        # Clock ramp (round 4, measured: tools/clock_ramp.py in profiles/r04_experiments.md section 9): after ANY idle of the device --
         # 50 ms are enough -- the first ~30 ms of MSMs run ~10 % slower than the steady state (20 MSMs right after idle: 1.18-1.25
         # ms each, the next 20: 1.12; chunks of 5 after idle: 1.48, 1.33, 1.27, 1.24, 1.22), and the driver's `--steps 20 --warmup 5`
         # puts the whole timed region inside that ramp.  A prover commits back to back for seconds: the steady state is the regime

@@ -1,3 +1,5 @@
+"""Clock ramp after idle (profiles/r04_experiments.md section 9): 2^20-pair MSMs over the 20-bit key in batches of 20 / 5 after
+idle gaps of 50 ms / 1 s, ms per MSM -- what `bench.py`'s preheat is for.  Not a test."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,5 @@
+"""Host-slice batches against device-resident vectors (profiles/r04_experiments.md section 8): pageable / page-locked slices in
+batches of 12 and 48 MSMs of 2^20 pairs, and the raw copy rates.  Not a test."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,5 @@
+"""A SECOND context on a torch stream in a process that already holds one (profiles/r04_experiments.md section 9): stream creation
+order decides which hardware queues the pipeline's three streams share.  Not a test."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,3 +1,5 @@
+"""`combine_vectors` at n = 2 .. 8, arbitrary / unit first coefficient (profiles/r04_experiments.md section 11); run under
+AMSM_VEC_SAT=0 for round 3's 9 x 29-limb kernels.  Not a test."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from accumulation_amd import Context, ffi
