@@ -29,6 +29,10 @@ n_big = n_fold = n_adv = n_bpl = 0
 # 20-bit precomputed key (FUZZ_BIG_LOG2=20) -- on mostly uniform scalars with edge values sprinkled in
 BPL_FRACTION = float(os.environ.get("FUZZ_BPL_FRACTION", "0.0"))
 PALLAS_FRACTION = float(os.environ.get("FUZZ_PALLAS_FRACTION", "0.7"))  # the rest of the cases run on BLS12-381
+# round 4: share of cases on the direct sum (precomputed keys of up to 2^15 generators, automatic window: DESIGN.md 4.2g) -- every
+# call form, grouped MSMs at lengths that are / are not multiples of 512, every scalar distribution, adversarial points in the key
+DIRECT_FRACTION = float(os.environ.get("FUZZ_DIRECT_FRACTION", "0.0"))
+n_direct = 0
 # points with extreme coordinates in the device's internal Montgomery radix (tests/golden/adversarial_points.json) and their
 # negatives: mixed into a third of the keys, with repetitions, so that equal / opposite / edge-valued operands meet in buckets
 import json  # noqa: E402
@@ -89,6 +93,65 @@ while time.time() < t_end:
                 assert bool(infs[g]) == bool(rinf) and (rinf or np.array_equal(outs[g], ref)), (tag, shift, g)
         ck.free()
         n_bpl += 1
+        n_cases += 1
+        continue
+    if rs.rand() < DIRECT_FRACTION:
+        n_key = int(rs.choice([1, 2, 3, 17, 255, 256, 511, 512, 513, 1000, 1024, 4097, 8192, 20000, 32768])) if rs.rand() < 0.7 \
+            else int(rs.randint(1, (1 << 15) + 1))
+        xy = pools[c.name][:n_key]
+        if rs.rand() < 0.35:
+            xy = xy.copy()
+            k = int(rs.randint(1, min(n_key, 24) + 1))
+            xy[rs.randint(0, n_key, size=k)] = adv[c.name][rs.randint(0, len(adv[c.name]), size=k)]
+            n_adv += 1
+        ck = CommitterKey.load(ctx, xy, None, 1)
+        kind = str(rs.choice(["uniform", "few", "sparse", "top"]))
+        mode = str(rs.choice(["single", "batch", "multi", "grouped", "grouped"]))
+        off = int(rs.randint(0, n_key)) if rs.rand() < 0.3 else 0
+        n = int(rs.randint(1, n_key - off + 1))
+        tag = ("direct", c.name, n_key, kind, mode, off, n)
+        before = ctx.pipeline_stats()["direct_sum"]
+        expect = None
+        if mode == "single":
+            sc = scalars(c, n, kind)
+            out, inf = VariableBaseMSM.multi_scalar_mul(ck, ctx.upload(sc) if rs.rand() < 0.5 else sc, base_off=off)
+            ref, rinf = cref.msm(c.curve_id, xy[off:off + n], sc, threads=4)
+            assert inf == rinf and np.array_equal(out, ref), tag
+            expect = 1 if n < (1 << 14) else None  # (from 2^14 pairs the two-valued shortcut may take a "few" / "top" vector)
+        elif mode == "batch":
+            vs = [scalars(c, n, kind) for _ in range(int(rs.randint(1, 6)))]
+            outs, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(v) for v in vs], mont=False, base_off=off)
+            for j, v in enumerate(vs):
+                ref, rinf = cref.msm(c.curve_id, xy[off:off + n], v, threads=4)
+                assert bool(infs[j]) == rinf and np.array_equal(outs[j], ref), (tag, j)
+            expect = len(vs) if n < (1 << 14) else None
+        elif mode == "multi":
+            jobs = []
+            for _ in range(int(rs.randint(1, 5))):
+                o2 = int(rs.randint(0, n_key))
+                n2 = int(rs.randint(1, n_key - o2 + 1))
+                jobs.append((o2, scalars(c, n2, kind)))
+            outs, infs = VariableBaseMSM.multi_scalar_mul_multi(ck, [(o2, ctx.upload(v)) for o2, v in jobs], mont=False)
+            for j, (o2, v) in enumerate(jobs):
+                ref, rinf = cref.msm(c.curve_id, xy[o2:o2 + len(v)], v, threads=4)
+                assert bool(infs[j]) == rinf and np.array_equal(outs[j], ref), (tag, j)
+        else:
+            if rs.rand() < 0.7 and n_key - off >= 512:
+                n = 512 * int(rs.randint(1, (n_key - off) // 512 + 1))  # the lengths whose classes fill whole workgroups
+            sc = scalars(c, n, kind)
+            shift = int(rs.randint(0, 15))
+            outs, infs = VariableBaseMSM.multi_scalar_mul_grouped(ck, ctx.upload(sc), shift, mont=False, base_off=off)
+            idx = np.arange(n)
+            for g in (0, 1):
+                m = sc.copy()
+                m[((idx >> shift) & 1) != g] = 0
+                ref, rinf = cref.msm(c.curve_id, xy[off:off + n], m, threads=4)
+                assert bool(infs[g]) == rinf and np.array_equal(outs[g], ref), (tag, shift, g)
+            expect = 1 if (n % 512 == 0 and n % (2 << shift) == 0) else 0
+        if expect is not None:
+            assert ctx.pipeline_stats()["direct_sum"] - before == expect, (tag, expect)
+        ck.free()
+        n_direct += 1
         n_cases += 1
         continue
     if roll < 0.02:
@@ -192,5 +255,5 @@ while time.time() < t_end:
     ck.free()
     ctx.set_window(0)
     n_cases += 1
-print(f"fuzz ok: {n_cases} cases ({n_big} large skewed, {n_fold} key folds, {n_adv} keys with adversarial points, {n_bpl} bucket-per-lane geometries) "
+print(f"fuzz ok: {n_cases} cases ({n_big} large skewed, {n_fold} key folds, {n_adv} keys with adversarial points, {n_bpl} bucket-per-lane geometries, {n_direct} direct sums) "
       f"in {budget:.0f} s (seed {seed}); pipeline stats: " + ", ".join(f"{k} {v.pipeline_stats()}" for k, v in ctxs.items()))
