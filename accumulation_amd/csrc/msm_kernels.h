@@ -704,9 +704,11 @@ __global__ void __launch_bounds__(256) k_ds_multiples(u32* __restrict__ xyzz, u3
 }
 template <class Fq, class Fr>
 __global__ void __launch_bounds__(256)
-    k_direct_sum(const u32* __restrict__ table, u32 key_n, u32 base_off, const u32* __restrict__ scalars, int mont, u32 n, u32 m,
-                 int group_shift, u32* __restrict__ flags, u32* __restrict__ partials) {
+    k_direct_sum(const u32* __restrict__ table, u32 key_n, DsBatch b, int mont, u32 m, int group_shift, u32* __restrict__ flags,
+                 u32* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
+  const u32 v = blockIdx.y, n = b.n[v], base_off = b.base_off[v];  // which MSM of the batch (its records: partials[v * gridDim.x ...])
+  const u32* __restrict__ scalars = b.scalars[v];
   const u32 L = blockIdx.x * 256u + threadIdx.x;
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   // grouped (two sums by bit group_shift of the scalar's index: the IPA rounds): every slab of n lanes takes the indices of class
@@ -753,7 +755,7 @@ __global__ void __launch_bounds__(256)
   }
   group_reduce_xyzz<Fq, 4>(acc);  // one-lane additions: afterwards the four lanes of a quad hold the same sum
   block_reduce_xyzz_quad<Fq>(acc, lds);
-  if (threadIdx.x == 0) xyzz_store<Fq>(partials, out_idx, acc);
+  if (threadIdx.x == 0) xyzz_store<Fq>(partials, (size_t)v * gridDim.x + out_idx, acc);
 }
 
 // fold: wave b sums records [b*n, (b+1)*n) (lane-strided + shuffle butterfly) and writes out[b] (C-ABI radix).

@@ -146,5 +146,12 @@ struct TVecArgs {
 
 // direct sum over a small key's table of digit multiples (msm_kernels.h k_direct_sum): 64 four-bit windows, multiples 1 .. 8
 constexpr u32 DS_W = 64, DS_MULT = 8;
+// up to DS_BATCH MSMs over the same key in one launch (blockIdx.y = which): the provers' batched commits
+constexpr int DS_BATCH = 16;
+struct DsBatch {
+  const u32* scalars[DS_BATCH];
+  u32 n[DS_BATCH];
+  u32 base_off[DS_BATCH];
+};
 
 }  // namespace amsm

@@ -266,3 +266,42 @@ def test_largest_default_key(cref, c):
         ck.free()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("k", [2, 5, 16, 17, 40])
+def test_batches_of_ragged_msms_in_one_launch(env, cref, k):
+    """amsm_msm_multi: up to 16 MSMs of different lengths and offsets per launch (blockIdx.y), the rest in further launches"""
+    from accumulation_amd import VariableBaseMSM
+    c, ctx, ck, xy, N = env
+    rs = np.random.RandomState(k)
+    jobs = []
+    for j in range(k):
+        off = int(rs.randint(0, N - 1))
+        n = int(rs.randint(1, min(N - off, 3000) + 1)) if j % 5 else N - off
+        jobs.append((off, cref.rng_scalars(0xC900 + 100 * k + j, n)))
+    before = ctx.pipeline_stats()["direct_sum"]
+    outs, infs = VariableBaseMSM.multi_scalar_mul_multi(ck, [(off, ctx.upload(v)) for off, v in jobs], mont=False)
+    assert ctx.pipeline_stats()["direct_sum"] - before == k
+    for j, (off, v) in enumerate(jobs):
+        ref, rinf = cref.msm(c.curve_id, xy[off:off + len(v)], v, threads=8)
+        assert bool(infs[j]) == bool(rinf) and np.array_equal(outs[j], ref), j
+
+
+def test_batch_with_an_empty_vector_and_a_bad_scalar(env, cref):
+    from accumulation_amd import VariableBaseMSM, ffi
+    c, ctx, ck, xy, N = env
+    vs = [cref.rng_scalars(0xCA00 + j, 700) for j in range(4)]
+    jobs = [(0, ctx.upload(vs[0])), (N, ctx.upload(vs[1])), (5, ctx.upload(vs[2]))]  # the second starts at the key's end: identity
+    outs, infs = VariableBaseMSM.multi_scalar_mul_multi(ck, jobs, mont=False)
+    assert bool(infs[1])
+    for j, off in ((0, 0), (2, 5)):
+        ref, rinf = cref.msm(c.curve_id, xy[off:off + 700], vs[j], threads=4)
+        assert np.array_equal(outs[j], ref) and not infs[j]
+    bad = vs[3].copy()
+    bad[123] = np.array(o.int_to_limbs((1 << 256) - 5, 4), dtype=np.uint64)
+    with pytest.raises(ffi.AmsmError) as e:
+        VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(vs[0]), ctx.upload(bad), ctx.upload(vs[2])], mont=False)
+    assert e.value.status == ffi.AMSM_E_SCALAR_RANGE
+    pts, _ = VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(vs[0]), ctx.upload(vs[2])], mont=False)  # flags left clear
+    ref, _ = cref.msm(c.curve_id, xy[:700], vs[2], threads=4)
+    assert np.array_equal(pts[1], ref)
