@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .engine import CommitterKey, Context, PedersenCommitment
+from .engine import CommitterKey, Context, PedersenCommitment, VariableBaseMSM
 from .hp_as import ASForHadamardProducts, MalformedAccumulator, MalformedInput, _pt_eq
 from .scalar_field import Fr
 from .sponge import CryptographicSponge, Sha256Sponge
@@ -113,6 +113,28 @@ class TrivialPC:
         vec.free()
         return LabeledCommitment(out)
 
+    @staticmethod
+    def commit_many(ck: CommitterKey, polys) -> list:
+        """several commitments under one key in ONE library call (amsm_msm_multi_device: small keys sum them in a single launch);
+        the same points as len(polys) calls of commit()"""
+        ctx = ck.ctx
+        fr = Fr(ctx.curve)
+        out = [LabeledCommitment((np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64), True)) for _ in polys]
+        jobs, which = [], []
+        for k, poly in enumerate(polys):
+            n = min(len(poly.coeffs), len(ck))
+            if n == 0:
+                continue
+            jobs.append((0, ctx.upload(fr.to_limbs_many([c % fr.r for c in poly.coeffs[:n]]))))
+            which.append(k)
+        if jobs:
+            pts, infs = VariableBaseMSM.multi_scalar_mul_multi(ck, jobs, mont=True)
+            for j, k in enumerate(which):
+                out[k] = LabeledCommitment((pts[j].copy(), bool(infs[j])))
+            for _, v in jobs:
+                v.free()
+        return out
+
     @classmethod
     def check(cls, vk: CommitterKey, commitment: LabeledCommitment, point: int, value: int,
               polynomial: LabeledPolynomial) -> bool:
@@ -207,7 +229,7 @@ class ASForTrivialPC:
         # steps 1c-1d: witness polynomials w = (p - v) / (X - z) and their commitments (:181-222)
         wit_polys = [LabeledPolynomial(_poly_div_linear(fr, w.coeffs, inst.eval, inst.point))
                      for inst, w in zip(instances, witnesses)]
-        wit_comms = [TrivialPC.commit(pk, wp) for wp in wit_polys]
+        wit_comms = TrivialPC.commit_many(pk, wit_polys)  # (the reference commits one by one, :198)
         # step 2: challenge point
         z = cls._challenge_point(fr, sponge, TrivialPC.supported_degree(pk), instances, wit_comms)
         # steps 3-4: evaluations at the challenge point, linear-combination challenges

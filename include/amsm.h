@@ -63,7 +63,8 @@ enum amsm_status {
 
 /* flags for amsm_bases_load / amsm_bases_generate */
 enum amsm_bases_flags {
-  AMSM_BASES_DEFAULT = 0,      /* library picks (precompute when the key is large enough to benefit) */
+  AMSM_BASES_DEFAULT = 0,      /* library picks: precomputed whenever the table fits (round 4: at every size -- keys of up to
+                                  2^15 generators also get the direct-sum table, see amsm_ctx_direct_sum_msms) */
   AMSM_BASES_PRECOMPUTE = 1,   /* keep 2^(c*w)*G_i for every window w resident in HBM (W x memory); creation fails with
                                   AMSM_E_OOM / AMSM_E_UNSUPPORTED (n * W >= 2^30) when the table cannot be built --
                                   only AMSM_BASES_DEFAULT falls back to a plain key (amsm_bases_precomputed() tells) */
@@ -139,7 +140,8 @@ int amsm_ctx_synchronize(amsm_ctx* ctx);
  * amsm_ctx_trim synchronises and releases the workspace and the free lists (live buffers and keys stay). */
 int amsm_ctx_memory(const amsm_ctx* ctx, size_t* workspace_bytes, size_t* vectors_live_bytes, size_t* vectors_pooled_bytes);
 int amsm_ctx_trim(amsm_ctx* ctx);
-/* Device memory a key holds: its table (W levels of affine points when precomputed, the generators otherwise), the C-ABI-radix
+/* Device memory a key holds: its table (W levels of affine points when precomputed -- plus 512 points per generator for a key of up
+ * to 2^15 generators, the direct-sum table -- the generators otherwise), the C-ABI-radix
  * copy amsm_bases_device_ptr made (0 if never asked), and the 17-bit-window TWIN of a 20-bit key -- built lazily, inside the
  * first MSM that needs it (a range below a quarter of 2^20 pairs, a vector with skewed digits; round 3 also grouped MSMs),
  * about as large as the table itself: 0 until then.  amsm_bases_prebuild_twin builds it NOW (at key-creation time, on the

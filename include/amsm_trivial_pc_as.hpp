@@ -6,6 +6,8 @@
 // combination of the witness polynomials -- is sequential host arithmetic in the reference and here (amsm_fr_*).
 // Same structure and same stand-in sponge as accumulation_amd/trivial_pc_as.py; tests compare the two byte for byte.
 #pragma once
+#include <memory>
+
 #include "amsm_hp_as.hpp"
 
 namespace amsm {
@@ -75,6 +77,25 @@ struct TrivialPC {  // setup / trim / commit / check (ext)
     FrVector v(ck.ctx(), std::vector<Fr>(poly.coeffs.begin(), poly.coeffs.begin() + (long)n));
     return LabeledCommitment{PedersenCommitment::commit(ck, v), {}};
   }
+  // several commitments under one key in ONE library call (amsm_msm_multi_device: small keys sum them in a single launch) --
+  // the same points as polys.size() calls of commit()
+  static std::vector<LabeledCommitment> commit_many(const CommitterKey& ck, const std::vector<const LabeledPolynomial*>& polys) {
+    std::vector<LabeledCommitment> out(polys.size(), InputInstance::zero(ck.ctx()).commitment);
+    std::vector<std::unique_ptr<FrVector>> vecs;
+    std::vector<std::pair<size_t, const FrVector*>> jobs;
+    std::vector<size_t> which;
+    for (size_t k = 0; k < polys.size(); k++) {
+      size_t n = std::min(polys[k]->coeffs.size(), ck.supported_num_elems());
+      if (n == 0) continue;
+      vecs.push_back(std::make_unique<FrVector>(ck.ctx(), std::vector<Fr>(polys[k]->coeffs.begin(), polys[k]->coeffs.begin() + (long)n)));
+      jobs.push_back({0, vecs.back().get()});
+      which.push_back(k);
+    }
+    if (jobs.empty()) return out;
+    std::vector<Affine> pts = MsmBatch::windows(ck, jobs);
+    for (size_t j = 0; j < which.size(); j++) out[which[j]] = LabeledCommitment{pts[j], {}};
+    return out;
+  }
   // check_individual_opening_challenges with one commitment and opening challenge 1: the proof IS the polynomial
   static bool check(const CommitterKey& vk, const LabeledCommitment& c, const Fr& point, const Fr& value,
                     const LabeledPolynomial& polynomial) {
@@ -127,11 +148,11 @@ class ASForTrivialPC {
     }
     // steps 1c-1d: witness polynomials w = (p - v) / (X - z) and their commitments (:181-222)
     std::vector<LabeledPolynomial> wit_polys;
-    std::vector<LabeledCommitment> wit_comms;
-    for (size_t k = 0; k < instances.size(); k++) {
+    for (size_t k = 0; k < instances.size(); k++)
       wit_polys.push_back(LabeledPolynomial{poly_div_linear(fr, witnesses[k]->coeffs, instances[k]->point), {}, {}});
-      wit_comms.push_back(TrivialPC::commit(pk, wit_polys.back()));
-    }
+    std::vector<const LabeledPolynomial*> wit_ptrs;
+    for (auto& w : wit_polys) wit_ptrs.push_back(&w);
+    std::vector<LabeledCommitment> wit_comms = TrivialPC::commit_many(pk, wit_ptrs);  // (the reference commits one by one, :198)
     Fr z = challenge_point(fr, sponge, TrivialPC::supported_degree(pk), instances, wit_comms);  // step 2
     Proof proof;  // steps 3-4
     for (size_t k = 0; k < instances.size(); k++)
