@@ -8,6 +8,11 @@
 // challenge / point algebra stays on the host.  Same structure and stand-in sponge as accumulation_amd/ipa_pc.py and
 // ipa_pc_as.py; tests compare the two byte for byte.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <future>
+
 #include "amsm_hp_as.hpp"
 
 namespace amsm {
@@ -430,11 +435,21 @@ class AtomicASForInnerProductArgPC {
       Affine comm = deterministic_commit(pk.verifier_key.ipa_ck_linear, lin);
       proof = Randomness{lin, comm, fr.to_mont(rng())};
     }
+    // AMSM_IPA_TRACE=1: wall time of the prover's stages on stderr (where a prove's host time goes)
+    static const bool trace = [] { const char* e = getenv("AMSM_IPA_TRACE"); return e && atoi(e) != 0; }();
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+      if (!trace) return;
+      auto t = std::chrono::steady_clock::now();
+      fprintf(stderr, "[ipa_pc_as prove] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+      t_prev = t;
+    };
     std::vector<Check> checks;
-    succinct_checks(ctx, pk.verifier_key.ipa_svk, ins, false, checks);
-    succinct_checks(ctx, pk.verifier_key.ipa_svk, olds, true, checks);
+    succinct_checks(ctx, pk.verifier_key.ipa_svk, ins, olds, checks);
+    mark("succinct checks");
     Sponge as_sponge = Sponge().fork("AS-FOR-IPA-PC-2020");
     Combined comb = combine(ctx, fr, pk.verifier_key.ipa_svk, checks, proof, as_sponge);
+    mark("combine");
     // combined check polynomial on the device: sum_i alpha_i * h_i (+ random linear polynomial)  :391-404
     std::vector<std::unique_ptr<FrVector>> vecs;
     std::vector<const void*> ptrs;
@@ -459,15 +474,19 @@ class AtomicASForInnerProductArgPC {
     } else {
       poly.reset(new FrVector(ctx, std::vector<Fr>{fr.zero()}));
     }
+    mark("check polynomials (device)");
     Fr challenge_canon = new_challenge(fr, as_sponge, comb.combined, comb.alphas_canon, checks,
                                        proof ? &proof->random_linear_polynomial : nullptr);
     Fr challenge = fr.to_mont(challenge_canon);
+    mark("new challenge");
     // compute_new_accumulator :424-472: evaluate, then ONE IPA opening of the combined polynomial
     FrVector z(ctx, poly->len());
     check(amsm_vec_powers(ctx.get(), challenge.data(), poly->len(), z.ptr()), "amsm_vec_powers");
     Fr evaluation = Ipa::inner_product(ctx, poly->ptr(), z.ptr(), poly->len());
+    mark("evaluation");
     ipa_pc::Proof ipa_proof = Ipa::open(ipa_ck, *poly, comb.randomized, challenge, proof ? proof->commitment_randomness : fr.zero(),
                                         proof.has_value(), rng);
+    mark("open");
     return {InputInstance{comb.randomized, challenge, evaluation, ipa_proof}, proof};
   }
 
@@ -484,8 +503,7 @@ class AtomicASForInnerProductArgPC {
       ins.push_back(InputInstance{Commitment{ipa_pc::zero_point(ctx), {}}, fr.zero(), fr.zero(), vk.default_proof});
     std::vector<Check> checks;
     try {
-      succinct_checks(ctx, vk.ipa_svk, ins, false, checks);
-      succinct_checks(ctx, vk.ipa_svk, olds, true, checks);
+      succinct_checks(ctx, vk.ipa_svk, ins, olds, checks);
     } catch (const hp_as::ASError&) {
       return false;
     }
@@ -544,15 +562,28 @@ class AtomicASForInnerProductArgPC {
     sc.resize(2, Fr{0, 0, 0, 0});
     return host_lincomb(ctx, {&g0, &g1}, sc);
   }
-  static void succinct_checks(Context& ctx, const ipa_pc::SuccinctVerifierKey& svk, const std::vector<InputInstance>& instances, bool accs,
-                              std::vector<Check>& out) {  // :190-221
-    for (auto& inst : instances) {
-      auto cp = Ipa::succinct_check(ctx, svk, inst.ipa_commitment, inst.point, inst.evaluation, inst.ipa_proof);
-      if (!cp) {
-        if (accs) throw MalformedAccumulator("Succinct check failed on accumulator.");
+  // :190-221, inputs first, then accumulators.  Every check is host work -- a chain of log d sponge challenges and one 2 log d + 2
+  // point combination (0.5-0.8 ms at d + 1 = 2^16) -- and independent of the others: one thread each (the reference runs them in
+  // sequence; same results, same order, and the error of the FIRST failing instance)
+  static void succinct_checks(Context& ctx, const ipa_pc::SuccinctVerifierKey& svk, const std::vector<InputInstance>& ins,
+                              const std::vector<InputInstance>& olds, std::vector<Check>& out) {
+    std::vector<const InputInstance*> all;
+    for (auto& x : ins) all.push_back(&x);
+    for (auto& x : olds) all.push_back(&x);
+    std::vector<std::future<std::optional<ipa_pc::SuccinctCheckPolynomial>>> futs;
+    auto one = [&ctx, &svk](const InputInstance* inst) {
+      return Ipa::succinct_check(ctx, svk, inst->ipa_commitment, inst->point, inst->evaluation, inst->ipa_proof);
+    };
+    for (size_t k = 1; k < all.size(); k++) futs.push_back(std::async(std::launch::async, one, all[k]));
+    std::vector<std::optional<ipa_pc::SuccinctCheckPolynomial>> cps;
+    if (!all.empty()) cps.push_back(one(all[0]));  // (the caller's thread takes the first)
+    for (auto& f : futs) cps.push_back(f.get());
+    for (size_t k = 0; k < all.size(); k++) {
+      if (!cps[k]) {
+        if (k >= ins.size()) throw MalformedAccumulator("Succinct check failed on accumulator.");
         throw MalformedInput("Succinct check failed on input.");
       }
-      out.push_back(Check{*cp, inst.ipa_proof.final_comm_key});
+      out.push_back(Check{*cps[k], all[k]->ipa_proof.final_comm_key});
     }
   }
   // combine_succinct_check_polynomials_and_commitments :254-346
