@@ -115,7 +115,7 @@ def test_pallas_2p16_opening(hiding, fold_above):
 def test_bls12_381_2p20_opening(hiding, fold_above):
     """BASELINE config 3 (the 384-bit field path).  Default: five physical folds (the first through the 20-bit key's window
     multiples, the top four of which sit off the 20-bit grid -- MsmGeom::n_narrow), then 15 rounds over the 2^15-point key;
-    17: three folds, then 17 rounds of grouped bucket-per-lane MSMs over a plain 2^17-point key"""
+    17: three folds, then 17 rounds of grouped MSMs over a plain 2^17-point key (8-bit windows, the chunked pipeline)"""
     got, ref, accepted, ref_ok, stats = _open_both_ways(o.BLS12_381_G1, 20, hiding, fold_above)
     _assert_equal(got, ref, accepted, ref_ok)
     assert stats["fallbacks"] == 0
