@@ -52,8 +52,8 @@ void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, 
 template <class Fq>
 void launch_ds_table(hipStream_t st, const u32* win_table, u32 n, u32 c, u32 W, u32* xyzz_scratch, u32* table);
 // nv <= DS_BATCH MSMs over the key in one launch: MSM v's `blocks` records (the return value, sized by the longest vector) at
-// partials[v * blocks ...].  group_shift >= 0 (nv = 1): two sums by that bit of the scalar's index (n a multiple of 512 and of
-// 2 << group_shift): class c's records are partials[c * blocks / 2 ...]
+// partials[v * blocks ...].  group_shift >= 0 (nv = 1): two sums by that bit of the scalar's index (n a multiple of
+// 2 << group_shift): class c's `blocks` records are partials[c * blocks ...]
 template <class Fq>
 u32 launch_direct_sum(hipStream_t st, const u32* table, u32 key_n, u32 nv, const u32* const* scalars, const u32* ns, const u32* base_offs,
                       int mont, u32 m, int group_shift, u32* flags, u32* partials);

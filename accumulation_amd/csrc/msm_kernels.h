@@ -707,24 +707,21 @@ __global__ void __launch_bounds__(256)
     k_direct_sum(const u32* __restrict__ table, u32 key_n, DsBatch b, int mont, u32 m, int group_shift, u32* __restrict__ flags,
                  u32* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
-  const u32 v = blockIdx.y, n = b.n[v], base_off = b.base_off[v];  // which MSM of the batch (its records: partials[v * gridDim.x ...])
+  // blockIdx.y: which MSM of the batch -- or, grouped (two sums by bit group_shift of the scalar's index: the IPA rounds; one
+  // vector), which index CLASS: this row of workgroups walks the n / 2 indices of its class (n a multiple of 2 << group_shift, the
+  // launcher's condition).  Either way its records are partials[blockIdx.y * gridDim.x ...]
+  const bool grouped = group_shift >= 0;
+  const u32 v = grouped ? 0u : blockIdx.y, cls = grouped ? blockIdx.y : 0u;
+  const u32 n = grouped ? b.n[0] >> 1 : b.n[v], base_off = b.base_off[v];
   const u32* __restrict__ scalars = b.scalars[v];
   const u32 L = blockIdx.x * 256u + threadIdx.x;
   XYZZ<Fq> acc = xyzz_inf<Fq>();
-  // grouped (two sums by bit group_shift of the scalar's index: the IPA rounds): every slab of n lanes takes the indices of class
-  // 0 first, then those of class 1 -- n / 2 each, a multiple of 256 (the launcher's condition), so a workgroup sums ONE class and
-  // its record goes to that class's half of `partials`
-  u32 out_idx = blockIdx.x;
-  if (group_shift >= 0) {
-    const u32 per_slab = n >> 8, slab = blockIdx.x / per_slab, r = blockIdx.x - slab * per_slab, cls = r >= (per_slab >> 1) ? 1u : 0u;
-    out_idx = cls * (gridDim.x >> 1) + slab * (per_slab >> 1) + (r - cls * (per_slab >> 1));
-  }
   if (L < n * (DS_W / m)) {
     const u32 g = L / n;
     u32 i = L - g * n;
-    if (group_shift >= 0) {
-      const u32 cls = i >= (n >> 1) ? 1u : 0u, jj = i - cls * (n >> 1), sh = (u32)group_shift;
-      i = ((jj >> sh) << (sh + 1u)) | (cls << sh) | (jj & ((1u << sh) - 1u));
+    if (grouped) {
+      const u32 sh = (u32)group_shift;
+      i = ((i >> sh) << (sh + 1u)) | (cls << sh) | (i & ((1u << sh) - 1u));
     }
     Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
     if (mont) s = fe_from_mont<Fr>(s);
@@ -755,7 +752,7 @@ __global__ void __launch_bounds__(256)
   }
   group_reduce_xyzz<Fq, 4>(acc);  // one-lane additions: afterwards the four lanes of a quad hold the same sum
   block_reduce_xyzz_quad<Fq>(acc, lds);
-  if (threadIdx.x == 0) xyzz_store<Fq>(partials, (size_t)v * gridDim.x + out_idx, acc);
+  if (threadIdx.x == 0) xyzz_store<Fq>(partials, (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc);
 }
 
 // fold: wave b sums records [b*n, (b+1)*n) (lane-strided + shuffle butterfly) and writes out[b] (C-ABI radix).

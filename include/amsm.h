@@ -112,9 +112,9 @@ unsigned long long amsm_ctx_two_valued_msms(const amsm_ctx* ctx);
 /* MSMs that were summed straight from a small key's table of digit multiples (round 4: precomputed keys of up to 2^15 generators --
  * AMSM_DIRECT_SUM_MAX_LOG2, at most 16, 0 turns it off -- also hold j 2^(4w) G_i for j = 1 .. 8, w = 0 .. 63, 512 affine points per
  * generator, so that an MSM is one launch of mixed additions and a tree: no buckets, no sort, no dependence on the digit
- * distribution).  Grouped MSMs (amsm_msm_grouped_device, the IPA rounds) are two such sums in one launch when each index class
- * fills whole workgroups (n a multiple of 512 and of 2 << group_shift), else they take the windowed pipelines.  Results do not
- * depend on the path. */
+ * distribution).  Grouped MSMs (amsm_msm_grouped_device, the IPA rounds) are two such sums in one launch -- one row of workgroups
+ * per index class -- whenever n is a multiple of 2 << group_shift (both classes then hold n / 2 indices), else they take the
+ * windowed pipelines.  Results do not depend on the path. */
 unsigned long long amsm_ctx_direct_sum_msms(const amsm_ctx* ctx);
 /* Which accumulation pipeline the context's MSMs took so far: *n_bucket_per_lane = MSMs enqueued on the bucket-per-lane
  * pipeline (keys of >= 2^20 generators, MSMs of (2^19, 2^20] pairs -- longer ones as windows of 2^20; 20-bit windows, 13

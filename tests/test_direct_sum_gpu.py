@@ -178,11 +178,12 @@ def test_scalars_that_do_not_fit_are_reported(env, cref):
     _msm(c, ctx, ck, xy, cref.rng_scalars(0xC501, n), cref)  # the slot's flag words were left clear
 
 
-@pytest.mark.parametrize("n,shift", [(512, 0), (512, 7), (1024, 8), (1024, 9), (4096, 3), (4096, 0), (8192, 12), (16384 - 512, 8), (16384 - 512, 5)])
+@pytest.mark.parametrize("n,shift", [(2, 0), (4, 1), (8, 0), (64, 5), (96, 4), (256, 7), (512, 0), (512, 7), (1024, 8), (1024, 9), (4000, 3), (4096, 3),
+                                     (4096, 0), (8192, 12), (16384 - 512, 8), (16384 - 512, 5)])
 def test_grouped_msm_as_two_direct_sums(env, cref, n, shift):
     """amsm_msm_grouped_device (the IPA rounds: two sums by one bit of the scalar's index) over a small key: one launch whose
-    workgroups each sum ONE class, a two-record fold -- whenever both classes fill whole workgroups (n a multiple of 512 and of
-    2 << shift)"""
+    two rows of workgroups each sum ONE class, a two-record fold -- whenever n is a multiple of 2 << shift (both classes then hold
+    n / 2 indices in the regular pattern)"""
     from accumulation_amd import VariableBaseMSM
     c, ctx, ck, xy, N = env
     sc = cref.rng_scalars(0xC600 + n + shift, n)
@@ -201,7 +202,7 @@ def test_grouped_msm_as_two_direct_sums(env, cref, n, shift):
 def test_grouped_msm_of_other_lengths_keeps_the_windowed_pipelines(env, cref):
     from accumulation_amd import VariableBaseMSM
     c, ctx, ck, xy, N = env
-    for n, shift in ((4000, 3), (300, 2), (1024, 10)):
+    for n, shift in ((4001, 3), (300, 2), (1024, 10)):
         sc = cref.rng_scalars(0xC680 + n, n)
         before = ctx.pipeline_stats()["direct_sum"]
         pts, infs = VariableBaseMSM.multi_scalar_mul_grouped(ck, ctx.upload(sc), shift, mont=False)
