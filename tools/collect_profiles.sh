@@ -21,6 +21,7 @@ cp $E/profile_as_ipa_pc_as_2p16_kernel_stats.csv profiles/${P}_profile_as_ipa_pc
 cp $E/profile_as_ipa_pc_as_2p16.jsonl profiles/${P}_profile_as_ipa_pc_as_2p16.jsonl
 cp gpurun_out/small16/chunked_kernel_stats.csv profiles/${P}_small16_chunked_kernel_stats.csv
 cp gpurun_out/small16/bps_kernel_stats.csv profiles/${P}_small16_bucket_split_kernel_stats.csv
+if [ -s gpurun_out/small16/direct12_kernel_stats.csv ]; then cp gpurun_out/small16/direct12_kernel_stats.csv profiles/${P}_small12_direct_sum_kernel_stats.csv; fi
 cp gpurun_out/mid_sizes.log profiles/${P}_mid_sizes.txt
 (for f in r1cs_nark_as_18_harness ipa_pc_as_16_n2 hp_as_22_harness ipa_pc_as_bls_20_n2; do
    echo "== $f  (rocprofv3 --kernel-trace of build/profile_as, whole run incl. set-up; tools/trace_busy.py)"
