@@ -46,6 +46,9 @@ void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, 
 template <class Fq>
 // level = 2^c * mul_m * (level - 1); mul_m = 0 / 1: no small multiple (power-of-two windows)
 void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c, u32* xyzz_scratch, u32 mul_m = 0);
+// levels 1 .. W - 1 of a small key (plain c-bit windows) from level 0 in two launches; xyzz_scratch: (W - 1) n records
+template <class Fq>
+void launch_precompute_all_levels(hipStream_t st, u32* table, u32 n, u32 c, u32 W, u32* xyzz_scratch);
 // Direct sum (msm_kernels.h k_direct_sum): the 512-points-per-generator table of a small key from its window table (W levels of
 // plain c-bit windows, device radix; xyzz_scratch: 512 n records), and one MSM as cdiv(n * 64 / m, 256) partial records
 // (returned) for launch_fold_quad

@@ -937,6 +937,21 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// All levels of a SMALL key in one pass (round 4): lane i walks its generator through the W - 1 levels (c doublings each) and
+// leaves them unconverted in xyzz_out[(w - 1) * n + i]; ONE k_batch_to_affine over (W - 1) n points follows.  The level-by-level
+// form costs a kernel with a Fermat inversion per point and level: 31 launches of 150 us for a 2^12-generator key.
+template <class Fq>
+__global__ void __launch_bounds__(64) k_precompute_all_levels(const u32* __restrict__ table, u32 n, u32 c, u32 W, u32* __restrict__ xyzz_out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Affine<Fq> p = affine_load<Fq>(table, i);
+  XYZZ<Fq> a = xyzz_from_affine<Fq>(p);
+  for (u32 w = 1; w < W; w++) {
+    for (u32 k = 0; k < c; k++) a = xyzz_dbl<Fq>(a);
+    xyzz_store<Fq>(xyzz_out, (size_t)(w - 1u) * n + i, a);
+  }
+}
+
 // out[i] = l[i] + x * r[i] for affine point vectors (the commitment-key fold `key_l += key_r * xi` of the IPA
 // opening, ark_poly_commit::ipa_pc ext, under src/ipa_pc_as/mod.rs:454): one lane per point, left-to-right
 // double-and-add over the `nbits` low bits of the canonical scalar x, then one inversion back to affine.
