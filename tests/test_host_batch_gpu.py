@@ -70,10 +70,11 @@ def test_batch_at_2p20_with_a_constant_vector_in_the_middle(cref, probe):
     c = o.PALLAS
     n = 1 << 20
     os.environ["AMSM_BPL_PROBE"] = probe
+    os.environ["AMSM_TWO_VALUED"] = "0"  # (with it a slice that looks two-valued sends the call down the device path: next test)
     try:
         ctx = Context(c.curve_id)
     finally:
-        del os.environ["AMSM_BPL_PROBE"]
+        del os.environ["AMSM_BPL_PROBE"], os.environ["AMSM_TWO_VALUED"]
     try:
         ck = CommitterKey.generate(ctx, 0x5EED1001, n)
         xy, _ = ck.read()
@@ -84,6 +85,31 @@ def test_batch_at_2p20_with_a_constant_vector_in_the_middle(cref, probe):
         after = ctx.pipeline_stats()
         took, fell = after["bucket_per_lane"] - before["bucket_per_lane"], after["fallbacks"] - before["fallbacks"]
         assert (took, fell) == ((4, 0) if probe == "1" else (5, 1))
+        for j, v in enumerate(vecs):
+            ref, rinf = cref.msm(c.curve_id, xy, v, threads=17)
+            assert bool(infs[j]) == bool(rinf) and np.array_equal(pts[j], ref), j
+        ck.free()
+    finally:
+        ctx.close()
+
+
+def test_batch_at_2p20_with_a_constant_slice_takes_the_two_valued_form(cref):
+    """the same five host slices with the two-valued shortcut on (the default): the constant one is v * (the sum of the
+    generators) -- no skew fallback, no twin -- and the four uniform ones run bucket-per-lane behind it"""
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    c = o.PALLAS
+    n = 1 << 20
+    ctx = Context(c.curve_id)
+    try:
+        ck = CommitterKey.generate(ctx, 0x5EED1001, n)
+        xy, _ = ck.read()
+        vecs = [cref.rng_scalars(70 + j, n) for j in range(5)]
+        vecs[2] = np.tile(h.scalars_to_np([o.rng_scalar(71, 0)]), (n, 1))
+        before, tv0 = ctx.pipeline_stats(), ctx.two_valued_msms()
+        pts, infs = VariableBaseMSM.multi_scalar_mul_batch_host(ck, vecs)
+        after = ctx.pipeline_stats()
+        assert (after["bucket_per_lane"] - before["bucket_per_lane"], after["fallbacks"] - before["fallbacks"]) == (4, 0)
+        assert ctx.two_valued_msms() - tv0 == 1 and ck.memory()["twin"] == 0
         for j, v in enumerate(vecs):
             ref, rinf = cref.msm(c.curve_id, xy, v, threads=17)
             assert bool(infs[j]) == bool(rinf) and np.array_equal(pts[j], ref), j

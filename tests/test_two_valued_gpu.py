@@ -96,6 +96,37 @@ def test_two_valued_vectors_in_a_batch_vs_c_oracle(env, curve, mont):
 
 
 @pytest.mark.parametrize("curve", CURVES, ids=["pallas", "bls12_381_g1"])
+def test_host_slices_that_look_two_valued_take_the_device_probe(env, curve):
+    """amsm_msm / amsm_msm_batch over HOST slices (the `&[Fr]` shape a Rust adapter passes: the reference harness's constant
+    vectors arrive this way): a 1024-sample look on the host sends the call's slices to the device path, whose exact probe decides
+    per vector -- the shortcut's vectors take it, the rest the regular pipelines, results as the C oracle's"""
+    from accumulation_amd import VariableBaseMSM
+    ctx, pre, plain, xy = env[curve]
+    n = (1 << 16) + 37
+    vecs = _vectors(curve, n)
+    names = ["constant", "uniform", "constant_with_zero_row", "eight_exceptions", "nine_exceptions", "boolean", "all_zero"]
+    for key in (pre, plain):
+        before = ctx.two_valued_msms()
+        out, inf = VariableBaseMSM.multi_scalar_mul_batch_host(key, [vecs[k][0] for k in names], mont=False)
+        assert ctx.two_valued_msms() - before == sum(1 for k in names if vecs[k][1])
+        for j, k in enumerate(names):
+            ref, ref_inf = cref.msm(curve, xy[:n], vecs[k][0])
+            assert bool(inf[j]) == bool(ref_inf) and np.array_equal(out[j], ref), (k, key.precomputed)
+        # a single host call (amsm_msm: uploaded, then the lone device vector's rules -- probed where another probe synchronises
+        # anyway or from 2^17 pairs up)
+        one, one_inf = VariableBaseMSM.multi_scalar_mul(key, vecs["one_exception_at_the_end"][0])
+        ref, ref_inf = cref.msm(curve, xy[:n], vecs["one_exception_at_the_end"][0])
+        assert bool(one_inf) == bool(ref_inf) and np.array_equal(one, ref)
+        # uniform slices only: nothing looks two-valued, the host path with its overlapped uploads
+        before = ctx.two_valued_msms()
+        out, inf = VariableBaseMSM.multi_scalar_mul_batch_host(key, [vecs["uniform"][0], vecs["uniform_behind_a_zero_head"][0]])
+        assert ctx.two_valued_msms() == before
+        for j, k in enumerate(("uniform", "uniform_behind_a_zero_head")):
+            ref, ref_inf = cref.msm(curve, xy[:n], vecs[k][0])
+            assert bool(inf[j]) == bool(ref_inf) and np.array_equal(out[j], ref), k
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=["pallas", "bls12_381_g1"])
 def test_windows_of_the_key_and_short_vectors(env, curve):
     """base_off != 0 (a window of the key) and vectors below the probe's minimum length (regular pipelines)."""
     from accumulation_amd import VariableBaseMSM
