@@ -29,6 +29,7 @@
 #include "host_poseidon.h"
 #include "host_serialize.h"
 #include "launch.h"
+#include "rng.h"
 
 using namespace amsm;
 
@@ -41,11 +42,14 @@ namespace {
 #include "api_host.inc"
 #include "api_schemes.inc"
 #include "api_multi.inc"
+#include "api_cpu.inc"
 
 #define DISPATCH(ctx, CALL_P, CALL_B)                   \
   ((ctx)->curve == AMSM_PALLAS ? (CALL_P) : (CALL_B))
 
 int bind_device(const amsm_ctx* ctx) {
+  // every entry point branches to the host backend BEFORE it binds a device; one that forgot to must fail, not touch HIP
+  if (ctx->host_only) return AMSM_E_UNSUPPORTED;
   HIP_TRY(hipSetDevice(ctx->device));
   return AMSM_OK;
 }

@@ -150,6 +150,7 @@ struct HostPool {
 struct amsm_ctx {
   int curve = 0;
   int device = 0;
+  bool host_only = false;  // the host backend (api_cpu.inc): device == AMSM_DEVICE_HOST, no stream, "device" pointers are host memory
   // One stream per pipeline STAGE, shared by all MSMs in flight (in-order per stage, so consecutive MSMs pipeline:
   // prep(k+1) and tail(k-1) run beside accumulate L0 of MSM k).  One stream per MSM instead made the overlap depend on
   // which hardware queues the runtime happened to map the streams to (measured 610-700 Mpairs/s for the same code).
@@ -267,6 +268,7 @@ struct amsm_ctx {
 struct amsm_bases {
   int curve = 0;
   int device = 0;
+  bool host = false;  // key of a host context: d_table is a host copy of the generators (C-ABI radix), nothing else is set
   size_t n = 0;
   int precomp = 0;
   int c = 0;  // window bits fixed at creation when precomputed
@@ -307,6 +309,7 @@ struct amsm_sponge {  // host-side Poseidon sponge over the curve's base field (
 struct amsm_matrix {
   int curve = 0;
   int device = 0;
+  bool host = false;  // matrix of a host context: the three arrays are host memory
   size_t n_rows = 0, nnz = 0;
   u32* d_row_ptr = nullptr;
   u32* d_col = nullptr;

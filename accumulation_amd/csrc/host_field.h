@@ -326,6 +326,35 @@ inline HXYZZ<P> hx_add(const HXYZZ<P>& a, const HXYZZ<P>& b) {
   o.zzz = h_mul<P>(h_mul<P>(a.zzz, b.zzz), ppp);
   return o;
 }
+// a += (x2, y2), an affine point that is not the identity (madd-2008-s; the host MSM's bucket accumulation)
+template <class P>
+inline void hx_madd(HXYZZ<P>& a, const HFe<P>& x2, const HFe<P>& y2) {
+  if (hx_is_inf<P>(a)) {
+    a.x = x2;
+    a.y = y2;
+    a.zz = a.zzz = h_one<P>();
+    return;
+  }
+  HFe<P> p = h_sub<P>(h_mul<P>(x2, a.zz), a.x), r = h_sub<P>(h_mul<P>(y2, a.zzz), a.y);
+  if (h_is_zero<P>(p)) {
+    if (!h_is_zero<P>(r)) {
+      a = hx_inf<P>();
+      return;
+    }
+    HXYZZ<P> q;
+    q.x = x2;
+    q.y = y2;
+    q.zz = q.zzz = h_one<P>();
+    a = hx_dbl<P>(q);
+    return;
+  }
+  HFe<P> pp = h_sqr<P>(p), ppp = h_mul<P>(p, pp), q = h_mul<P>(a.x, pp);
+  HFe<P> x3 = h_sub<P>(h_sub<P>(h_sub<P>(h_sqr<P>(r), ppp), q), q);
+  a.y = h_sub<P>(h_mul<P>(r, h_sub<P>(q, x3)), h_mul<P>(a.y, ppp));
+  a.x = x3;
+  a.zz = h_mul<P>(a.zz, pp);
+  a.zzz = h_mul<P>(a.zzz, ppp);
+}
 // affine (Montgomery x|y) -> XYZZ; (0,0) or is_inf -> infinity
 template <class P>
 inline HXYZZ<P> hx_from_affine(const u64* xy, bool is_inf) {

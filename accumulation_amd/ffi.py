@@ -1,8 +1,8 @@
 """ctypes binding of the C ABI in include/amsm.h (libamsm.so, built in-tree by build.py).
 
-There is no CPU fallback: importing works without a GPU (so the symbol table can be checked on a
-build box) but every compute entry point returns AMSM_E_NO_DEVICE there, and `load()` raises if the
-shared library itself is missing.
+Nothing falls back implicitly: importing works without a GPU, a GPU context cannot be created there
+(AMSM_E_NO_DEVICE), and `load()` raises if the shared library itself is missing.  The library's host
+backend is a device of its own (AMSM_DEVICE_HOST) that a caller has to ask for.
 """
 from __future__ import annotations
 
@@ -26,6 +26,8 @@ AMSM_E_NO_DEVICE = -5
 AMSM_E_SCALAR_RANGE = -6
 AMSM_E_RCCL = -7
 
+AMSM_DEVICE_HOST = -1
+
 AMSM_BASES_DEFAULT = 0
 AMSM_BASES_PRECOMPUTE = 1
 AMSM_BASES_NO_PRECOMPUTE = 2
@@ -40,6 +42,7 @@ SIGNATURES = {
     "amsm_strerror": (C.c_char_p, [C.c_int]),
     "amsm_device_count": (C.c_int, []),
     "amsm_ctx_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),
+    "amsm_ctx_is_host": (C.c_int, [_vp]),
     "amsm_ctx_create_multi": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), C.c_int]),
     "amsm_ctx_num_devices": (C.c_int, [_vp]),
     "amsm_ctx_shard": (_vp, [_vp, C.c_int]),

@@ -91,7 +91,7 @@ def main() -> int:
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        raise SystemExit("bench.py needs a GPU: it times the HIP path (the library's host backend is never chosen implicitly)")
     if args.one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -24,8 +24,10 @@
  * amsm_*_serialize / _deserialize, amsm_poseidon_* on distinct sponges) may be called from any thread concurrently, and from a
  * fork()ed child of a process that used them.
  * Errors: 0 = OK, negative = AMSM_E_*; nothing throws across the boundary.
- * There is NO CPU fallback: every entry point that computes on the device fails with AMSM_E_NO_DEVICE when no gfx950 GPU is
- * usable (the host helpers above need none).
+ * Nothing falls back to the CPU implicitly: with no usable gfx950 GPU amsm_ctx_create(.., device_id >= 0, ..) fails with
+ * AMSM_E_NO_DEVICE.  A caller that WANTS the host backend asks for it (device_id = AMSM_DEVICE_HOST, or amsm_ctx_create_multi with
+ * n_dev = 0: SURVEY.md section 8(b), BASELINE.json config 1 "plumbing, no GPU"): every entry point below then computes on the host
+ * cores -- same arguments, same results; "device" pointers are host memory from amsm_dev_alloc; keys are plain (flags are hints).
  *
  * Multi-GPU: ONE process drives the GPUs of a node through a multi-device context (amsm_ctx_create_multi, below): the
  * committer key is sharded over the devices by contiguous index ranges, every MSM entry point that takes a key accepts a
@@ -74,12 +76,17 @@ enum amsm_bases_flags {
 const char* amsm_strerror(int status);
 /* Number of usable gfx950 devices (0 when there is none); never initialises a context. */
 int amsm_device_count(void);
+/* device_id of the host backend (accumulation_amd/csrc/api_cpu.inc: window-parallel Pippenger + plain loops on the library's own
+ * host field arithmetic; what ark-ec's CPU MSM is to the reference).  Explicit only. */
+#define AMSM_DEVICE_HOST (-1)
 
 /* ---- context -------------------------------------------------------------------------------- */
 /* One context = one GPU + one HIP stream + a grow-only workspace.
  * `stream` is a hipStream_t owned by the caller (e.g. torch.cuda.current_stream().cuda_stream) or
  * NULL to let the context create its own non-blocking stream. */
 int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream);
+/* 1 for a context of the host backend (device_id == AMSM_DEVICE_HOST / n_dev == 0), else 0. */
+int amsm_ctx_is_host(const amsm_ctx* ctx);
 /* Multi-device context (reference: `prove` is ONE synchronous call in ONE process,
  * src/lib.rs:163-249): n_dev >= 1 devices driven by the calling process.  Device device_ids[0] is the PRIMARY: scalar
  * vectors handed to the `_device` entry points, the scalar-field vector kernels and every result live there.  Keys created
@@ -91,7 +98,8 @@ int amsm_ctx_create(amsm_ctx** out, int curve, int device_id, void* stream);
  * unavailable, AMSM_COLLECTIVE=peer, or a device is listed twice) and fold + normalise once.  Results are bit-identical to
  * the single-device ones.  Entry points that do not shard (grouped / multi-offset MSMs, key folds, the IPA round,
  * amsm_bases_device_ptr) return AMSM_E_UNSUPPORTED / NULL for a sharded key.
- * A device id may appear more than once (two shards on one GPU: how a 1-GPU box exercises this path). */
+ * A device id may appear more than once (two shards on one GPU: how a 1-GPU box exercises this path).
+ * n_dev == 0 (device_ids ignored): a context of the host backend, as amsm_ctx_create(.., AMSM_DEVICE_HOST, NULL). */
 int amsm_ctx_create_multi(amsm_ctx** out, int curve, const int* device_ids, int n_dev);
 /* 1 for amsm_ctx_create contexts. */
 int amsm_ctx_num_devices(const amsm_ctx* ctx);

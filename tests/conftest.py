@@ -21,12 +21,12 @@ def _have_gpu() -> bool:
 
 
 def pytest_collection_modifyitems(config, items):
-    """`-m gpu` on a box without a GPU must fail loudly, not pass vacuously or skip: the HIP path has no fallback."""
+    """`-m gpu` on a box without a GPU must fail loudly, not pass vacuously or skip: the HIP path never degrades to the host backend."""
     expr = (config.getoption("-m") or "").strip()
     wants_gpu = "gpu" in expr and "not gpu" not in expr
     if wants_gpu and any(i.get_closest_marker("gpu") for i in items) and not _have_gpu():
         raise pytest.UsageError("-m gpu selected but libamsm.so sees no gfx950 GPU (amsm_device_count() == 0): "
-                                "the GPU tests cannot run here and there is no CPU fallback to run instead")
+                                "the GPU tests cannot run here (the host backend has its own tests: -m 'not gpu')")
 
 
 @pytest.fixture(scope="session")

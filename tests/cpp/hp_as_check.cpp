@@ -6,6 +6,8 @@
 #include "amsm_hp_as.hpp"
 #include "amsm_poseidon.hpp"
 
+#include "check_device.hpp"
+
 // -DAMSM_TEST_POSEIDON: the same template runs with the reference's sponge (ark-sponge Poseidon, include/amsm_poseidon.hpp)
 // as the Sponge argument instead of the SHA-256 stand-in
 #ifdef AMSM_TEST_POSEIDON
@@ -100,7 +102,7 @@ static Accumulator run_template(Context& ctx, const CommitterKey& ck, const std:
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, 0);
+    Context ctx(AMSM_PALLAS, check_device());
     CommitterKey ck = PedersenCommitment::setup(ctx, VECTOR_LEN, 4242);
     struct Scenario {
       const char* name;

@@ -7,6 +7,8 @@
 #include "amsm_ipa_pc_as.hpp"
 #include "amsm_poseidon.hpp"
 
+#include "check_device.hpp"
+
 // -DAMSM_TEST_POSEIDON: the same template runs with the reference's sponge (ark-sponge Poseidon, include/amsm_poseidon.hpp)
 // as the Sponge argument instead of the SHA-256 stand-in
 #ifdef AMSM_TEST_POSEIDON
@@ -96,7 +98,7 @@ static void print_fr(const char* name, const Fr& canonical) {
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, 0);
+    Context ctx(AMSM_PALLAS, check_device());
     ipa_pc::FrX fr(AMSM_PALLAS);
     ipa_pc::CommitterKey pp = Ipa::setup(ctx, DEGREE, 0xABCDEF);
     // the polynomial commitment alone: open / check round trip and its two rejections (tests/test_ipa_gpu.py)

@@ -7,6 +7,8 @@
 #include "amsm_r1cs_nark_as.hpp"
 #include "amsm_poseidon.hpp"
 
+#include "check_device.hpp"
+
 // -DAMSM_TEST_POSEIDON: the same template runs with the reference's sponge (ark-sponge Poseidon, include/amsm_poseidon.hpp)
 // as the Sponge argument instead of the SHA-256 stand-in
 #ifdef AMSM_TEST_POSEIDON
@@ -96,7 +98,7 @@ static void print_point(const char* name, const Affine& p) {
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, 0);
+    Context ctx(AMSM_PALLAS, check_device());
     const size_t n_inst = NUM_INPUTS + 1;
     const Fr one = {1, 0, 0, 0};
     std::vector<r1cs_nark::Matrix::Row> A, B, C;

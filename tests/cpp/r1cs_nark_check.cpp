@@ -6,6 +6,8 @@
 #include "amsm_r1cs_nark.hpp"
 #include "amsm_poseidon.hpp"
 
+#include "check_device.hpp"
+
 // -DAMSM_TEST_POSEIDON: the same template runs with the reference's sponge (ark-sponge Poseidon, include/amsm_poseidon.hpp)
 // as the Sponge argument instead of the SHA-256 stand-in
 #ifdef AMSM_TEST_POSEIDON
@@ -49,7 +51,7 @@ static void print_fr(const char* name, const Fr& x) {
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, 0);
+    Context ctx(AMSM_PALLAS, check_device());
     hp_as::FrOps fr{AMSM_PALLAS};
     const size_t num_inputs = 5, num_constraints = 100, n_inst = num_inputs + 1;
     const Fr one = {1, 0, 0, 0};

@@ -6,6 +6,8 @@
 #include "amsm_trivial_pc_as.hpp"
 #include "amsm_poseidon.hpp"
 
+#include "check_device.hpp"
+
 // -DAMSM_TEST_POSEIDON: the same template runs with the reference's sponge (ark-sponge Poseidon, include/amsm_poseidon.hpp)
 // as the Sponge argument instead of the SHA-256 stand-in
 #ifdef AMSM_TEST_POSEIDON
@@ -86,7 +88,7 @@ static void print_words(const char* name, const uint64_t* w, size_t n, int flag)
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, 0);
+    Context ctx(AMSM_PALLAS, check_device());
     CommitterKey pp = TrivialPC::setup(ctx, DEGREE, 0x7121A1);
     struct Scenario {
       const char* name;

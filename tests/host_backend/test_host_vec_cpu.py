@@ -1,0 +1,2 @@
+"""test_vec_gpu.py on the host backend (conftest.py of this directory; test_host_context_cpu.py says why)."""
+from tests.test_vec_gpu import *  # noqa: F401,F403

@@ -1,5 +1,6 @@
-"""CPU tests: the C-ABI library builds, loads and exports every symbol include/amsm.h declares; with no
-GPU every compute entry point fails loudly (AMSM_E_NO_DEVICE) -- there is no CPU fallback."""
+"""CPU tests: the C-ABI library builds, loads and exports every symbol include/amsm.h declares; with no GPU a GPU context
+cannot be created (AMSM_E_NO_DEVICE, nothing falls back implicitly), while a context of the host backend (AMSM_DEVICE_HOST,
+explicit) computes the same results through the same entry points."""
 import ctypes as C
 import os
 import re
@@ -39,7 +40,7 @@ def test_header_cites_reference_interfaces():
 
 def test_strerror_and_stage_names(built_lib):
     assert built_lib.amsm_strerror(0) == b"ok"
-    assert b"no CPU fallback" in built_lib.amsm_strerror(ffi.AMSM_E_NO_DEVICE)
+    assert b"never chosen implicitly" in built_lib.amsm_strerror(ffi.AMSM_E_NO_DEVICE)
     n = built_lib.amsm_stage_count()
     names = [built_lib.amsm_stage_name(i).decode() for i in range(n)]
     assert "accum_l0" in names and "prep_chain" in names
@@ -56,6 +57,34 @@ def test_no_gpu_fails_loudly(built_lib, have_gpu):
     with pytest.raises(ffi.AmsmError) as e:
         Context(ffi.AMSM_PALLAS)
     assert e.value.status == ffi.AMSM_E_NO_DEVICE
+
+
+def test_host_backend_computes_results_where_there_is_no_gpu(built_lib, cref):
+    """SURVEY.md section 8(b) / BASELINE.json config 1: with n_dev == 0 the SAME entry points return results, not an error --
+    an MSM and a hiding Pedersen commitment through the raw C ABI against the C restatement."""
+    import numpy as np
+    h = C.c_void_p()
+    assert built_lib.amsm_ctx_create_multi(C.byref(h), ffi.AMSM_PALLAS, None, 0) == ffi.AMSM_OK and h.value
+    assert built_lib.amsm_ctx_is_host(h) == 1
+    n = 777
+    ck = C.c_void_p()
+    assert built_lib.amsm_bases_generate(h, 0x5EED1001, n + 1, ffi.AMSM_BASES_DEFAULT, C.byref(ck)) == ffi.AMSM_OK
+    xy = np.zeros((n + 1, 8), dtype=np.uint64)
+    assert built_lib.amsm_bases_read(h, ck, 0, n + 1, xy.ctypes.data_as(C.c_void_p), None) == ffi.AMSM_OK
+    assert np.array_equal(xy, cref.rng_points(ffi.AMSM_PALLAS, 0x5EED1001, n + 1))
+    sc = cref.rng_scalars(99, n)
+    out, inf = np.zeros(8, dtype=np.uint64), C.c_uint8(9)
+    assert built_lib.amsm_msm(h, ck, 0, sc.ctypes.data_as(C.c_void_p), n, 0, out.ctypes.data_as(C.c_void_p), C.byref(inf)) == ffi.AMSM_OK
+    ref, ref_inf = cref.msm(ffi.AMSM_PALLAS, xy[:n], sc)
+    assert inf.value == ref_inf and np.array_equal(out, ref)
+    elems, r = cref.fr_to_mont(ffi.AMSM_PALLAS, sc), cref.fr_to_mont(ffi.AMSM_PALLAS, cref.rng_scalars(5, 1))
+    hid = np.ascontiguousarray(xy[n])
+    assert built_lib.amsm_pedersen_commit(h, ck, elems.ctypes.data_as(C.c_void_p), n, r.ctypes.data_as(C.c_void_p),
+                                          hid.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(inf)) == ffi.AMSM_OK
+    both, both_inf = cref.msm(ffi.AMSM_PALLAS, xy, np.concatenate([sc, cref.rng_scalars(5, 1)]))
+    assert inf.value == both_inf and np.array_equal(out, both)
+    built_lib.amsm_bases_free(ck)
+    built_lib.amsm_ctx_destroy(h)
 
 
 def test_invalid_arguments_rejected(built_lib):

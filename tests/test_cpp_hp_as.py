@@ -25,13 +25,13 @@ def test_cpp_hp_as_compiles(built_lib):
     assert os.path.exists(EXE)
 
 
-@pytest.mark.gpu
-def test_cpp_hp_as_template_and_python_cross_check(built_lib):
+def _template_and_cross_check(device):
+    """device 0: the HIP path; -1: the library's host backend (AMSM_DEVICE_HOST) -- same program, same mirror, same bytes"""
     from accumulation_amd import Context, PedersenCommitment, ffi
     from accumulation_amd.hp_as import ASForHadamardProducts as AS
     from tests.test_hp_as_scheme_gpu import VECTOR_LEN, SchemeRng, generate_inputs
     build()
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([EXE], capture_output=True, text=True, env=dict(os.environ, AMSM_CHECK_DEVICE=str(device)), timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln.split() for ln in out.stdout.splitlines()]
     assert ["done"] in lines and ["missing_rng", "raised"] in lines
@@ -41,7 +41,7 @@ def test_cpp_hp_as_template_and_python_cross_check(built_lib):
     assert ok == {(n, z) for n in names for z in ("zk", "no_zk")}
     vals = {ln[0]: ln[1:] for ln in lines if ln[0].startswith(("zk_", "nozk_"))}
     # the same run on the Python mirror: one iteration of [1, 1, 2, 3]
-    ctx = Context(ffi.AMSM_PALLAS)
+    ctx = Context(ffi.AMSM_PALLAS, device=device)
     ck = PedersenCommitment.setup(ctx, VECTOR_LEN, seed=4242)
     pk, vk, dk = AS.index(ck)
     for make_zk, tag in ((False, "nozk"), (True, "zk")):
@@ -57,3 +57,18 @@ def test_cpp_hp_as_template_and_python_cross_check(built_lib):
             assert int(got[0]) == int(bool(pt[1]))
             assert [int(x, 16) for x in got[1:]] == [int(v) for v in np.asarray(pt[0]).reshape(-1)], (tag, j)
     ctx.close()
+    return out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_hp_as_template_and_python_cross_check(built_lib):
+    gpu = _template_and_cross_check(0)
+    # ... and the host backend behind the same ABI prints the same accumulators, byte for byte
+    host = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMSM_CHECK_DEVICE="-1"))
+    assert host.returncode == 0, host.stdout + host.stderr
+    assert host.stdout == gpu
+
+
+def test_cpp_hp_as_template_and_python_cross_check_on_the_host_backend(built_lib):
+    """no GPU needed (-m "not gpu"): BASELINE.json config 1 'plumbing, no GPU', SURVEY.md section 8(b)"""
+    _template_and_cross_check(-1)

@@ -25,8 +25,8 @@ def test_cpp_ipa_pc_as_compiles(built_lib):
     assert os.path.exists(EXE)
 
 
-@pytest.mark.gpu
-def test_cpp_ipa_pc_as_template_and_python_cross_check(built_lib):
+def _template_and_cross_check(device):
+    """device 0: the HIP path; -1: the library's host backend (AMSM_DEVICE_HOST) -- same program, same mirror, same bytes"""
     from accumulation_amd import Context, ffi
     from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
     from accumulation_amd.ipa_pc_as import AtomicASForInnerProductArgPC as AS
@@ -34,7 +34,7 @@ def test_cpp_ipa_pc_as_template_and_python_cross_check(built_lib):
     from tests.test_hp_as_scheme_gpu import SchemeRng
     from tests.test_ipa_gpu import DEGREE, generate_inputs
     build()
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([EXE], capture_output=True, text=True, env=dict(os.environ, AMSM_CHECK_DEVICE=str(device)), timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln.split() for ln in out.stdout.splitlines()]
     assert ["done"] in lines
@@ -46,7 +46,7 @@ def test_cpp_ipa_pc_as_template_and_python_cross_check(built_lib):
              "accumulators_only", "no_inputs_init"]
     assert ok == {(n, z) for n in names for z in ("zk", "no_zk")}
     vals = {ln[0]: ln[1:] for ln in lines if ln[0].startswith(("zk_", "nozk_"))}
-    ctx = Context(ffi.AMSM_PALLAS)
+    ctx = Context(ffi.AMSM_PALLAS, device=device)
     r = MODULI[ctx.curve]
     assert DEGREE == 11
     pp = IpaPC.setup(ctx, DEGREE, seed=0xABCDEF)
@@ -78,3 +78,18 @@ def test_cpp_ipa_pc_as_template_and_python_cross_check(built_lib):
         same_scalar(f"{tag}_evaluation", i.evaluation)
         same_scalar(f"{tag}_c", i.ipa_proof.c)
     ctx.close()
+    return out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_ipa_pc_as_template_and_python_cross_check(built_lib):
+    gpu = _template_and_cross_check(0)
+    # ... and the host backend behind the same ABI prints the same accumulators, byte for byte
+    host = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMSM_CHECK_DEVICE="-1"))
+    assert host.returncode == 0, host.stdout + host.stderr
+    assert host.stdout == gpu
+
+
+def test_cpp_ipa_pc_as_template_and_python_cross_check_on_the_host_backend(built_lib):
+    """no GPU needed (-m "not gpu"): BASELINE.json config 1 'plumbing, no GPU', SURVEY.md section 8(b)"""
+    _template_and_cross_check(-1)

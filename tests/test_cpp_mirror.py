@@ -28,10 +28,9 @@ def test_cpp_mirror_compiles(built_lib):
     assert os.path.exists(EXE)
 
 
-@pytest.mark.gpu
-def test_cpp_mirror_matches_oracle(built_lib, cref):
+def _mirror_matches_oracle(cref, device):
     build()
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300, env=dict(os.environ, AMSM_CHECK_DEVICE=str(device)))
     assert out.returncode == 0, out.stdout + out.stderr
     vals = {}
     for line in out.stdout.splitlines():
@@ -77,3 +76,13 @@ def test_cpp_mirror_matches_oracle(built_lib, cref):
     assert pt("hostcommit_a") == Pa and pt("hostcommit_b777") == Pb777 and pt("commit_b777") == Pb777
     assert pt("hostcommit_a_hiding_3") == o.add(c, Pa, o.mul(c, 3, H))
     assert vals["error_check"] == ["-1"]
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_matches_oracle(built_lib, cref):
+    _mirror_matches_oracle(cref, 0)
+
+
+def test_cpp_mirror_matches_oracle_on_the_host_backend(built_lib, cref):
+    """the same program with its Context on AMSM_DEVICE_HOST: no GPU needed"""
+    _mirror_matches_oracle(cref, -1)

@@ -25,7 +25,7 @@ def test_multi_device_check_compiles(built_lib):
 
 
 def test_multi_context_without_gpu_fails_loudly(built_lib):
-    """no CPU fallback: creation reports AMSM_E_NO_DEVICE on a box without a GPU"""
+    """nothing falls back implicitly: creation over device ids reports AMSM_E_NO_DEVICE on a box without a GPU"""
     import ctypes as C
     from accumulation_amd import ffi
     lib = built_lib

@@ -26,10 +26,8 @@ def test_poseidon_variant_compiles(built_lib, name):
     assert os.path.exists(build(name))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", SCHEMES)
-def test_six_scenarios_with_poseidon(built_lib, name):
-    out = subprocess.run([build(name)], capture_output=True, text=True, timeout=900)
+def _six_scenarios(name, device):
+    out = subprocess.run([build(name)], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMSM_CHECK_DEVICE=str(device)))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     lines = out.stdout.splitlines()
     assert "done" in lines[-1] and not any(ln.startswith("exception") for ln in lines)
@@ -37,3 +35,17 @@ def test_six_scenarios_with_poseidon(built_lib, name):
     if name != "r1cs_nark":  # the NARK alone is not an accumulation scheme: its check has prove / verify lines instead
         expected = 6 if name == "trivial_pc_as" else 12  # six scenarios (x zk / no-zk where the scheme has a zk mode)
         assert len(ok) == expected, out.stdout[-3000:]
+    return out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCHEMES)
+def test_six_scenarios_with_poseidon(built_lib, name):
+    gpu = _six_scenarios(name, 0)
+    assert _six_scenarios(name, -1) == gpu  # the host backend behind the same ABI: the same lines, accumulators included
+
+
+@pytest.mark.parametrize("name", SCHEMES)
+def test_six_scenarios_with_poseidon_on_the_host_backend(built_lib, name):
+    """-m "not gpu": all five drivers with the reference's sponge on AMSM_DEVICE_HOST"""
+    _six_scenarios(name, -1)

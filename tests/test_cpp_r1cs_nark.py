@@ -25,8 +25,8 @@ def test_cpp_r1cs_nark_compiles(built_lib):
     assert os.path.exists(EXE)
 
 
-@pytest.mark.gpu
-def test_cpp_r1cs_nark_simple_circuit_and_python_cross_check(built_lib):
+def _template_and_cross_check(device):
+    """device 0: the HIP path; -1: the library's host backend (AMSM_DEVICE_HOST) -- same program, same mirror, same bytes"""
     from accumulation_amd import Context, ffi
     from accumulation_amd import r1cs_nark as nark
     from accumulation_amd.scalar_field import Fr
@@ -36,13 +36,13 @@ def test_cpp_r1cs_nark_simple_circuit_and_python_cross_check(built_lib):
     from tests.test_hp_as_scheme_gpu import SchemeRng
     from tests.test_r1cs_nark_gpu import dummy_circuit
     build()
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([EXE], capture_output=True, text=True, env=dict(os.environ, AMSM_CHECK_DEVICE=str(device)), timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln.split() for ln in out.stdout.splitlines()]
     assert ["done"] in lines and ["mode", "nozk", "ok"] in lines and ["mode", "zk", "ok"] in lines
     vals = {ln[0]: ln[1:] for ln in lines}
     c = o.PALLAS
-    ctx = Context(ffi.AMSM_PALLAS)
+    ctx = Context(ffi.AMSM_PALLAS, device=device)
     fr = Fr(ctx.curve)
     A, B, C_, _, _ = dummy_circuit(5, 100, 2, 3, c.r)
     ipk = nark.index(ctx, A, B, C_, 6, 8, key_seed=7)
@@ -71,3 +71,18 @@ def test_cpp_r1cs_nark_simple_circuit_and_python_cross_check(built_lib):
             assert [int(x, 16) for x in vals["zk_sigma_a"][1:]] == [int(v) for v in fr.to_limbs(s.sigma_a)]
             assert [int(x, 16) for x in vals["zk_sigma_o"][1:]] == [int(v) for v in fr.to_limbs(s.sigma_o)]
     ctx.close()
+    return out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_r1cs_nark_simple_circuit_and_python_cross_check(built_lib):
+    gpu = _template_and_cross_check(0)
+    # ... and the host backend behind the same ABI prints the same accumulators, byte for byte
+    host = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMSM_CHECK_DEVICE="-1"))
+    assert host.returncode == 0, host.stdout + host.stderr
+    assert host.stdout == gpu
+
+
+def test_cpp_r1cs_nark_simple_circuit_and_python_cross_check_on_the_host_backend(built_lib):
+    """no GPU needed (-m "not gpu"): BASELINE.json config 1 'plumbing, no GPU', SURVEY.md section 8(b)"""
+    _template_and_cross_check(-1)

@@ -24,8 +24,8 @@ def test_cpp_r1cs_nark_as_compiles(built_lib):
     assert os.path.exists(EXE)
 
 
-@pytest.mark.gpu
-def test_cpp_r1cs_nark_as_template_and_python_cross_check(built_lib):
+def _template_and_cross_check(device):
+    """device 0: the HIP path; -1: the library's host backend (AMSM_DEVICE_HOST) -- same program, same mirror, same bytes"""
     from accumulation_amd import Context, ffi
     from accumulation_amd import r1cs_nark as nark
     from accumulation_amd.r1cs_nark_as import ASForR1CSNark as AS
@@ -34,7 +34,7 @@ def test_cpp_r1cs_nark_as_template_and_python_cross_check(built_lib):
     from tests.test_r1cs_nark_as_scheme_gpu import NUM_CONSTRAINTS, NUM_INPUTS, generate_inputs
     from tests.test_r1cs_nark_gpu import dummy_circuit
     build()
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([EXE], capture_output=True, text=True, env=dict(os.environ, AMSM_CHECK_DEVICE=str(device)), timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln.split() for ln in out.stdout.splitlines()]
     assert ["done"] in lines
@@ -43,7 +43,7 @@ def test_cpp_r1cs_nark_as_template_and_python_cross_check(built_lib):
              "accumulators_only", "no_inputs_init"]
     assert ok == {(n, z) for n in names for z in ("zk", "no_zk")}
     vals = {ln[0]: ln[1:] for ln in lines if ln[0].startswith(("zk_", "nozk_"))}
-    ctx = Context(ffi.AMSM_PALLAS)
+    ctx = Context(ffi.AMSM_PALLAS, device=device)
     r = MODULI[ctx.curve]
     A, B, C_, _, _ = dummy_circuit(NUM_INPUTS, NUM_CONSTRAINTS, 2, 3, r)
     ipk = nark.index(ctx, A, B, C_, NUM_INPUTS + 1, NUM_INPUTS + 3, key_seed=31337)
@@ -72,3 +72,18 @@ def test_cpp_r1cs_nark_as_template_and_python_cross_check(built_lib):
         got_inputs = [sum(words[4 * j + t] << (64 * t) for t in range(4)) for j in range(len(words) // 4)]
         assert got_inputs == [x % r for x in i.r1cs_input], tag
     ctx.close()
+    return out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_r1cs_nark_as_template_and_python_cross_check(built_lib):
+    gpu = _template_and_cross_check(0)
+    # ... and the host backend behind the same ABI prints the same accumulators, byte for byte
+    host = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMSM_CHECK_DEVICE="-1"))
+    assert host.returncode == 0, host.stdout + host.stderr
+    assert host.stdout == gpu
+
+
+def test_cpp_r1cs_nark_as_template_and_python_cross_check_on_the_host_backend(built_lib):
+    """no GPU needed (-m "not gpu"): BASELINE.json config 1 'plumbing, no GPU', SURVEY.md section 8(b)"""
+    _template_and_cross_check(-1)

@@ -24,15 +24,15 @@ def test_cpp_trivial_pc_as_compiles(built_lib):
     assert os.path.exists(EXE)
 
 
-@pytest.mark.gpu
-def test_cpp_trivial_pc_as_template_and_python_cross_check(built_lib):
+def _template_and_cross_check(device):
+    """device 0: the HIP path; -1: the library's host backend (AMSM_DEVICE_HOST) -- same program, same mirror, same bytes"""
     from accumulation_amd import Context, ffi
     from accumulation_amd.scalar_field import Fr
     from accumulation_amd.trivial_pc_as import ASForTrivialPC as AS, TrivialPC
     from tests.test_hp_as_scheme_gpu import SchemeRng
     from tests.test_trivial_pc_as_scheme_gpu import DEGREE, generate_inputs
     build()
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([EXE], capture_output=True, text=True, env=dict(os.environ, AMSM_CHECK_DEVICE=str(device)), timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln.split() for ln in out.stdout.splitlines()]
     assert ["done"] in lines and ["tampered_decide", "0"] in lines
@@ -40,7 +40,7 @@ def test_cpp_trivial_pc_as_template_and_python_cross_check(built_lib):
     assert ok == {"single_input_init", "multiple_inputs_init", "simple_accumulation", "multiple_inputs_accumulation",
                   "accumulators_only", "no_inputs_init"}
     vals = {ln[0]: ln[1:] for ln in lines if ln[0].startswith("acc_")}
-    ctx = Context(ffi.AMSM_PALLAS)
+    ctx = Context(ffi.AMSM_PALLAS, device=device)
     fr = Fr(ctx.curve)
     pp = TrivialPC.setup(ctx, DEGREE, seed=0x7121A1)
     ck, _ = TrivialPC.trim(pp, DEGREE)
@@ -57,3 +57,18 @@ def test_cpp_trivial_pc_as_template_and_python_cross_check(built_lib):
     assert [int(x, 16) for x in vals["acc_point"][1:]] == [int(v) for v in fr.to_limbs(acc.instance.point)]
     assert [int(x, 16) for x in vals["acc_eval"][1:]] == [int(v) for v in fr.to_limbs(acc.instance.eval)]
     ctx.close()
+    return out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_trivial_pc_as_template_and_python_cross_check(built_lib):
+    gpu = _template_and_cross_check(0)
+    # ... and the host backend behind the same ABI prints the same accumulators, byte for byte
+    host = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMSM_CHECK_DEVICE="-1"))
+    assert host.returncode == 0, host.stdout + host.stderr
+    assert host.stdout == gpu
+
+
+def test_cpp_trivial_pc_as_template_and_python_cross_check_on_the_host_backend(built_lib):
+    """no GPU needed (-m "not gpu"): BASELINE.json config 1 'plumbing, no GPU', SURVEY.md section 8(b)"""
+    _template_and_cross_check(-1)

@@ -201,7 +201,7 @@ def bench_vec(log2n):
 def bench_trivial_pc_as(log2d, reps=5):
     """cfg0 (examples/scaling-as.rs:62-63,91-104): trivial_pc_as at degree 2^log2d - 1, one input accumulated into two old
     accumulators: 3 MSMs of <= 2^log2d points in prove (witness polynomials), one in decide.  The reference runs it on the
-    CPU; here it goes through the same GPU path (no CPU fallback exists) -- far too small to fill the device."""
+    CPU; here it goes through the same GPU path (bench.py reports the host backend's line beside it) -- far too small to fill the device."""
     from accumulation_amd.trivial_pc_as import ASForTrivialPC as TAS, Input as TInput, InputInstance as TInst, LabeledPolynomial, TrivialPC
     ctx = Context(ffi.AMSM_PALLAS)
     fr = Fr(ctx.curve)
