@@ -9,6 +9,13 @@
 //
 //   profile_as <scheme: trivial_pc_as | ipa_pc_as | hp_as | r1cs_nark_as | all> <log_min> <log_max>
 //              [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] [--curve 0|1] [--constant] [--no-roundtrip]
+//              [--device D] [--seed S] [--dump FILE]
+//   --device -1  runs on the library's host backend (amsm.h AMSM_DEVICE_HOST: BASELINE.json config 1 "plumbing, no GPU").
+//   --seed S     varies the harness's random stream and the synthetic vectors (0: the bench's inputs).
+//   --dump FILE  ONE (scheme, size, shape): exactly one prove after the first accumulation, then FILE receives the serialised new
+//                accumulator and proof (ark-serialize layout, include/amsm_serialize.hpp; two records of u64 LE length + bytes) --
+//                tests/test_profile_as_dump.py rebuilds the same accumulation on the Python mirrors (the oracle-checked ones)
+//                and compares the bytes, at the sizes of BASELINE.json's configs on the GPU box.
 //
 // Prints the reference's lines ("Indexer:", "Prover:", ...) and one JSON object per (scheme, size, shape) on lines starting
 // with "JSON ".  Times are wall-clock milliseconds of the blocking calls (median of R proves after the warm-up accumulation).
@@ -30,7 +37,26 @@ struct Opt {
   std::string scheme = "all", shape = "both", sponge = "sha256";
   int log_min = 10, log_max = 10, reps = 3, curve = AMSM_PALLAS;
   bool constant = false, roundtrip = true;
+  int device = 0;
+  uint64_t seed = 0;
+  std::string dump;
 };
+
+static void dump_records(const Opt& o, const std::vector<uint8_t>& acc, const std::vector<uint8_t>& proof) {
+  if (o.dump.empty()) return;
+  FILE* f = fopen(o.dump.c_str(), "wb");
+  if (!f) throw Error(AMSM_E_INVALID_ARG, "--dump: cannot open the file");
+  for (const std::vector<uint8_t>* r : {&acc, &proof}) {
+    uint64_t n = r->size();
+    fwrite(&n, 8, 1, f);
+    if (n) fwrite(r->data(), 1, n, f);
+  }
+  fclose(f);
+}
+// the timed proves: R of them after one more warm-up -- or, with --dump, exactly one (so that the rng stream a mirror has to
+// replay is: first accumulation, one prove)
+template <class F>
+static double timed_proves(const Opt& o, F&& prove_once);
 
 struct HarnessRng {  // ark_std::test_rng() stand-in: a fixed stream
   uint64_t seed, i = 0;
@@ -82,15 +108,21 @@ static double median_ms(int reps, F&& f) {
   std::sort(t.begin(), t.end());
   return t[t.size() / 2];
 }
+template <class F>
+static double timed_proves(const Opt& o, F&& prove_once) {
+  if (!o.dump.empty()) return median_ms(1, prove_once);
+  prove_once();
+  return median_ms(o.reps, prove_once);
+}
 
 // ---- hp_as (src/hp_as/mod.rs; inputs like :980-1044 at vector length 2^k) ---------------------------------------------------
 template <class Sponge>
 static void profile_hp(const Opt& o, int lg, bool harness_shape) {
   using AS = hp_as::ASForHadamardProducts<Sponge>;
-  Context ctx(o.curve, 0);
+  Context ctx(o.curve, o.device);
   hp_as::FrOps fr{o.curve};
   const size_t n = (size_t)1 << lg;
-  HarnessRng hr(0xA11CE);
+  HarnessRng hr(0xA11CE ^ o.seed);
   hp_as::Rng zk_rng = harness_shape ? hp_as::Rng([&hr]() { return hr.field(); }) : hp_as::Rng();
   Result r;
   auto t0 = Clock::now();
@@ -114,12 +146,12 @@ static void profile_hp(const Opt& o, int lg, bool harness_shape) {
     Affine c3 = PedersenCommitment::commit(ck, prod, rnd ? &rnd->rand_3 : nullptr);
     return hp_as::Accumulator{hp_as::InputInstance{c1, c2, c3}, hp_as::InputWitness{a, b, rnd}};
   };
-  std::vector<hp_as::Accumulator> inputs{make_input(100)};
+  std::vector<hp_as::Accumulator> inputs{make_input(100 + o.seed)};
   auto first = AS::prove(*keys.prover_key, inputs, {}, zk_rng);
   std::vector<hp_as::Accumulator> old{first.first};
   if (harness_shape) old.push_back(first.first);
-  std::pair<hp_as::Accumulator, hp_as::Proof> res = AS::prove(*keys.prover_key, inputs, old, zk_rng);
-  r.prove_ms = median_ms(o.reps, [&] { res = AS::prove(*keys.prover_key, inputs, old, zk_rng); });
+  std::pair<hp_as::Accumulator, hp_as::Proof> res;
+  r.prove_ms = timed_proves(o, [&] { res = AS::prove(*keys.prover_key, inputs, old, zk_rng); });
   std::vector<hp_as::InputInstance> ii{inputs[0].instance}, oi;
   for (auto& a : old) oi.push_back(a.instance);
   t0 = Clock::now();
@@ -140,6 +172,7 @@ static void profile_hp(const Opt& o, int lg, bool harness_shape) {
     auto pb = ser::serialize(ctx, res.second);
     r.roundtrip = r.roundtrip && ser::serialize(ctx, ser::deserialize<hp_as::Proof>(ctx, pb)) == pb;
   }
+  if (!o.dump.empty()) dump_records(o, ser::serialize(ctx, res.first), ser::serialize(ctx, res.second));
   printf("Vector length: %zu\n", n);
   report(o, "hp_as", lg, "log2_len", harness_shape ? "harness: 1 input + 2x the same accumulator" : "n2: 1 input + 1 accumulator",
          harness_shape, r);
@@ -150,11 +183,11 @@ template <class Sponge>
 static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
   using AS = r1cs_nark_as::ASForR1CSNark<Sponge>;
   using Nark = r1cs_nark::R1CSNark<Sponge>;
-  Context ctx(o.curve, 0);
+  Context ctx(o.curve, o.device);
   hp_as::FrOps fr{o.curve};
   const size_t n_con = (size_t)1 << lg, n_inputs = 5, n_inst = n_inputs + 1;
   const Fr one = {1, 0, 0, 0};
-  HarnessRng hr(0xB0B);
+  HarnessRng hr(0xB0B ^ o.seed);
   hp_as::Rng zk_rng = harness_shape ? hp_as::Rng([&hr]() { return hr.field(); }) : hp_as::Rng();
   Result r;
   auto t0 = Clock::now();
@@ -185,8 +218,8 @@ static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
   auto first = AS::prove(keys.pk, inputs, {}, zk_rng);
   std::vector<r1cs_nark_as::Accumulator> old{first.first};
   if (harness_shape) old.push_back(first.first);
-  auto res = AS::prove(keys.pk, inputs, old, zk_rng);
-  r.prove_ms = median_ms(o.reps, [&] { res = AS::prove(keys.pk, inputs, old, zk_rng); });
+  std::pair<r1cs_nark_as::Accumulator, r1cs_nark_as::Proof> res;
+  r.prove_ms = timed_proves(o, [&] { res = AS::prove(keys.pk, inputs, old, zk_rng); });
   std::vector<r1cs_nark_as::InputInstance> ii{inputs[0].instance};
   std::vector<r1cs_nark_as::AccumulatorInstance> oi;
   for (auto& a : old) oi.push_back(a.instance);
@@ -209,6 +242,7 @@ static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
     auto ib = ser::serialize(ctx, inputs[0]);
     r.roundtrip = r.roundtrip && ser::serialize(ctx, ser::deserialize<r1cs_nark_as::Input>(ctx, ib)) == ib;
   }
+  if (!o.dump.empty()) dump_records(o, ser::serialize(ctx, res.first), ser::serialize(ctx, res.second));
   printf("Constraints: %zu\n", n_con);
   report(o, "r1cs_nark_as", lg, "log2_constraints",
          harness_shape ? "harness: 1 input + 2x the same accumulator" : "n2: 1 input + 1 accumulator", harness_shape, r);
@@ -220,12 +254,12 @@ static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
 template <class Sponge>
 static void profile_nark(const Opt& o, int lg, bool make_zk) {
   using Nark = r1cs_nark::R1CSNark<Sponge>;
-  Context ctx(o.curve, 0);
+  Context ctx(o.curve, o.device);
   hp_as::FrOps fr{o.curve};
   const size_t n_con = (size_t)1 << lg, n_inputs = 5, n_inst = n_inputs + 1;
   const size_t n_wit = (n_con > 5 ? n_con - 5 : 1) + 1;  // a, b, then num_witness_variables - 1 copies of a
   const Fr one = {1, 0, 0, 0};
-  HarnessRng hr(0xB0B);
+  HarnessRng hr(0xB0B ^ o.seed);
   hp_as::Rng zk_rng = make_zk ? hp_as::Rng([&hr]() { return hr.field(); }) : hp_as::Rng();
   Result r;
   Fr a = hr.field(), b = hr.field();
@@ -271,10 +305,10 @@ template <class Sponge>
 static void profile_ipa(const Opt& o, int lg, bool harness_shape) {
   using AS = ipa_pc_as::AtomicASForInnerProductArgPC<Sponge>;
   using Ipa = ipa_pc::InnerProductArgPC<Sponge>;
-  Context ctx(o.curve, 0);
+  Context ctx(o.curve, o.device);
   ipa_pc::FrX fr(o.curve);
   const size_t degree = ((size_t)1 << lg) - 1;
-  HarnessRng hr(0xD1);
+  HarnessRng hr(0xD1 ^ o.seed);
   hp_as::Rng prng([&hr]() { return hr.field(); });
   hp_as::Rng zk_rng = harness_shape ? prng : hp_as::Rng();
   Result r;
@@ -283,7 +317,7 @@ static void profile_ipa(const Opt& o, int lg, bool harness_shape) {
   auto keys = AS::index(pp, degree);
   r.index_ms = ms_since(t0);
   // dl_input_gen: a random polynomial of the supported degree, committed (hiding when zk), opened at a random point
-  FrVector poly = FrVector::random(ctx, 77, degree + 1, true);
+  FrVector poly = FrVector::random(ctx, 77 + o.seed, degree + 1, true);
   auto cr = Ipa::commit(keys.pk.ipa_ck, poly, harness_shape, prng);
   Fr point = fr.to_mont(hr.field());
   FrVector z(ctx, degree + 1);
@@ -295,8 +329,8 @@ static void profile_ipa(const Opt& o, int lg, bool harness_shape) {
   auto first = AS::prove(keys.pk, inputs, {}, zk_rng);
   std::vector<ipa_pc_as::Accumulator> old{first.first};
   if (harness_shape) old.push_back(first.first);
-  auto res = AS::prove(keys.pk, inputs, old, zk_rng);
-  r.prove_ms = median_ms(o.reps, [&] { res = AS::prove(keys.pk, inputs, old, zk_rng); });
+  std::pair<ipa_pc_as::Accumulator, ipa_pc_as::Proof> res;
+  r.prove_ms = timed_proves(o, [&] { res = AS::prove(keys.pk, inputs, old, zk_rng); });
   t0 = Clock::now();
   r.verified = AS::verify(ctx, keys.vk, inputs, old, res.first, res.second);
   r.verify_ms = ms_since(t0);
@@ -313,6 +347,7 @@ static void profile_ipa(const Opt& o, int lg, bool harness_shape) {
     auto pb = ser::serialize(ctx, res.second);
     r.roundtrip = r.roundtrip && ser::serialize(ctx, ser::deserialize<ipa_pc_as::Proof>(ctx, pb)) == pb;
   }
+  if (!o.dump.empty()) dump_records(o, ser::serialize(ctx, res.first), ser::serialize(ctx, res.second));
   printf("Degree: %zu\n", degree);
   report(o, "ipa_pc_as", lg, "log2_degree_plus_1",
          harness_shape ? "harness: 1 input + 2x the same accumulator" : "n2: 1 input + 1 accumulator", harness_shape, r);
@@ -323,10 +358,10 @@ template <class Sponge>
 static void profile_trivial(const Opt& o, int lg, bool harness_shape) {
   using namespace trivial_pc_as;
   using AS = ASForTrivialPC<Sponge>;
-  Context ctx(o.curve, 0);
+  Context ctx(o.curve, o.device);
   hp_as::FrOps fr{o.curve};
   const size_t degree = ((size_t)1 << lg) - 1;
-  HarnessRng hr(0x7121A1);
+  HarnessRng hr(0x7121A1 ^ o.seed);
   Result r;
   CommitterKey pp = TrivialPC::setup(ctx, degree, 0x7121A1);
   CommitterKey ck = TrivialPC::trim(pp, degree);
@@ -341,8 +376,8 @@ static void profile_trivial(const Opt& o, int lg, bool harness_shape) {
   auto first = AS::prove(keys.prover_key, inputs, {});
   std::vector<Accumulator> old{first.first};
   if (harness_shape) old.push_back(first.first);
-  auto res = AS::prove(keys.prover_key, inputs, old);
-  r.prove_ms = median_ms(o.reps, [&] { res = AS::prove(keys.prover_key, inputs, old); });
+  std::pair<Accumulator, Proof> res;
+  r.prove_ms = timed_proves(o, [&] { res = AS::prove(keys.prover_key, inputs, old); });
   std::vector<InputInstance> ii{inputs[0].instance}, oi;
   for (auto& a : old) oi.push_back(a.instance);
   t0 = Clock::now();
@@ -362,6 +397,7 @@ static void profile_trivial(const Opt& o, int lg, bool harness_shape) {
     auto pb = ser::serialize(ctx, res.second);
     r.roundtrip = r.roundtrip && ser::serialize(ctx, ser::deserialize<Proof>(ctx, pb)) == pb;
   }
+  if (!o.dump.empty()) dump_records(o, ser::serialize(ctx, res.first), ser::serialize(ctx, res.second));
   printf("Degree: %zu\n", degree);
   report(o, "trivial_pc_as", lg, "log2_degree_plus_1",
          harness_shape ? "harness: 1 input + 2x the same accumulator" : "n2: 1 input + 1 accumulator", false, r);
@@ -391,7 +427,7 @@ int main(int argc, char** argv) {
   Opt o;
   if (argc < 4) {
     fprintf(stderr, "usage: %s <scheme|all> <log_min> <log_max> [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] "
-                    "[--curve 0|1] [--constant] [--no-roundtrip]\n", argv[0]);
+                    "[--curve 0|1] [--constant] [--no-roundtrip] [--device D] [--seed S] [--dump FILE]\n", argv[0]);
     return 2;
   }
   o.scheme = argv[1];
@@ -405,10 +441,17 @@ int main(int argc, char** argv) {
     else if (a == "--curve" && i + 1 < argc) o.curve = atoi(argv[++i]);
     else if (a == "--constant") o.constant = true;
     else if (a == "--no-roundtrip") o.roundtrip = false;
+    else if (a == "--device" && i + 1 < argc) o.device = atoi(argv[++i]);
+    else if (a == "--seed" && i + 1 < argc) o.seed = strtoull(argv[++i], nullptr, 0);
+    else if (a == "--dump" && i + 1 < argc) o.dump = argv[++i];
     else {
       fprintf(stderr, "unknown option %s\n", a.c_str());
       return 2;
     }
+  }
+  if (!o.dump.empty() && (o.scheme == "all" || o.log_min != o.log_max || o.shape == "both")) {
+    fprintf(stderr, "--dump takes one scheme, one size and one shape\n");
+    return 2;
   }
   try {
     if (o.sponge == "poseidon") run_all<poseidon::PoseidonSponge>(o);
