@@ -17,6 +17,16 @@ struct DevBuf {
 
 }  // namespace
 
+// One range of an MSM that is longer than the 2^c-pair window of its bucket-per-lane key (round 5; 2^22 pairs over the 20-bit key:
+// four ranges).  The ranges used to be independent MSMs -- four preps, four 2^19-bucket reductions, four folds, summed on the
+// host -- although they share the key's bucket index space: now range 1 writes the MSM's bucket table, ranges 2 .. k add to it
+// (k_accum_bpl<ACC>) and only the last one carries a tail.  The table is one of two the context owns (consecutive long MSMs
+// alternate; the first range of the next user waits for the previous user's tail through `shared_free`).
+struct Share {
+  int buf = -1;  // which of amsm_ctx::shared_buckets; -1: an ordinary MSM
+  bool first = false, last = false;
+};
+
 // One pipeline slot = one stream + one private workspace, so two MSMs of a batch can be in flight:
 // the latency-bound tail of MSM i (fold partials, bucket reduce) overlaps the throughput-bound head of
 // MSM i+1 on the other slot's stream.
@@ -38,6 +48,7 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   // the MSM this slot carries, kept until it is collected: a bucket-per-lane MSM whose prep reports a skewed input is
   // re-run from here through the chunked pipeline (msm_collect)
   struct Job {
+    Share share;  // this MSM is one range of a longer one whose ranges share a bucket set (buf >= 0)
     const amsm_bases* bases = nullptr;
     size_t base_off = 0, n = 0;
     const void* d_scalars = nullptr;
@@ -50,6 +61,7 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   size_t h_pinned_bytes = 0;
   MsmGeom geom = {};
   bool busy = false;
+  bool share_overflow = false;  // set by msm_collect: a range of a shared MSM found skewed digits -- the whole MSM is re-run unshared
   hipStream_t tail = nullptr;  // the stream this slot's tail (and its result copy) was queued on
 };
 
@@ -111,9 +123,16 @@ struct HostPool {
   std::mutex busy;
   HostPool() {
     int want = 7;  // (round 4: 3 -> 7 -- the harness shapes of hp_as / r1cs_nark_as prove 10-20 % faster, same box)
-    if (const char* e = getenv("AMSM_HOST_THREADS")) want = atoi(e);
-    const int hw = (int)std::thread::hardware_concurrency();
-    want = std::max(0, std::min(want, std::min(15, hw > 1 ? hw - 1 : 0)));
+    int hw = (int)std::thread::hardware_concurrency();
+    // one process per GPU (torchrun exports LOCAL_WORLD_SIZE): the node's cores are shared by that many pools -- eight ranks of
+    // seven helpers each would be 64 threads on whatever the box has (round 5: the driver's first 8-rank run must not find out)
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) {
+      const int lw = atoi(e);
+      if (lw > 1) hw = std::max(1, hw / lw);
+    }
+    if (const char* e = getenv("AMSM_HOST_THREADS")) want = atoi(e);  // explicit: taken as given (still below the cap of 15)
+    else want = std::min(want, hw > 1 ? hw - 1 : 0);
+    want = std::max(0, std::min(want, 15));
     for (int i = 0; i < want; i++) workers.emplace_back(new ShardWorker());
     // a fork()ed child (Python multiprocessing, a host that forks verifier workers) inherits this object but none of its
     // threads: the child drops the workers WITHOUT joining them and runs every region on the calling thread
@@ -217,6 +236,13 @@ struct amsm_ctx {
   bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline
                           // (AMSM_BPL_PROBE=0: find out from the prep's overflow flag only -- the safety net either way)
   unsigned long long n_bpl = 0, n_bpl_fallbacks = 0;  // MSMs that took it / that were re-run chunked (skewed digits)
+  // MSMs longer than the key's window: one bucket set for all their ranges (struct Share; AMSM_SHARE_BUCKETS=0: independent ranges, A/B)
+  bool share_buckets = true;
+  DevBuf shared_buckets[2];
+  hipEvent_t shared_free[2] = {};  // recorded behind the tail that last read the table
+  bool shared_used[2] = {false, false};
+  unsigned shared_rr = 0;
+  unsigned long long n_shared = 0;  // long MSMs that ran over one bucket set
   bool profiling = false;
   float stage_ms[ST_COUNT] = {};  // mean over the MSMs of the last call
   float stage_acc[ST_COUNT] = {};

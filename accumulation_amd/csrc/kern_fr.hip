@@ -238,6 +238,12 @@ static void prep_bps_attr() {
   prep_bps_attr_devices.fetch_or(bit, std::memory_order_release);
 }
 
+__global__ void k_mirror_flags(const u32* __restrict__ flags, u32* __restrict__ host_mirror) {
+  if (threadIdx.x < 2u) host_mirror[threadIdx.x] = flags[threadIdx.x];
+}
+void launch_mirror_flags(hipStream_t st, const u32* flags, u32* host_mirror) {
+  hipLaunchKernelGGL(k_mirror_flags, dim3(1), dim3(64), 0, st, flags, host_mirror);
+}
 void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
   hipLaunchKernelGGL(k_vec_fill, dim3(cdiv_(n, 256)), dim3(256), 0, st, out, make_uint4(v[0], v[1], v[2], v[3]),
                      make_uint4(v[4], v[5], v[6], v[7]), n);

@@ -15,7 +15,7 @@ void launch_accum_l0(hipStream_t st, const u32* table, const u32* vals_sorted, c
 // bucket-per-lane accumulation (msm_kernels.h: k_accum_bpl) over the transposed layout k_prep_local_t wrote
 template <class Fq>
 void launch_accum_bpl(hipStream_t st, const u32* table, const u32* ents_t, const void* grp, const u32* order, u32 n_groups,
-                      u32 groups_per_part, const u32* flags, u32* buckets, u32 wg_per_cu = 0);
+                      u32 groups_per_part, const u32* flags, u32* buckets, u32 wg_per_cu = 0, bool accumulate = false);
 // resident 256-lane workgroups of accumulate L0 per CU (occupancy query); lds_pad = unused dynamic LDS per workgroup,
 // which caps the residency (AMSM_L0_LDS_PAD: leaves wave slots / registers to the kernels of the other MSMs in flight)
 template <class Fq>
@@ -181,6 +181,9 @@ void launch_ipa_round_scalars(hipStream_t st, const u32* xi_mont, u32 j, u32 log
 template <class Fr>
 void launch_check_poly_coeffs(hipStream_t st, const u32* xi_mont, u32 k, u32* out);
 void launch_vec_fill(hipStream_t st, u32* out, const u32 value[8], u32 n);
+// the two flag words of an MSM slot (scalar-range error, prep overflow) into page-locked host memory: what k_fold's mirror does
+// for an MSM with a tail, for a range that leaves its sums in a shared bucket set and has none (api_pipeline.inc: Share)
+void launch_mirror_flags(hipStream_t st, const u32* flags, u32* host_mirror);
 void launch_bounds(hipStream_t st, const void* keys_sorted, bool keys16, u32* vals_sorted, MsmGeom g, u32* start, u32* items);
 
 }  // namespace amsm

@@ -193,7 +193,10 @@ AMSM_DEV void group_reduce_xyzz(XYZZ<Fq>& acc);
 struct BplGroupHdr {
   u32 base, m;
 };
-template <class Fq>
+// ACC (round 5): the bucket table already holds the sums of the MSM's earlier ranges (an MSM longer than the key's 2^c-pair
+// window runs as ranges of 2^c pairs over ONE bucket set: api_pipeline.inc Share) -- a lane starts from its bucket's sum instead
+// of the identity; the odd lane of a split bucket still starts empty (the exchange below adds the halves).
+template <class Fq, bool ACC>
 __global__ void __launch_bounds__(256)
     k_accum_bpl(const u32* __restrict__ table, const u32* __restrict__ ents_t, const BplGroupHdr* __restrict__ grp,
                 const u32* __restrict__ order, u32 n_groups, u32 groups_per_part, const u32* __restrict__ flags,
@@ -218,14 +221,17 @@ __global__ void __launch_bounds__(256)
     gw = (j * 4u + wave) * groups_per_part + q;
   }
   if (gw >= n_groups) return;
-#ifdef AMSM_BPL_FIXM  // (timing experiment: every wave the same length)
-  const u32 base = __builtin_amdgcn_readfirstlane(grp[gw].base), m = AMSM_BPL_FIXM;
-#else
   const u32 base = __builtin_amdgcn_readfirstlane(grp[gw].base), m = __builtin_amdgcn_readfirstlane(grp[gw].m);
-#endif
   const u32 b = order[gw * 64u + lane];
   const u32* row = ents_t + base + lane;
+  // the first and the last group of a partition hold the two halves of its 64 largest buckets on adjacent lanes
+  // (prep_kernels.h: BPL_SPLIT): one exchange after the rows, the even lane stores the bucket
+  const u32 q = gw % groups_per_part;
+  const bool pairs = q == 0u || q + 1u == groups_per_part;  // uniform per wave
   XYZZ<Fq> acc = xyzz_inf<Fq>();
+  if (ACC) {  // (issued before every other memory operation of the wave: the oldest to retire, the in-order waits below hold)
+    if (!pairs || !(lane & 1u)) acc = xyzz_load<Fq>(buckets, b);
+  }
   if (m) {
     u32 e0 = row[0];
     u32 e1 = m > 1u ? row[64] : BPL_PAD;
@@ -244,24 +250,14 @@ __global__ void __launch_bounds__(256)
       else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       Affine<Fq> pt = gather_read<Fq>(region, lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef AMSM_BPL_NOGATHER  // (timing experiments only: the two halves of the loop on their own)
       gather_issue<Fq>(table, e2 & ENTRY_IDX & ~BPL_PAD, region, lane);  // the points of iteration k + 2
-#endif
-#ifndef AMSM_BPL_NOMADD
       if (!(e0 & BPL_PAD)) xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (e0 & ENTRY_NEG) != 0));
-#else
-      if (!(e0 & BPL_PAD)) acc.x.v[0] ^= pt.x.v[0] ^ pt.y.v[1];
-#endif
       e0 = e1;
       e1 = e2;
       e2 = e3;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before the LDS is released
   }
-  // the first and the last group of a partition hold the two halves of its 64 largest buckets on adjacent lanes
-  // (prep_kernels.h: BPL_SPLIT): one exchange, the even lane stores the bucket
-  const u32 q = gw % groups_per_part;
-  const bool pairs = q == 0u || q + 1u == groups_per_part;  // uniform per wave
   if (pairs) group_reduce_xyzz<Fq, 2>(acc);
   if (!pairs || !(lane & 1u)) xyzz_store<Fq>(buckets, b, acc);
 }

@@ -50,6 +50,7 @@ SIGNATURES = {
     "amsm_ctx_collectives": (C.c_ulonglong, [_vp]),
     "amsm_ctx_two_valued_msms": (C.c_ulonglong, [_vp]),
     "amsm_ctx_direct_sum_msms": (C.c_ulonglong, [_vp]),
+    "amsm_ctx_shared_bucket_msms": (C.c_ulonglong, [_vp]),
     "amsm_ctx_pipeline_stats": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "amsm_ctx_pipeline_stats_small": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "amsm_ctx_destroy": (None, [_vp]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "amsm_pedersen_commit_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "amsm_host_lincomb": (C.c_int, [C.c_int, _vp, _vp, _vp, _sz, _vp, _vp]),
     "amsm_host_lincomb_batch": (C.c_int, [C.c_int, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amsm_host_threads": (C.c_int, []),
     "amsm_fr_mul": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),
     "amsm_fr_add": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),
     "amsm_fr_sub": (C.c_int, [C.c_int, _vp, _vp, _sz, _vp]),

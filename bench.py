@@ -167,7 +167,18 @@ def main() -> int:
         # puts the whole timed region inside that ramp.  A prover commits back to back for seconds: the steady state is the regime
         # the metric is about, so the device is kept busy with PREHEAT untimed MSMs of the same workload before the W warm-up steps
         # (reported as config.preheat_msms; --no-preheat measures from cold clocks).  The timed region is still exactly K steps.
+        # value_cold (round 5): the SAME K steps timed the way rounds 1-3 did -- W warm-up steps after an idle
+        # device, no preheat -- reported beside `value` in the same line so that rounds stay comparable whatever the protocol
+        elapsed_cold = None
         if not args.no_preheat:
+            sync_all()
+            time.sleep(0.25)  # idle clocks, as a freshly started process finds them
+            run_steps(args.warmup)
+            sync_all()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            sync_all()
+            elapsed_cold = time.perf_counter() - t0
             run_steps(PREHEAT_MSMS)
         run_steps(args.warmup)
         ctx.set_profiling(True)
@@ -198,18 +209,22 @@ def main() -> int:
         ms_host = (time.perf_counter() - t1) / 5 * 1e3
         # ... and the same host slices handed over back to back, the way the reference's provers call `commit`
         # (src/hp_as/mod.rs:372-385): amsm_msm_batch overlaps the upload of vector v + 1 with MSM v
-        ms_host_batch = pipe = plain_rate = ms_host_batch_pinned = ms_host_pinned = None
+        ms_host_batch = pipe = plain_rate = ms_host_batch_pinned = ms_host_pinned = ms_dev_batch12 = pinned_note = None
         if world == 1:
             h_vecs = [v.download() for v in vecs]
             VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(3)])
             reps = 12
+            # like with like: the device-resident batch of the SAME length (pipeline fill and drain weigh more in 12 MSMs than in K)
+            t1 = time.perf_counter()
+            VariableBaseMSM.multi_scalar_mul_batch(ck, [vecs[i % n_distinct] for i in range(reps)], mont=False)
+            ms_dev_batch12 = (time.perf_counter() - t1) / reps * 1e3
             t1 = time.perf_counter()
             hb_pts, hb_inf = VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(reps)])
             ms_host_batch = (time.perf_counter() - t1) / reps * 1e3
             if "all" in last and not (np.array_equal(hb_pts[:n_distinct], last["all"][0][:n_distinct])):
                 raise SystemExit("host-slice batch differs from the device-resident batch")
-            # the same slices page-locked by the caller (amsm_host_register -- what a Rust adapter can do once for the vectors it
-            # commits to repeatedly): asynchronous DMA copies
+            # the same slices page-locked by the caller (hipHostRegister through torch-free ctypes would do the same; the library's
+            # amsm_host_register is a documented no-op since round 5): a failure here never costs the bench line
             try:
                 for hv in h_vecs:
                     ctx.host_register(hv)
@@ -225,6 +240,10 @@ def main() -> int:
                 for _ in range(5):
                     ffi.check(ctx._lib.amsm_msm(ctx._h, ck._h, 0, _ptr(h_scalars), n, 0, _ptr(out), C.byref(inf)), "amsm_msm")
                 ms_host_pinned = (time.perf_counter() - t1) / 5 * 1e3
+            except SystemExit:
+                raise
+            except Exception as e:  # noqa: BLE001  (memlock limits, an already-registered range, ...)
+                pinned_note = f"{type(e).__name__}: {e}"
             finally:
                 for hv in h_vecs + [h_scalars]:
                     try:
@@ -250,7 +269,20 @@ def main() -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if world > 1 and elapsed_cold is not None:
+        t = torch.tensor([elapsed_cold], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_cold = float(t.item())
+    if world > 1:  # what every rank holds, for the line's `ranks` (a bad curve should be diagnosable from the JSON alone)
+        mem = ctx.memory()
+        mine = {"rank": rank, "key_bytes": key_bytes(ck, ctx, n), "workspace_bytes": mem["workspace_bytes"],
+                "host_pool_threads": int(ctx._lib.amsm_host_threads()), "pipeline_stats": ctx.pipeline_stats()}
+        held = [None] * world
+        dist.all_gather_object(held, mine)
+        for r_, h_ in zip(rank_info, held):
+            r_.update({k: v for k, v in h_.items() if k != "rank"})
     pairs_per_step = sum(r["pairs"] for r in rank_info) if rank_info else n
+    value_cold = None if elapsed_cold is None else pairs_per_step * args.steps / elapsed_cold
     total_pairs = pairs_per_step * args.steps
     value = total_pairs / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -290,6 +322,10 @@ def main() -> int:
                 # host slices, 12 per call (amsm_msm_batch): PCIe-inclusive like the line above, uploads overlapped
                 "ms_per_msm_host_scalars_batch": None if ms_host_batch is None else round(ms_host_batch, 4),
                 "pairs_per_s_host_scalars_batch": None if ms_host_batch is None else round(n / (ms_host_batch * 1e-3), 1),
+                # the device-resident batch of the same twelve MSMs, and the ratio the host slices reach of it
+                "pairs_per_s_device_batch_of_12": None if ms_dev_batch12 is None else round(n / (ms_dev_batch12 * 1e-3), 1),
+                "host_slices_fraction_of_device_batch_of_12": None if not (ms_dev_batch12 and ms_host_batch) else round(ms_dev_batch12 / ms_host_batch, 3),
+                "host_scalars_pinned_note": pinned_note,
                 # ... from page-locked caller memory (amsm_host_register): single blocking call / batches of 12
                 "ms_per_msm_host_scalars_pinned": None if ms_host_pinned is None else round(ms_host_pinned, 4),
                 "pairs_per_s_host_scalars_batch_pinned": None if ms_host_batch_pinned is None else round(n / (ms_host_batch_pinned * 1e-3), 1),
@@ -306,6 +342,11 @@ def main() -> int:
                 "ranks": rank_info,
                 "msms_in_flight": 1 if args.sync else 3,
                 "preheat_msms": 0 if args.no_preheat else PREHEAT_MSMS,
+                # the --no-preheat protocol of rounds 1-3 on the same box, same process (whole-job pairs/s; max over ranks)
+                "value_cold": value_cold,
+                "host_pool_threads": int(ctx._lib.amsm_host_threads()),
+                "collective": None if world == 1 else (f"torch.distributed all_gather_into_tensor of {sharded.engine.record_bytes}-byte records, "
+                                                        f"backend {args.backend}" + (f" (RCCL {rccl_version()})" if args.backend == "nccl" else "")),
                 "seeds": {"scalars": SEED_SCALARS, "points": SEED_POINTS},
             },
             "roofline": {
@@ -500,6 +541,15 @@ def alu_hw_roofline(args, ck, n, kernel_ms):
     return {"unit": "G mixed-additions/s", "achieved": a["achieved"], "peak": round(peak, 2), "frac": a["achieved"] / peak,
             "mads_per_mixed_addition": MADS_PER_MADD[args.curve],
             "basis": "v_mad_u64_u32 issue only: 5.2 cycles per wave64 per SIMD (tools/ubench_valu.hip), 1024 SIMDs, 2.4 GHz nominal"}
+
+
+def rccl_version():
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:  # noqa: BLE001
+        return f"unknown ({type(e).__name__})"
 
 
 def key_bytes(ck, ctx, n):

@@ -124,6 +124,11 @@ unsigned long long amsm_ctx_two_valued_msms(const amsm_ctx* ctx);
  * per index class -- whenever n is a multiple of 2 << group_shift (both classes then hold n / 2 indices), else they take the
  * windowed pipelines.  Results do not depend on the path. */
 unsigned long long amsm_ctx_direct_sum_msms(const amsm_ctx* ctx);
+/* MSMs longer than the 2^c-pair window of their bucket-per-lane key (2^22 pairs over a 20-bit key: BASELINE.json config 5, the
+ * commitments of src/hp_as/mod.rs:372-385,911-918) that ran over ONE bucket set: range 1 writes the set, ranges 2 .. k add to it,
+ * one bucket reduction and one fold per MSM instead of one per range (round 5).  A range whose digits turn out skewed sends the
+ * whole MSM back to independent ranges; results do not depend on the path. */
+unsigned long long amsm_ctx_shared_bucket_msms(const amsm_ctx* ctx);
 /* Which accumulation pipeline the context's MSMs took so far: *n_bucket_per_lane = MSMs enqueued on the bucket-per-lane
  * pipeline (keys of >= 2^20 generators, MSMs of (2^19, 2^20] pairs -- longer ones as windows of 2^20; 20-bit windows, 13
  * gathered additions per pair), *n_fallbacks = those whose scalars turned out skewed (a digit value shared by a large part of
@@ -308,6 +313,9 @@ int amsm_host_lincomb(int curve, const uint64_t* xy_mont, const uint8_t* is_inf,
 int amsm_host_lincomb_batch(int curve, size_t n_jobs, const size_t* n_terms, const uint64_t* const* xy_mont,
                             const uint8_t* const* is_inf, const uint64_t* const* scalars_mont, uint64_t* out_xy_mont,
                             uint8_t* out_is_inf);
+/* Helper threads of the process-wide host pool behind the two calls above (and behind the host backend): AMSM_HOST_THREADS if set,
+ * else min(7, cores / LOCAL_WORLD_SIZE - 1) -- a node's ranks (one process per GPU under torchrun) share its cores. */
+int amsm_host_threads(void);
 
 /* ---- device buffers for scalar-field vectors ------------------------------------------------- */
 int amsm_dev_alloc(amsm_ctx* ctx, size_t bytes, void** d_ptr);

@@ -69,3 +69,50 @@ def test_two_rank_branch_on_one_gpu(built_lib):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 1e7
     assert "point-sharded x2" in d["config"]["parallelism"]
+
+
+def _torchrun(nproc, port, script, *args, timeout=1500):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+                           "127.0.0.1", "--master-port", str(port), script, *args], capture_output=True, text=True, timeout=timeout,
+                          cwd=ROOT, env=env)
+
+
+@pytest.mark.parametrize("strong", [False, True], ids=["weak", "strong"])
+def test_eight_rank_branch_on_one_gpu(built_lib, strong):
+    """The driver's 8-GPU command line with all eight ranks on the one GPU of this box (gloo; numbers meaningless): rendezvous, the
+    rank table, max-over-ranks timing, eight 832 MiB keys + eight workspaces + eight host pools side by side -- what the first real
+    8-rank run would otherwise meet for the first time."""
+    args = ["--gpus", "8", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--one-gpu"] + (["--strong"] if strong else [])
+    r = _torchrun(8, 29561 + int(strong), os.path.join(ROOT, "bench.py"), *args)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = _line(r.stdout)
+    for k in KEYS:
+        assert k in d, k
+    cfg = d["config"]
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["scaling"] == ("strong" if strong else "weak")
+    assert len(cfg["ranks"]) == 8 and sorted(x["rank"] for x in cfg["ranks"]) == list(range(8))
+    per_rank = (1 << 20) // 8 if strong else 1 << 20
+    assert all(x["pairs"] == per_rank for x in cfg["ranks"])
+    assert d["value"] * d["ms_per_step"] * 1e-3 == pytest.approx(8 * per_rank, rel=1e-6)  # whole-job pairs / max-over-ranks time
+    for x in cfg["ranks"]:  # what a bad curve would be diagnosed from
+        assert x["key_bytes"]["table"] > 0 and x["workspace_bytes"] > 0 and "pipeline_stats" in x
+        assert 0 <= x["host_pool_threads"] <= 7
+    import multiprocessing
+    assert cfg["ranks"][0]["host_pool_threads"] <= max(0, multiprocessing.cpu_count() // 8 - 1) or cfg["ranks"][0]["host_pool_threads"] == 0
+    assert "gloo" in cfg["collective"] and "128-byte records" in cfg["collective"]
+    assert cfg["value_cold"] and cfg["value_cold"] > 0
+
+
+def test_sharded_schemes_eight_ranks_on_one_gpu(built_lib):
+    """BASELINE configs 4 / 5 in their 8-way layout (tools/bench_sharded.py): hp_as over 2^22 elements and r1cs_nark_as over 2^18
+    constraints split over eight ranks that share GPU 0, records exchanged over gloo; both accumulations verify and decide"""
+    r = _torchrun(8, 29571, os.path.join(ROOT, "tools", "bench_sharded.py"), "--backend", "gloo", "--one-gpu", "--reps", "2")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    kinds = {x["kind"]: x for x in lines}
+    assert set(kinds) == {"hp_as_sharded", "r1cs_nark_as_sharded"}
+    for x in lines:
+        assert x["n_gpus"] == 8 and x["verify_ok"] and x["decide_ok"] and x["scaling"] == "strong"
+    assert kinds["hp_as_sharded"]["elements_per_rank"] == (1 << 22) // 8
+    assert kinds["r1cs_nark_as_sharded"]["constraints_per_rank"] == (1 << 18) // 8
