@@ -145,8 +145,7 @@ class Context:
         return v
 
     def host_register(self, arr: np.ndarray) -> None:
-        """Page-lock a host array (amsm_host_register): the host-slice entry points then copy from it by DMA.  Keep the
-        array alive and call host_unregister before it is freed."""
+        """amsm_host_register: a documented no-op since round 5 (page-locking never gained and sometimes cost: include/amsm.h)."""
         ffi.check(self._lib.amsm_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes), "amsm_host_register")
 
     def host_unregister(self, arr: np.ndarray) -> None:

@@ -209,7 +209,7 @@ def main() -> int:
         ms_host = (time.perf_counter() - t1) / 5 * 1e3
         # ... and the same host slices handed over back to back, the way the reference's provers call `commit`
         # (src/hp_as/mod.rs:372-385): amsm_msm_batch overlaps the upload of vector v + 1 with MSM v
-        ms_host_batch = pipe = plain_rate = ms_host_batch_pinned = ms_host_pinned = ms_dev_batch12 = pinned_note = None
+        ms_host_batch = pipe = plain_rate = ms_dev_batch12 = None
         if world == 1:
             h_vecs = [v.download() for v in vecs]
             VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(3)])
@@ -223,33 +223,6 @@ def main() -> int:
             ms_host_batch = (time.perf_counter() - t1) / reps * 1e3
             if "all" in last and not (np.array_equal(hb_pts[:n_distinct], last["all"][0][:n_distinct])):
                 raise SystemExit("host-slice batch differs from the device-resident batch")
-            # the same slices page-locked by the caller (hipHostRegister through torch-free ctypes would do the same; the library's
-            # amsm_host_register is a documented no-op since round 5): a failure here never costs the bench line
-            try:
-                for hv in h_vecs:
-                    ctx.host_register(hv)
-                ctx.host_register(h_scalars)
-                VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(3)])
-                t1 = time.perf_counter()
-                hp_pts, _ = VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(reps)])
-                ms_host_batch_pinned = (time.perf_counter() - t1) / reps * 1e3
-                if not np.array_equal(hp_pts, hb_pts):
-                    raise SystemExit("page-locked host-slice batch differs from the pageable one")
-                ffi.check(ctx._lib.amsm_msm(ctx._h, ck._h, 0, _ptr(h_scalars), n, 0, _ptr(out), C.byref(inf)), "amsm_msm")
-                t1 = time.perf_counter()
-                for _ in range(5):
-                    ffi.check(ctx._lib.amsm_msm(ctx._h, ck._h, 0, _ptr(h_scalars), n, 0, _ptr(out), C.byref(inf)), "amsm_msm")
-                ms_host_pinned = (time.perf_counter() - t1) / 5 * 1e3
-            except SystemExit:
-                raise
-            except Exception as e:  # noqa: BLE001  (memlock limits, an already-registered range, ...)
-                pinned_note = f"{type(e).__name__}: {e}"
-            finally:
-                for hv in h_vecs + [h_scalars]:
-                    try:
-                        ctx.host_unregister(hv)
-                    except Exception:
-                        pass
             del h_vecs
             pipe = ctx.pipeline_stats()
             pipe["two_valued"] = ctx.two_valued_msms()  # 0 here: the timed vectors are uniform
@@ -325,10 +298,8 @@ def main() -> int:
                 # the device-resident batch of the same twelve MSMs, and the ratio the host slices reach of it
                 "pairs_per_s_device_batch_of_12": None if ms_dev_batch12 is None else round(n / (ms_dev_batch12 * 1e-3), 1),
                 "host_slices_fraction_of_device_batch_of_12": None if not (ms_dev_batch12 and ms_host_batch) else round(ms_dev_batch12 / ms_host_batch, 3),
-                "host_scalars_pinned_note": pinned_note,
-                # ... from page-locked caller memory (amsm_host_register): single blocking call / batches of 12
-                "ms_per_msm_host_scalars_pinned": None if ms_host_pinned is None else round(ms_host_pinned, 4),
-                "pairs_per_s_host_scalars_batch_pinned": None if ms_host_batch_pinned is None else round(n / (ms_host_batch_pinned * 1e-3), 1),
+                "host_scalars_page_locked": "not measured: amsm_host_register is a documented no-op since round 5 -- page-locked slices never ran "
+                                            "faster than pageable ones and ran up to 27 % slower (profiles/r05_host_slices.md)",
                 # no precomputed multiples (one copy of the key, a bucket set per window): the variable-base rate
                 "pairs_per_s_plain_key": None if plain_rate is None else round(plain_rate, 1),
                 "key_bytes": key_bytes(ck, ctx, n),

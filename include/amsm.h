@@ -262,18 +262,16 @@ int amsm_partials_combine_batch(amsm_ctx* ctx, const void* d_partials, size_t n_
 int amsm_msm_batch(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const uint64_t* const* scalars, size_t n_vecs,
                    size_t n, int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
 
-/* Round 4: page-lock caller memory so that the host-slice entry points (amsm_msm, amsm_msm_batch, amsm_pedersen_commit[_batch])
- * copy from it by DMA at the link's rate instead of staging pageable memory through the runtime's bounce buffers (~24 GB/s
- * measured: 1.4 ms per 2^20 scalars, longer than the MSM).  A Rust adapter registers the `Vec<Fr>` buffers it commits to
- * repeatedly (accumulator witnesses, the prover's r1cs vectors) once; memory from hipHostMalloc needs no registration.  The
- * calling thread is then not held by the copy (hipMemcpyAsync from pageable memory returns when the data has been staged).
- * Measured on MI355X / ROCm 7.2 (round 4): the runtime's pageable path already moves 56 GB/s and a host-slice batch runs
- * at the same rate from either kind of memory -- register where the CALLER needs its thread back, not for throughput.
- * Process-wide, reference counting is the caller's business: unregister before the memory is freed.
- * Errors: AMSM_E_INVALID_ARG (null / zero bytes), AMSM_E_HIP (already registered, not page-lockable), AMSM_E_NO_DEVICE. */
+/* Page-locking caller memory for the host-slice entry points (amsm_msm, amsm_msm_batch, amsm_pedersen_commit[_batch]).
+ * Since round 5 amsm_host_register / amsm_host_unregister are NO-OPS kept for binary compatibility (AMSM_OK; AMSM_E_INVALID_ARG
+ * for a null pointer / zero bytes): on MI355X / ROCm 7.2 a 32 MiB scalar vector crosses the link at 55-56 GB/s from pageable,
+ * registered and hipHostMalloc'ed memory alike, so page-locking cannot gain throughput, and it lost some -- the first copy out
+ * of a freshly registered region stalls ~2 ms (lazy pinning), on some boxes every copy does (host-slice batches -20 % .. -27 %).
+ * Evidence: profiles/r05_host_slices.md.  Hand the slices over as they are (a Rust `&[Fr]`); memory the caller has page-locked
+ * itself still works. */
 int amsm_host_register(void* ptr, size_t bytes);
 int amsm_host_unregister(void* ptr);
-/* 1: `ptr` is page-locked (registered or hipHostMalloc'ed) and the host-slice entry points will copy from it asynchronously */
+/* 1: `ptr` is page-locked (hipHostRegister'ed or hipHostMalloc'ed by the caller) */
 int amsm_host_is_pinned(const void* ptr);
 
 /* Replaces `PedersenCommitment::commit(ck, elems, Some(r))` (ext): MSM over ck.generators[..n] plus

@@ -93,6 +93,11 @@ def test_batch_at_2p20_with_a_constant_vector_in_the_middle(cref, probe):
         ctx.close()
 
 
+def ffi_mod():
+    from accumulation_amd import ffi
+    return ffi
+
+
 def test_batch_at_2p20_with_a_constant_slice_takes_the_two_valued_form(cref):
     """the same five host slices with the two-valued shortcut on (the default): the constant one is v * (the sum of the
     generators) -- no skew fallback, no twin -- and the four uniform ones run bucket-per-lane behind it"""
@@ -137,11 +142,12 @@ def test_vectors_longer_than_a_window_of_the_key(cref):
         ctx.close()
 
 
-def test_page_locked_slices_same_results_two_uploads_in_flight(cref):
-    """round 4: amsm_host_register -- the host-slice batch detects page-locked sources and keeps two uploads ahead of the MSM
-    being enqueued (DMA copies).  Same points as from pageable memory; registration is visible through amsm_host_is_pinned and
-    ends with amsm_host_unregister."""
+def test_page_locked_slices_same_results_and_register_is_a_no_op(cref):
+    """round 5: amsm_host_register / _unregister are documented no-ops (page-locking never gained throughput and cost some:
+    include/amsm.h, profiles/r05_host_slices.md) -- memory the CALLER page-locked itself (here: torch's pinned allocator) is still
+    taken as it is and gives the same points as pageable slices."""
     import ctypes as C
+    import torch
     from accumulation_amd import CommitterKey, Context, VariableBaseMSM
     c = o.PALLAS
     ctx = Context(c.curve_id)
@@ -153,20 +159,20 @@ def test_page_locked_slices_same_results_two_uploads_in_flight(cref):
         ref, rinf = VariableBaseMSM.multi_scalar_mul_batch_host(ck, vecs)
         lib = ctx._lib
         assert lib.amsm_host_is_pinned(C.c_void_p(vecs[0].ctypes.data)) == 0
-        for v in vecs:
-            ctx.host_register(v)
-        try:
-            assert all(lib.amsm_host_is_pinned(C.c_void_p(v.ctypes.data)) == 1 for v in vecs)
-            pts, infs = VariableBaseMSM.multi_scalar_mul_batch_host(ck, vecs)
-            assert np.array_equal(pts, ref) and np.array_equal(infs, rinf)
-            one, one_inf = VariableBaseMSM.multi_scalar_mul(ck, vecs[4])  # amsm_msm from a registered slice
-            assert np.array_equal(one, ref[4]) and bool(one_inf) == bool(rinf[4])
-            mixed = VariableBaseMSM.multi_scalar_mul_batch_host(ck, vecs[:3] + [vecs[3].copy()] + vecs[4:6])  # one pageable among them
-            assert np.array_equal(mixed[0], ref[:6])
-        finally:
-            for v in vecs:
-                ctx.host_unregister(v)
+        ctx.host_register(vecs[0])  # no-op: nothing is page-locked behind the caller's back
         assert lib.amsm_host_is_pinned(C.c_void_p(vecs[0].ctypes.data)) == 0
+        ctx.host_unregister(vecs[0])
+        assert lib.amsm_host_register(None, 8) == ffi_mod().AMSM_E_INVALID_ARG and lib.amsm_host_unregister(None) == ffi_mod().AMSM_E_INVALID_ARG
+        keep = [torch.from_numpy(v.view(np.int64)).pin_memory() for v in vecs]
+        pinned = [t.numpy().view(np.uint64) for t in keep]
+        assert all(lib.amsm_host_is_pinned(C.c_void_p(v.ctypes.data)) == 1 for v in pinned)
+        pts, infs = VariableBaseMSM.multi_scalar_mul_batch_host(ck, pinned)
+        assert np.array_equal(pts, ref) and np.array_equal(infs, rinf)
+        one, one_inf = VariableBaseMSM.multi_scalar_mul(ck, pinned[4])  # amsm_msm from a page-locked slice
+        assert np.array_equal(one, ref[4]) and bool(one_inf) == bool(rinf[4])
+        mixed = VariableBaseMSM.multi_scalar_mul_batch_host(ck, pinned[:3] + [vecs[3]] + pinned[4:6])  # one pageable among them
+        assert np.array_equal(mixed[0], ref[:6])
+        del pinned, keep
         got, ginf = cref.msm(c.curve_id, xy, vecs[2], threads=8)
         assert np.array_equal(ref[2], got) and bool(rinf[2]) == bool(ginf)
         ck.free()
