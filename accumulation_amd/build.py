@@ -55,7 +55,7 @@ def _compile(unit: str) -> str:
     src = os.path.join(CSRC, unit)
     obj = os.path.join(OBJ, unit.replace(".hip", ".o"))
     log = obj + ".log"
-    extra = os.environ.get("AMSM_EXTRA_FLAGS", "").split()  # e.g. -DAMSM_PALLAS_SAT (A/B of the Pallas field layout)
+    extra = os.environ.get("AMSM_EXTRA_FLAGS", "").split()  # (sanitizer / debug builds of the host side)
     cmd = ["hipcc", *FLAGS, *extra, "-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
     with open(log, "w") as lf:
         rc = subprocess.call(cmd, stdout=lf, stderr=subprocess.STDOUT)

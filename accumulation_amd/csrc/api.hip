@@ -29,6 +29,7 @@
 #include "host_poseidon.h"
 #include "host_serialize.h"
 #include "launch.h"
+#include "msm_select.h"
 #include "rng.h"
 
 using namespace amsm;

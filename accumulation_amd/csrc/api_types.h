@@ -17,6 +17,13 @@ struct DevBuf {
 
 }  // namespace
 
+// Measured constants of the launcher (environment knobs until round 5: each was A/B'd, the numbers are in DESIGN.md / profiles/)
+namespace tune {
+constexpr int K0_MAX = 32;                 // largest chunk of accumulate L0 (24 -> 805, 32 -> 811-816 M pairs/s in 2^20 batches)
+constexpr amsm::u32 K1 = 1024;             // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew)
+constexpr int TAIL_QUAD_HIDDEN_LOG2 = 17;  // bucket tables up to 2^this take the quad tail inside a batch too (2^16 234 -> 283 M pairs/s)
+}  // namespace tune
+
 // One range of an MSM that is longer than the 2^c-pair window of its bucket-per-lane key (round 5; 2^22 pairs over the 20-bit key:
 // four ranges).  The ranges used to be independent MSMs -- four preps, four 2^19-bucket reductions, four folds, summed on the
 // host -- although they share the key's bucket index space: now range 1 writes the MSM's bucket table, ranges 2 .. k add to it
@@ -30,10 +37,7 @@ struct Share {
 // One pipeline slot = one stream + one private workspace, so two MSMs of a batch can be in flight:
 // the latency-bound tail of MSM i (fold partials, bucket reduce) overlaps the throughput-bound head of
 // MSM i+1 on the other slot's stream.
-#ifndef AMSM_N_SLOTS
-#define AMSM_N_SLOTS 3
-#endif
-constexpr int N_SLOTS = AMSM_N_SLOTS;  // MSMs of one batch in flight (tools/build_variant.sh: -DAMSM_N_SLOTS=4 for an A/B)
+constexpr int N_SLOTS = 3;  // MSMs of one batch in flight (4 measured no better)
 
 struct Slot {  // buffers and events of one MSM in flight (the streams belong to the context: one per pipeline stage)
   hipEvent_t l0_done = nullptr, prep_done = nullptr;
@@ -176,62 +180,19 @@ struct amsm_ctx {
   hipStream_t stream = nullptr;  // main: the caller's stream -- accumulate L0 and every non-MSM kernel
   hipStream_t s_prep = nullptr;  // digits, sort, bounds, scan (memory-bound)
   hipStream_t s_tail = nullptr;  // fold partials, bucket reduce, fold, D2H (latency-bound)
-  // round 4: the one-lane bucket reduction is a ~0.55 ms chain of dependent point operations WHATEVER the bucket count; with one
-  // tail stream the tails of consecutive MSMs queue behind each other, which bounds a batch of 2^18 / 2^19-pair MSMs (whose
-  // accumulation takes 0.25 / 0.5 ms) at one MSM per 0.6 ms.  Consecutive MSMs alternate between two tail streams
-  // (AMSM_TAIL_STREAMS=1: one, A/B)
-  hipStream_t s_tail2 = nullptr;
-  unsigned tail_rr = 0;
-  int tail_streams = 1;  // (measured, same box: 2^19 batches 697 -> 580 M pairs/s with two, 2^20 unchanged: off)
-  int bpl_wg_per_cu = 0;  // AMSM_BPL_WG_PER_CU: resident k_accum_bpl workgroups per CU for small grids (0 = automatic)
   bool own_stream = false;
-  bool custom_prep = true;  // AMSM_PREP=rocprim: digits + rocPRIM radix sort + bounds + rocPRIM scan instead (A/B, fallback)
-  int window_override = 0;
-  int K0 = 0;          // 0 = automatic (see make_geom)
+  int window_override = 0;  // amsm_ctx_set_window: every MSM chunked with this width (tests, sweeps)
   int cu_count = 256;
-  // AMSM_L0_SPREAD=1: small launches as ONE round at 1-2 workgroups per CU (residency capped with unused LDS).  Built on the
-  // theory that the dispatcher packs a CU to the kernel's occupancy before moving on; measured in round 2 it changes nothing
-  // (2^16: 0.460 vs 0.447 ms per blocking call) -- the small-launch time was the per-flush bucket search.  Off.
-  bool small_spread = false;
-  u32 l0_lds_pad = 0;  // AMSM_L0_LDS_PAD: dynamic LDS bytes per accumulate-L0 workgroup that only cap its residency
-  int K0_max = 32;     // automatic choice: largest chunk (AMSM_K0_MAX); round 2, batches of 2^20-pair MSMs: 32 -> 811-816, 24 -> 805 Mpairs/s
-  bool two_phase = true;  // automatic choice: two chunk sizes so that the grid is a whole number of rounds (AMSM_K0_2PHASE=0: A/B)
   int wave_slots = 4096;  // resident accumulate-L0 waves: CUs x resident 256-lane blocks per CU x 4
-  int K1 = 1024;  // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew only)
-  int red_s = 0;  // buckets per lane of the bucket reduction; 0 = automatic (make_geom), AMSM_RED_S overrides
-  int split_log2 = 21;      // MSMs of 2^split_min_log2 pairs and more over a precomputed key run as windows of 2^split_log2
-  int split_min_log2 = 22;  // generators (msm_multi_split_xyzz; AMSM_SPLIT_LOG2=0 disables, AMSM_SPLIT_MIN_LOG2)
-  bool one_stream = true;  // a lone blocking MSM runs its whole chain on the caller's stream (AMSM_ONE_STREAM=0: per-stage streams, A/B)
-  int red2 = 1;  // bucket reduction as row / column sums for sets of 2^18 buckets and more (AMSM_RED2=0: never, 2: from 1024 buckets)
-  int tail_quad_hidden_log2 = 17;  // bucket tables up to 2^this take the quad tail inside a batch too (AMSM_TAIL_QUAD_HIDDEN_LOG2; 0: never)
-  bool tail_quad = true;  // bucket reduce / fold with a quad of lanes per logical lane (AMSM_TAIL_QUAD=0: one lane, A/B)
-  bool bpl = true;  // keys of 2^20 generators and more are precomputed for 20-bit windows and their MSMs of (2^19, 2^20] pairs
-                    // take the bucket-per-lane pipeline (AMSM_BPL=0: 17-bit windows + the chunked pipeline, round 2's path)
-  // round 4: window widths that add up to exactly 256 bits (MsmGeom::n_narrow) -- keys of 2^18 generators and more are
-  // precomputed that way and take the bucket-per-lane pipeline for any range that fills a quarter of their buckets, grouped
-  // MSMs included (AMSM_NARROW=0: round 3's tables -- 20-bit windows with a spread top window from 2^20, 16 bits below)
-  bool narrow = true;
-  int radix = 0;  // AMSM_RADIX: 1 = mixed-radix tables (R = 13 * 2^16 from 2^20 generators, 5 * 2^16 for 2^18 / 2^19), 0 = off
-  bool narrow_mid = false;  // AMSM_NARROW=2: also keys of 2^18 / 2^19 generators (c = 18 / 19; measured slower, api_pipeline.inc)
-  // round 4: plain keys (no precomputed multiples) of 2^16 .. 2^20 pairs take the bucket-per-lane pipeline with one bucket set
-  // per window, longer ones as ranges of 2^20 (AMSM_BPL_PLAIN=0: the chunked pipeline, round 3's path)
-  bool bpl_plain = true;
-  bool bpl_mid = false;  // (experiment, off: measured no better than the other pipelines) Pallas keys of 2^16 .. 2^19 generators: 17-bit windows and the bucket-per-lane pipeline for MSMs of
-                        // 2^15 .. 2^19 pairs over them (AMSM_BPL_MID=0: round 2's widths and the other pipelines)
-  // Bucket-split pipeline for precomputed-key MSMs of 2^16 .. 2^17 pairs (AMSM_BPS): 0 never; 1 (default) the grouped MSMs of
-  // the IPA opening rounds only -- their scalars are challenge products, uniform by construction, and the call is one blocking
-  // MSM (ipa_pc_as 2^16 prove 8.17 -> 7.69 ms); 2 every candidate, behind the skew probe -- pays on uniform vectors (hp_as 2^16
-  // prove 1.03 -> 0.85 ms, batches 216 -> 250 M pairs/s) but the probe's synchronisation and the constant vectors of the
-  // reference's DummyCircuit cost r1cs_nark_as at 2^16 more than that (5.2 -> 5.9 ms): not the default THEN.  Late in round 3 the
-  // constant vectors take the two-valued form, both probes share one synchronisation, the skew probe leaves at its first skewed
-  // window and skips two-valued vectors: r1cs_nark_as 2^16 harness-zk pays 1.73 -> 1.8 ms, uniform work gains (2^16 batches 199 ->
-  // 228 M pairs/s, hp_as 2^16 n = 2 prove 0.99 -> 0.84 ms) -- and north_star's workload is the uniform one: 2 is the default
-  int bps = 2;  // (late round 3: 2 -- see the comment's last lines)
-  int bps_max_log2 = 17;  // AMSM_BPS_MAX_LOG2: largest MSM (log2 pairs) the bucket-split pipeline takes (experiments)
+  // ---- the documented switches (include/amsm.h "Environment"; msm_select.h: Switches) -- everything else that used to be an
+  // environment knob is a measured constant now (namespace tune below; the A/Bs are in profiles/ and DESIGN.md) ----
+  bool bpl = true;        // AMSM_BPL=0: no 20-bit tables, no bucket-per-lane pipeline (17-bit windows + the chunked pipeline)
+  bool bpl_plain = true;  // AMSM_BPL_PLAIN=0: plain keys stay on the chunked pipeline
+  int bps = 2;            // AMSM_BPS: bucket-split pipeline 0 never, 1 grouped MSMs only, 2 every candidate of 2^16 .. 2^17 pairs
+  int split_log2 = 21;    // AMSM_SPLIT_LOG2: MSMs of 2^22 pairs and more over a key without a 20-bit table run as ranges of 2^this (0: whole)
   unsigned long long n_bps = 0, n_bps_fallbacks = 0;
   unsigned long long n_direct = 0;  // MSMs summed straight from a small key's 512-points-per-generator table (k_direct_sum)
   int direct_max_log2 = 15;         // keys of up to 2^this generators carry that table (AMSM_DIRECT_SUM_MAX_LOG2; 0: none)
-  int direct_m = 0;                 // windows per lane of k_direct_sum (AMSM_DIRECT_M; 0: by size)
   unsigned direct_rr = 0;           // which stream the next direct sum of a batch takes
   bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline
                           // (AMSM_BPL_PROBE=0: find out from the prep's overflow flag only -- the safety net either way)
@@ -313,7 +274,6 @@ struct amsm_bases {
   int bpl = 0;
   int top_shift = 0;  // MsmGeom::top_shift of the table (level W - 1 = 2^(c (W - 1) - top_shift) G)
   int n_narrow = 0;   // MsmGeom::n_narrow of the table (level w = 2^(window_exponent) G)
-  int radix_m = 0, radix_k = 0;  // MsmGeom::radix_m / radix_k of the table (level w = (m 2^k)^w G); 0: power-of-two windows
   // small keys (round 4): j 2^(4 w) G_i for j = 1 .. 8, w = 0 .. 63 at [((j - 1) 64 + w) n + i] -- every MSM over such a key that is
   // not grouped is a plain sum of table points (msm_kernels.h k_direct_sum); null: none
   u32* d_small = nullptr;

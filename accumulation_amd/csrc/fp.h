@@ -93,24 +93,20 @@ struct Fe {
 namespace amsm {
 
 // Field the DEVICE kernels compute in for a given ABI field: Pallas Fq runs on 9 x 29-bit unsaturated limbs
-// (internal Montgomery radix 2^261, fpu.h), BLS12-381 Fq on 14 x 28-bit limbs (radix 2^392); -DAMSM_PALLAS_SAT /
-// -DAMSM_BLS_SAT keep the saturated 32-bit-limb asm schedules (A/B).
+// (internal Montgomery radix 2^261, fpu.h), BLS12-381 Fq on 14 x 28-bit limbs (radix 2^392).  (The saturated 32-bit-limb
+// schedules serve both scalar fields; for the base fields they measured 21 % / 23 % slower: DESIGN.md 4.1.)
 template <class Fq>
 struct DevField {
   using type = Fq;
 };
-#ifndef AMSM_PALLAS_SAT
 template <>
 struct DevField<PallasFq> {
   using type = PallasFqU;
 };
-#endif
-#ifndef AMSM_BLS_SAT
 template <>
 struct DevField<Bls12381Fq> {  // 14 x 28-bit limbs, internal radix 2^392: mixed addition 22.6 k vs 29.4 k cycles
   using type = Bls12381FqU;
 };
-#endif
 
 template <class P>
 AMSM_DEV Fe<P> fe_zero() {
@@ -261,7 +257,7 @@ AMSM_DEV Fe<P> fe_dot3(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const 
 }
 
 }  // namespace amsm
-#if !defined(AMSM_NO_ASM_MUL) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
 #include "fp_mul_gfx950.h"
 #endif
 namespace amsm {

@@ -54,68 +54,28 @@ struct Bls12381FqU {  // 14 x 28 bits, R' = 2^392 ~ 2520 p: measured against the
   AMSM_TABLE(k_export, 14, 0x0002fffdu, 0x00900000u, 0x0c000276u, 0x0000bc40u, 0x08baebf4u, 0x05753c75u, 0x055f4898u, 0x07052574u, 0x07ce5853u, 0x056ec6d7u, 0x071a97a2u, 0x0e4935c0u, 0x0ec3fa80u, 0x00015f65u)
 };
 
-// Round 3: the two SCALAR fields on 9 x 29 limbs for the arbitrary-coefficient linear combination (vec_kernels.h).  Memory stays what ark-ff defines (8
-// words, Montgomery radix R = 2^256): a multiplication here divides by 2^261, so every product carries a factor 1/32 -- which the
-// launcher absorbs into the (uniform) coefficients on the host.
-// Both moduli are 1 mod 2^29 (constant-add reduction step); Pallas' has the 2^22 top limb as well.
-struct PallasFr;
-struct PallasFrU {
-  using Sat = PallasFr;
-  static constexpr int L = 9;
-  static constexpr int W = 8;
-  static constexpr int B = 29;
-  static constexpr bool UNSAT = true;
-  static constexpr u32 NINV = 0x1fffffffu;
-  static constexpr bool CHAIN = true;
-  AMSM_TABLE(mod, 9, 0x00000001u, 0x02375908u, 0x052a3763u, 0x0d31f813u, 0x00000224u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00400000u)
-};
-struct Bls12381Fr;
-struct Bls12381FrU {
-  using Sat = Bls12381Fr;
-  static constexpr int L = 9;
-  static constexpr int W = 8;
-  static constexpr int B = 29;
-  static constexpr bool UNSAT = true;
-  static constexpr u32 NINV = 0x1fffffffu;
-  static constexpr bool CHAIN = false;
-  AMSM_TABLE(mod, 9, 0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u)
-};
-
 template <class P>
 AMSM_HD constexpr u32 u_mask() {
   return (1u << P::B) - 1u;
 }
 
-// ---- reduction-step knobs (round 3; A/B with tools/fp_bench.hip: -DAMSM_UCHAIN=0 -DAMSM_UCONST=0 restore round 2) ----
+// ---- the reduction step's two tricks (round 3; the A/B against round 2's schedule is in DESIGN.md 4.1) ----
 // The compiler's own schedule of a 9 x 29 product (round 2) kept one 64-bit accumulator chain PER COLUMN, started from zero,
 // and merged it with the carry of the column below by a 64-bit add (v_lshl_add_u64: half rate); the reduction step added
 // m * p_0 = m as a zero-extended 64-bit add (v_mov + v_lshl_add_u64) and m * 2^22 as a 64-bit shift + 64-bit add: 99 non-MAD
 // instructions per multiplication, 63 of them half rate, next to 117 MADs.  Round 3:
-//   AMSM_UCHAIN: an opaque (empty-asm) use of the accumulator after every column shift, so that the next column's MADs chain
+//   chain:  an opaque (empty-asm) use of the accumulator after every column shift, so that the next column's MADs chain
 //                from the carry instead of from zero (no merge add);
-//   AMSM_UCONST: p_0 = 1 (Pallas: p = 1 mod 2^29): (acc + m) >> B == (acc + 2^B - 1) >> B, one 64-bit add of a constant and no
+//   const:  p_0 = 1 (Pallas: p = 1 mod 2^29): (acc + m) >> B == (acc + 2^B - 1) >> B, one 64-bit add of a constant and no
 //                m in the low column; a power-of-two limb of p (2^22 at limb 8) as a MAD by a constant held in an SGPR the
 //                compiler cannot see through (one half-rate instruction instead of shift + add).
 // Measured (MI355X, cycles per operation per SIMD at 2 / 4 waves per SIMD): Pallas multiplication 899 / 862 -> 877 / 822, squaring
 // 747 / 709 -> 715 / 685, mixed addition 8 640 / 8 288 -> 8 208 / 7 963 (-5 % / -4 %); 126 MADs + 81 full-rate + 40 half-rate
 // instructions per multiplication instead of 117 + 89 + 59.  BLS12-381 (p_0 != 1, no power-of-two limb) is unchanged.  A strictly
-// linear chain (an opaque use after EVERY product, AMSM_UCHAIN=2) removes the remaining merge adds but spills: 12 300.
-#ifndef AMSM_UCHAIN
-#define AMSM_UCHAIN 1
-#endif
-#ifndef AMSM_UCONST
-#define AMSM_UCONST 1
-#endif
+// linear chain (an opaque use after EVERY product) removes the remaining merge adds but spills: 12 300.
 template <class P>
 AMSM_DEV void u_opaque(u64& acc) {
-#if AMSM_UCHAIN
   if constexpr (P::CHAIN) asm("" : "+v"(acc));
-#endif
-}
-AMSM_DEV void u_opaque2(u64& acc) {  // AMSM_UCHAIN=2 (experiment): a strictly linear MAD chain, opaque after every product
-#if AMSM_UCHAIN >= 2
-  asm("" : "+v"(acc));
-#endif
 }
 template <u32 V>
 AMSM_DEV u32 u_sgpr_const() {  // V in an SGPR, opaque to the optimiser (hoisted out of loops like any pure expression)
@@ -131,12 +91,8 @@ AMSM_DEV void u_red_term(u64& acc, const u32* m) {
   constexpr int J = K - I;
   if constexpr (I < K && J >= 1 && J < P::L) {
     if constexpr (P::mod(J) != 0) {
-#if AMSM_UCONST
       if constexpr (u_is_pow2(P::mod(J))) acc += (u64)m[I] * u_sgpr_const<P::mod(J)>();
-      else
-#endif
-        acc += (u64)m[I] * P::mod(J);
-      u_opaque2(acc);
+      else acc += (u64)m[I] * P::mod(J);
     }
   }
 }
@@ -155,12 +111,7 @@ AMSM_DEV u32 u_red_low(u64& acc) {
   u32 mk;
   if constexpr (P::NINV == M) {  // p_0 = 1
     mk = (0u - lo) & M;
-#if AMSM_UCONST
     acc = (acc + (u64)M) >> P::B;  // == (acc + mk) >> B: lo + mk is 0 or 2^B
-#else
-    acc += (u64)mk;
-    acc >>= P::B;
-#endif
   } else {
     mk = (lo * P::NINV) & M;
     acc += (u64)mk * P::mod(0);
@@ -258,7 +209,6 @@ AMSM_DEV Fe<P> u_mul(const Fe<P>& a, const Fe<P>& b, const Fe<P>* add = nullptr)
       int j = k - i;
       if (j >= 0 && j < L) {
         ac += (u64)a.v[i] * b.v[j];
-        u_opaque2(ac);
       }
     }
   });
@@ -280,9 +230,7 @@ AMSM_DEV Fe<P> u_mul_add_mul(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, con
       int j = k - i;
       if (j >= 0 && j < L) {
         ac += (u64)a.v[i] * b.v[j];
-        u_opaque2(ac);
         ac += (u64)c.v[i] * d.v[j];
-        u_opaque2(ac);
       }
     }
   });
@@ -350,7 +298,7 @@ AMSM_DEV Fe<P> u_sqr(const Fe<P>& a, const Fe<P>* add = nullptr) {
       if (j >= 0 && j < L) {
         if (i < j) ac += (u64)a2[i] * a.v[j];
         else if (i == j) ac += (u64)a.v[i] * a.v[i];
-        if (i <= j) u_opaque2(ac);
+
       }
     }
   });

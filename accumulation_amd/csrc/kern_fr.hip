@@ -14,12 +14,10 @@ namespace amsm {
 
 static inline u32 cdiv_(u32 a, u32 b) { return (a + b - 1) / b; }
 // grid of a streaming (grid-stride) kernel: enough 256-lane workgroups to fill the wave slots a few times over, not one
-// per 256 elements beyond that (AMSM_VEC_BLOCKS_PER_CU overrides the 64 per CU: one element per lane up to 2^22 elements)
+// per 256 elements beyond that (64 per CU: one element per lane up to 2^22 elements; round 2, 2^22 elements: 64 -> 0.57-0.79 of
+// 8 TB/s, 8 -> 0.52-0.75)
 static u32 stream_grid(u32 n) {
-  static const u32 per_cu = [] {
-    const char* e = getenv("AMSM_VEC_BLOCKS_PER_CU");
-    return (u32)std::max(1, e ? atoi(e) : 64);  // round 2, 2^22 elements: 64 -> 0.57-0.79 of 8 TB/s, 8 -> 0.52-0.75
-  }();
+  constexpr u32 per_cu = 64;
   static const u32 cus = [] {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -63,8 +61,6 @@ static PrepGeom prep_geom(const MsmGeom& g) {
   // heavy: several times the expected size AND big enough for 64 workgroups to beat one (below, one workgroup is fine)
   pg.HEAVY = std::max<u32>(4u * (g.E / pg.P + 1u), 1u << 17);
   pg.FIX = 0;
-  if (const char* e = getenv("AMSM_PREP_HEAVY"))  // 0: one workgroup per partition whatever its size (A/B)
-    if (atoi(e) == 0) pg.HEAVY = 0xffffffffu;
   return pg;
 }
 // words per per-bucket array of the heavy-partition path (every partition's 2^SH buckets, padded)
@@ -114,11 +110,10 @@ static PrepGeom prep_bpl_geom(const MsmGeom& g) {
   while ((max_idx >> pg.IB) != 0ull) pg.IB++;
   pg.CAP = BPL_LOCAL_BUDGET_WORDS - BPL_LOCAL_FIXED_WORDS;  // ~35.3 k entries: a partition of a 2^20-pair MSM holds ~26.6 k
   pg.HEAVY = 0xffffffffu;
-  static const bool with_hist = [] { const char* e = getenv("AMSM_BPL_HIST"); return e && atoi(e) != 0; }();  // A/B
   // fixed partitions: what uniform digits bring plus a quarter and a constant, at most what the LDS stage takes (a partition
   // beyond it takes the skew fallback either way)
   const unsigned long long per = std::max<unsigned long long>(((unsigned long long)g.E + pg.P - 1) / std::max(1u, pg.P), g.part_max);
-  pg.FIX = with_hist ? 0u : (u32)std::min<unsigned long long>(pg.CAP, (per + per / 4ull + 2048ull + 15ull) & ~15ull);
+  pg.FIX = (u32)std::min<unsigned long long>(pg.CAP, (per + per / 4ull + 2048ull + 15ull) & ~15ull);
   return pg;
 }
 // 8-byte interchange entries the partition pass may write (fixed partitions reserve FIX each)
@@ -186,9 +181,8 @@ static PrepGeom prep_bps_geom(const MsmGeom& g, u32 log2_l) {
   pg.CAP = BPS_LOCAL_BUDGET_WORDS - bps_local_fixed_words(1u << pg.SH);
   pg.HEAVY = 0xffffffffu;
   // fixed partitions (PrepGeom::FIX): half as much again as a uniform partition holds, at most what the LDS stage takes
-  static const bool with_hist = [] { const char* e = getenv("AMSM_BPS_HIST"); return e && atoi(e) != 0; }();  // A/B
   const unsigned long long per = ((unsigned long long)g.E + pg.P - 1) / std::max(1u, pg.P);
-  pg.FIX = with_hist ? 0u : (u32)std::min<unsigned long long>(pg.CAP, (per + per / 2ull + 1024ull + 15ull) & ~15ull);
+  pg.FIX = (u32)std::min<unsigned long long>(pg.CAP, (per + per / 2ull + 1024ull + 15ull) & ~15ull);
   return pg;
 }
 // 4-byte interchange entries the partition pass may write
@@ -210,7 +204,6 @@ u32 prep_bps_stride(const MsmGeom& g, u32 log2_l) {
 int prep_bps_choose(const MsmGeom& g) {
   if (!g.precomp || g.n == 0 || g.S > 32u || g.B < 64u || (g.B & (g.B - 1u))) return -1;
   unsigned long long want = 128;
-  if (const char* e = getenv("AMSM_BPS_WANT")) want = (unsigned long long)std::max(1, atoi(e));  // partitions wanted (A/B)
   while (want * 24576ull < g.E) want <<= 1;
   for (int l = 0; l <= 6; l++) {
     if ((10 - l) < 0 || (g.B >> (10 - l)) == 0) continue;
@@ -247,54 +240,6 @@ void launch_mirror_flags(hipStream_t st, const u32* flags, u32* host_mirror) {
 void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
   hipLaunchKernelGGL(k_vec_fill, dim3(cdiv_(n, 256)), dim3(256), 0, st, out, make_uint4(v[0], v[1], v[2], v[3]),
                      make_uint4(v[4], v[5], v[6], v[7]), n);
-}
-
-// ---- host-side coefficient preparation for the 9 x 29-limb vector kernels (vec_kernels.h, round 3) ----
-// AMSM_VEC_SAT=0: combinations with arbitrary coefficients on round 3's 9 x 29-limb kernels (k_vec_combine_u) -- the default
-// since round 4 is the generated 8 x 32 multiplier everywhere, whose fe_dot2 / fe_dot3 share one reduction between products too
-static bool vec_sat() {
-  static const bool on = [] {
-    const char* e = getenv("AMSM_VEC_SAT");
-    return !e || atoi(e) != 0;
-  }();
-  return on;
-}
-template <class Fr>
-static void fr_times_pow2(const u32 in[8], int k, u32 out[8]) {  // in * 2^k mod r (in < r)
-  u32 v[8];
-  memcpy(v, in, 32);
-  for (int t = 0; t < k; t++) {
-    u32 carry = 0;
-    for (int i = 0; i < 8; i++) {
-      const u32 nv = (v[i] << 1) | carry;
-      carry = v[i] >> 31;
-      v[i] = nv;
-    }
-    bool ge = carry != 0;
-    if (!ge) {
-      ge = true;
-      for (int i = 7; i >= 0; i--)
-        if (v[i] != Fr::mod(i)) {
-          ge = v[i] > Fr::mod(i);
-          break;
-        }
-    }
-    if (ge) {
-      u64 borrow = 0;
-      for (int i = 0; i < 8; i++) {
-        const u64 d = (u64)v[i] - Fr::mod(i) - borrow;
-        v[i] = (u32)d;
-        borrow = (d >> 63) & 1u;
-      }
-    }
-  }
-  memcpy(out, v, 32);
-}
-template <class Fr>
-static bool fr_is_one(const u32 c[8]) {
-  for (int i = 0; i < 8; i++)
-    if (c[i] != Fr::one(i)) return false;
-  return true;
 }
 
 void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
@@ -469,22 +414,7 @@ void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
   template <>                                                                                                        \
   void launch_vec_combine<FR>(hipStream_t st, const CombineArgs& a_in, u32* out) {                                   \
     dim3 grid(stream_grid(a_in.n)), block(256);                                                                      \
-    CombineArgs a = a_in;                                                                                            \
-    const bool f1 = a.n_vecs >= 1 && fr_is_one<FR>(a.coeff[0]);                                                      \
-    if (!vec_sat() && !f1 && a.n_vecs >= 1) { /* see vec_kernels.h: wins only without a unit first coefficient */    \
-      for (u32 j = 0; j < a.n_vecs && j < (u32)VEC_MAX; j++) fr_times_pow2<FR>(a.coeff[j], 5, a.coeff_u[j]);         \
-      switch (a.n_vecs) {                                                                                            \
-        case 1: hipLaunchKernelGGL((k_vec_combine_u<FR, 1>), grid, block, 0, st, a, out); break;                     \
-        case 2: hipLaunchKernelGGL((k_vec_combine_u<FR, 2>), grid, block, 0, st, a, out); break;                     \
-        case 3: hipLaunchKernelGGL((k_vec_combine_u<FR, 3>), grid, block, 0, st, a, out); break;                     \
-        case 4: hipLaunchKernelGGL((k_vec_combine_u<FR, 4>), grid, block, 0, st, a, out); break;                     \
-        case 5: hipLaunchKernelGGL((k_vec_combine_u<FR, 5>), grid, block, 0, st, a, out); break;                     \
-        case 6: hipLaunchKernelGGL((k_vec_combine_u<FR, 6>), grid, block, 0, st, a, out); break;                     \
-        case 7: hipLaunchKernelGGL((k_vec_combine_u<FR, 7>), grid, block, 0, st, a, out); break;                     \
-        default: hipLaunchKernelGGL((k_vec_combine_u<FR, 8>), grid, block, 0, st, a, out); break;                    \
-      }                                                                                                              \
-      return;                                                                                                        \
-    }                                                                                                                \
+    const CombineArgs& a = a_in;                                                                                     \
     switch (a.n_vecs) {                                                                                              \
       case 0: /* only the hiding addend */                                                                          \
       case 1: hipLaunchKernelGGL((k_vec_combine<FR, 1>), grid, block, 0, st, a, out); break;                         \

@@ -11,15 +11,14 @@ namespace amsm {
 // ---- per-curve (Fq) launchers ------------------------------------------------------------------
 template <class Fq>
 void launch_accum_l0(hipStream_t st, const u32* table, const u32* vals_sorted, const u32* start,
-                     const u32* item_off, MsmGeom g, u32* partials, u32 lds_pad = 0);
+                     const u32* item_off, MsmGeom g, u32* partials);
 // bucket-per-lane accumulation (msm_kernels.h: k_accum_bpl) over the transposed layout k_prep_local_t wrote
 template <class Fq>
 void launch_accum_bpl(hipStream_t st, const u32* table, const u32* ents_t, const void* grp, const u32* order, u32 n_groups,
                       u32 groups_per_part, const u32* flags, u32* buckets, u32 wg_per_cu = 0, bool accumulate = false);
-// resident 256-lane workgroups of accumulate L0 per CU (occupancy query); lds_pad = unused dynamic LDS per workgroup,
-// which caps the residency (AMSM_L0_LDS_PAD: leaves wave slots / registers to the kernels of the other MSMs in flight)
+// resident 256-lane workgroups of accumulate L0 per CU (occupancy query)
 template <class Fq>
-int accum_l0_blocks_per_cu(u32 lds_pad = 0);
+int accum_l0_blocks_per_cu();
 template <class Fq>
 void launch_accum_l1(hipStream_t st, u32 lanes_per_bucket, const u32* partials, const u32* items, const u32* item_off, MsmGeom g,
                      u32* buckets, u32* heavy_count, u32* heavy_list);
@@ -45,7 +44,7 @@ void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, 
                       bool clear_flags = false);  // clear_flags: the two words are zeroed once they have been copied out
 template <class Fq>
 // level = 2^c * mul_m * (level - 1); mul_m = 0 / 1: no small multiple (power-of-two windows)
-void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c, u32* xyzz_scratch, u32 mul_m = 0);
+void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, u32 c, u32* xyzz_scratch);
 // levels 1 .. W - 1 of a small key (plain c-bit windows) from level 0 in two launches; xyzz_scratch: (W - 1) n records
 template <class Fq>
 void launch_precompute_all_levels(hipStream_t st, u32* table, u32 n, u32 c, u32 W, u32* xyzz_scratch);
@@ -87,9 +86,8 @@ void launch_points_fold(hipStream_t st, const u32* l, const u32* r, u32 n, const
 // window_exponent_of(c, W, n_narrow, 0, w); levels 0 .. levels-1 usable): out[i] = table[i] + x * table[n + i], i < n.  False
 // (nothing launched) when x does not fit the usable levels.
 template <class Fq>
-// radix_m > 0: mixed-radix levels (level w = (radix_m 2^radix_k)^w G): x is cut into radix-R digits instead
 bool launch_points_fold_tab(hipStream_t st, const u32* table, u32 stride, u32 c, u32 W, u32 n_narrow, u32 levels, u32 n,
-                            const u32 x_canon[8], u32 nbits, u32* out, u32* xyzz_scratch, u32 radix_m = 0, u32 radix_k = 0);
+                            const u32 x_canon[8], u32 nbits, u32* out, u32* xyzz_scratch);
 
 // two-valued vectors (vec_kernels.h k_tv_probe, msm_kernels.h k_tv_sum): exact probe into TV_PROBE_WORDS zeroed words, and the
 // sum of the generators with non-zero scalars as `blocks` partial records

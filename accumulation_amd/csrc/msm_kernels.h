@@ -78,11 +78,8 @@ AMSM_DEV Affine<Fq> gather_read(const u32* lds_wave, u32 lane) {
 // after the sort), bits 0..29 = index into the generator table.
 constexpr u32 ENTRY_NEG = 0x80000000u, ENTRY_LAST = 0x40000000u, ENTRY_IDX = 0x3fffffffu;
 
-#ifndef AMSM_L0_VGPR_ATTR
-#define AMSM_L0_VGPR_ATTR
-#endif
 template <class Fq>
-__global__ void __launch_bounds__(256) AMSM_L0_VGPR_ATTR
+__global__ void __launch_bounds__(256)
     k_accum_l0(const u32* __restrict__ table, const u32* __restrict__ vals_sorted, const u32* __restrict__ start,
                const u32* __restrict__ item_off, MsmGeom g, u32* __restrict__ partials) {
   // two gather regions per wave: the points of mixed addition i+2 are fetched while i and i+1 are computed
@@ -906,25 +903,14 @@ __global__ void __launch_bounds__(256) k_batch_to_affine(const u32* __restrict__
 // unconverted in xyzz_out[i] for k_batch_to_affine (large keys: the per-point inversion is 2/3 of this kernel).
 template <class Fq, bool XYZZ_OUT>
 __global__ void __launch_bounds__(256)
-    k_precompute_level(u32* __restrict__ table, u32 stride, u32 level, u32 c, u32* __restrict__ xyzz_out, u32 mul_m) {
+    k_precompute_level(u32* __restrict__ table, u32 stride, u32 level, u32 c, u32* __restrict__ xyzz_out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= stride) return;
   Affine<Fq> p = affine_load<Fq>(table, (size_t)(level - 1) * stride + i);
   XYZZ<Fq> a = xyzz_inf<Fq>();
   if (!affine_is_inf<Fq>(p)) {
-    if (mul_m > 1u) {  // mixed radix: first the small odd multiple m p (double-and-add over m's bits, mixed additions of p) ...
-      a = xyzz_dbl_affine<Fq>(p);  // the top bit of m, doubled once: m >= 2
-      const int top = 31 - __clz(mul_m);
-      if ((mul_m >> (top - 1)) & 1u) xyzz_madd<Fq>(a, p);
-      for (int b = top - 2; b >= 0; b--) {
-        a = xyzz_dbl<Fq>(a);
-        if ((mul_m >> b) & 1u) xyzz_madd<Fq>(a, p);
-      }
-      for (u32 k = 0; k < c; k++) a = xyzz_dbl<Fq>(a);  // ... then 2^c
-    } else {
-      a = xyzz_dbl_affine<Fq>(p);
-      for (u32 k = 1; k < c; k++) a = xyzz_dbl<Fq>(a);
-    }
+    a = xyzz_dbl_affine<Fq>(p);
+    for (u32 k = 1; k < c; k++) a = xyzz_dbl<Fq>(a);
   }
   if (XYZZ_OUT) {
     xyzz_store<Fq>(xyzz_out, i, a);

@@ -35,7 +35,6 @@ struct MsmGeom {
   u32 nA;            // chunks of phase A (a multiple of 256: a workgroup never straddles the phases)
   u32 T0;            // entries covered by phase A = nA * K0
   u32 n_chunks;      // work items of accumulate L0 (upper bound: sized for E entries)
-  u32 l0_per_cu;     // host only: resident accumulate-L0 workgroups per CU to enforce for this launch (0 = natural occupancy)
   u32 K1;            // max partials folded by one L1 lane
   u32 top_split;     // plain keys on the bucket-per-lane pipeline (round 4): the TOP window owns two bucket sets, the scalars with an
                      // even index feed the first, the odd ones the second (the host adds the two sums) -- its digits reach only
@@ -54,11 +53,6 @@ struct MsmGeom {
                      // A narrow window's signed digit is DOUBLED (it lands on the even buckets of the full range) and what it
                      // multiplies stands one doubling short: table level w = 2^(e_w) G (precomputed key) / the set's sum counts
                      // 2^(e_w) (plain key), e_w = window_exponent().  0: the legacy walk (equal widths, top_shift)
-  u32 radix_m;       // round 4, mixed radix: m > 0 -- the W digits are taken in radix R = radix_m * 2^radix_k (m small and odd: 5, 13), NOT
-  u32 radix_k;       // a power of two: R^W just covers 2^256, so all W digits are uniform over (-R/2, R/2] and every one of the
-  u32 radix_magic;   // nb = R / 2 buckets is fed alike by every window (no narrow / doubled / spread window).  Table level w =
-                     // R^w G.  radix_magic = floor(2^32 / m) + 1 (division by m as a multiply-high, vec_kernels.h: digit_step).
-                     // c = ceil(log2 R) then only sizes words; n_narrow = top_shift = 0
   u32 bpl;           // 1: bucket-per-lane pipeline (k_prep_local_t + k_accum_bpl; 20-bit windows), 2: bucket-split pipeline
                      // (k_prep_local_s + k_accum_bps; small and medium MSMs), 0: chunked pipeline
   u32 bps_log2_l;    // bucket-split: log2 of the lanes per bucket
@@ -86,7 +80,7 @@ AMSM_GEOM_FN u32 window_exponent_of(u32 c, u32 W, u32 n_narrow, u32 top_shift, u
 AMSM_GEOM_FN u32 window_exponent(const MsmGeom& g, u32 w) { return window_exponent_of(g.c, g.W, g.n_narrow, g.top_shift, w); }
 // the parameters of the signed-digit walk (vec_kernels.h: digit_step), as every kernel that walks scalars receives them
 struct DigitWalk {
-  u32 c, W, n_narrow, top_shift, radix_m, radix_k, radix_magic;
+  u32 c, W, n_narrow, top_shift;
 };
 AMSM_GEOM_FN DigitWalk digit_walk_of(const MsmGeom& g) {
   DigitWalk d;
@@ -94,9 +88,6 @@ AMSM_GEOM_FN DigitWalk digit_walk_of(const MsmGeom& g) {
   d.W = g.W;
   d.n_narrow = g.n_narrow;
   d.top_shift = g.top_shift;
-  d.radix_m = g.radix_m;
-  d.radix_k = g.radix_k;
-  d.radix_magic = g.radix_magic;
   return d;
 }
 // narrow windows a width-c walk over 256 bits needs (0 when the widths divide evenly; ~0u when c - 1 is not narrow enough)
@@ -122,9 +113,6 @@ struct CombineArgs {
   const u32* vec[VEC_MAX];
   u32 len[VEC_MAX];
   u32 coeff[VEC_MAX][8];
-  // filled by the launcher for the 9 x 29-limb kernel (vec_kernels.h): coefficient * 32 mod r (a product there divides by 2^261
-  // instead of 2^256)
-  u32 coeff_u[VEC_MAX][8];
   const u32* hiding;
   u32 hiding_len;
   u32 n_vecs;

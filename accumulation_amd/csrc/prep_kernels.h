@@ -681,9 +681,6 @@ __global__ void __launch_bounds__(1024)
   const u32 total = gb[NG];
   const bool ok = fits && total <= stride;
   if (!ok && t == 0) atomicOr(err + 1, 1u);  // overflow: the host falls back to the chunked pipeline
-#ifdef AMSM_PREP_DEBUG
-  if (!ok && t == 0) printf("[k_prep_local_t] partition %u: %u entries (FIX %u CAP %u), padded %u of stride %u, rows %u .. %u\n", p, n_p, pg.FIX, pg.CAP, total, stride, gm[0], gm[NG - 1u]);
-#endif
   if (t < NG) {
     BplGroup h;
     h.base = p * stride + gb[t];

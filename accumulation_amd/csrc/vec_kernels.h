@@ -18,40 +18,8 @@ namespace amsm {
 // recoding's carry for the next window and shifts s.  Window w is c bits wide, or c - 1 (MsmGeom::n_narrow: the top windows,
 // digit doubled); the legacy short top window of a top_shift key is spread by its shift.  A scalar that does not fit the
 // windows (non-canonical: >= 2^255) leaves carry = 1 behind the last window -- the callers' `rest`.
-// Mixed radix (DigitWalk::radix_m > 0, round 4): the digit is s mod R, R = m 2^k, and s becomes s div R -- the low k bits, then a
-// division of the remaining 256-bit number by the small odd m, sixteen bits at a time from the top: the running remainder stays
-// below m, so every step divides a number below m 2^16 <= 2^21, for which q = mulhi(x, floor(2^32 / m) + 1) is exact (the
-// multiplier overshoots 2^32 / m by less than 2^-32 relative, x / m has a fractional part of at most (m - 1) / m).
 template <class Fr>
 AMSM_DEV u32 digit_step(Fe<Fr>& s, const DigitWalk& dw, u32 w, u32& carry, u32& neg) {
-  if (dw.radix_m) {  // uniform over the grid
-    const u32 k = dw.radix_k, m = dw.radix_m, mg = dw.radix_magic;
-    const u32 low = s.v[0] & ((1u << k) - 1u);
-#pragma unroll
-    for (int i = 0; i < 7; i++) s.v[i] = (s.v[i] >> k) | (s.v[i + 1] << (32 - k));
-    s.v[7] >>= k;
-    u32 rem = 0;
-#pragma unroll
-    for (int i = 7; i >= 0; i--) {
-      const u32 x1 = (rem << 16) | (s.v[i] >> 16);
-      const u32 q1 = __umulhi(x1, mg);
-      const u32 r1 = x1 - q1 * m;
-      const u32 x2 = (r1 << 16) | (s.v[i] & 0xffffu);
-      const u32 q2 = __umulhi(x2, mg);
-      rem = x2 - q2 * m;
-      s.v[i] = (q1 << 16) | q2;
-    }
-    const u32 raw = (rem << k) + low + carry, R = m << k;
-    neg = 0;
-    carry = 0;
-    u32 d = raw;
-    if (raw > (R >> 1)) {
-      d = R - raw;
-      neg = 1;
-      carry = 1;
-    }
-    return d;
-  }
   const u32 c = dw.c, W = dw.W;
   const u32 narrow = (w + dw.n_narrow >= W) ? 1u : 0u;  // uniform over the grid
   const u32 cw = c - narrow;
@@ -276,94 +244,6 @@ __global__ void __launch_bounds__(256) k_hp_t_vecs(TVecArgs a) {
     ha = ha2;
     hb = hb2;
     li = nx;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Round 3: the linear combination with ARBITRARY coefficients on the unsaturated 9 x 29-limb multiplier (fpu.h: PallasFrU /
-// Bls12381FrU; constant-add reduction step, one MAD per limb product, no carries) with the sum of products reduced ONCE (u_dot:
-// up to four products per Montgomery reduction).  Memory keeps ark-ff's format (Montgomery radix 2^256): a product here divides
-// by 2^261, so it carries a factor 1/32, which the launcher folds into the uniform coefficients with host field arithmetic.
-// Bounds (cap = 2^261 > 70 r): canonical operands < r; a product of A and B is < r + A B / 2^261; what is stored is
-// canonicalised from < 8 r.  Measured at 2^22 elements (profiles/r03_vec_unsat_ab.md): n = 2 0.53 -> 0.60 of 8 TB/s, n = 3
-// 0.49 -> 0.63.  The same treatment LOST for the Hadamard product (0.80 -> 0.785), for combinations whose first coefficient is
-// one (0.775 -> 0.70 at n = 2: one product left, nothing to share) and for compute_t_vecs (register pressure: 0.49 -> 0.43 with
-// the prefetch, 0.49 without), so those stay on the generated 8 x 32 schedule.  AMSM_VEC_SAT=1 puts everything there (A/B).
-// ---------------------------------------------------------------------------------------------
-template <class Fr>
-struct FrUnsat;
-template <>
-struct FrUnsat<PallasFr> {
-  using type = PallasFrU;
-};
-template <>
-struct FrUnsat<Bls12381Fr> {
-  using type = Bls12381FrU;
-};
-template <class U>
-AMSM_DEV Fe<U> fru_load(const u32* __restrict__ p) {  // canonical Montgomery element (8 words) -> 9 tight limbs
-  Fe<typename U::Sat> w = fe_load<typename U::Sat>(p);
-  return u_unpack<U>(w.v);
-}
-template <class U>
-AMSM_DEV Fe<U> fru_zero() {
-  Fe<U> r;
-#pragma unroll
-  for (int i = 0; i < U::L; i++) r.v[i] = 0;
-  return r;
-}
-template <class U>
-AMSM_DEV Fe<U> fru_arg(const u32 c[8]) {  // a kernel-argument element
-  return u_unpack<U>(c);
-}
-template <class U, u32 KMAX, bool NT>
-AMSM_DEV void fru_store(u32* __restrict__ p, Fe<U> a) {  // a tight, value < KMAX * r
-  u_canon<U, KMAX>(a);
-  Fe<typename U::Sat> w;
-  u_pack<U>(a, w.v);
-  if (NT) fe_store_nt<typename U::Sat>(p, w);
-  else fe_store<typename U::Sat>(p, w);
-}
-
-// sum_{t < NP} pa[t] pb[t] / 2^261, four products per reduction; NP compile time.  Each group is < r + (sum A B) / 2^261.
-template <class U, int NP, int G = 0>
-AMSM_DEV void fru_dot_acc(Fe<U>& acc, const Fe<U>* pa, const Fe<U>* pb) {
-  if constexpr (G < NP) {
-    constexpr int K = NP - G < 4 ? NP - G : 4;
-    acc = u_add<U>(acc, u_dot<U, K>(pa + G, pb + G));
-    fru_dot_acc<U, NP, G + 4>(acc, pa, pb);
-  }
-}
-
-template <class Fr, int NV>
-__global__ void __launch_bounds__(256) k_vec_combine_u(CombineArgs a, u32* __restrict__ out) {
-  using U = typename FrUnsat<Fr>::type;
-  const u32 stride = gridDim.x * blockDim.x;
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  auto load = [&](u32 e, Fe<U>* x, Fe<U>& h) {
-#pragma unroll
-    for (int j = 0; j < NV; j++) x[j] = e < a.len[j] ? fru_load<U>(a.vec[j] + (size_t)e * 8) : fru_zero<U>();
-    h = (a.hiding && e < a.hiding_len) ? fru_load<U>(a.hiding + (size_t)e * 8) : fru_zero<U>();
-  };
-  Fe<U> cf[NV];
-#pragma unroll
-  for (int j = 0; j < NV; j++) cf[j] = fru_arg<U>(a.coeff_u[j]);  // 32 c_j mod r
-  Fe<U> x[NV], acc;
-  load(i, x, acc);
-  for (;;) {
-    const u32 nx = i + stride;
-    const bool more = nx < a.n;
-    Fe<U> x2[NV], h2;
-    if (more) load(nx, x2, h2);
-    fru_dot_acc<U, NV>(acc, cf, x);                                            // hiding + two reduced sums at most  [< 4.2 r]
-    if (a.hiding == out) fru_store<U, 8, false>(out + (size_t)i * 8, acc);    // (in-place chunked combination re-reads `out`)
-    else fru_store<U, 8, true>(out + (size_t)i * 8, acc);
-    if (!more) break;
-#pragma unroll
-    for (int j = 0; j < NV; j++) x[j] = x2[j];
-    acc = h2;
-    i = nx;
   }
 }
 

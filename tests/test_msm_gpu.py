@@ -430,104 +430,60 @@ def test_randomized_geometry_stress(ctxs, cref):
         ctx.set_window(0)
 
 
-@pytest.mark.parametrize("k0", ["4", "8", "20", "64"])
-def test_chunk_length_override(cref, k0):
-    """AMSM_K0 (entries per accumulate-L0 lane) only changes the work split, never the result."""
-    import os
-    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
-    c = o.PALLAS
-    old = os.environ.get("AMSM_K0")
-    os.environ["AMSM_K0"] = k0
-    try:
-        ctx = Context(c.curve_id)
-        n = 5000
-        xy = cref.rng_points(c.curve_id, 1, n)
-        sc = cref.rng_scalars(2, n)
-        ref, rinf = cref.msm(c.curve_id, xy, sc, threads=4)
-        for flags in (1, 2):
-            ck = CommitterKey.load(ctx, xy, None, flags)
-            out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
-            assert oinf == rinf and np.array_equal(out, ref), (k0, flags)
-            ck.free()
-        ctx.close()
-    finally:
-        if old is None:
-            os.environ.pop("AMSM_K0", None)
-        else:
-            os.environ["AMSM_K0"] = old
-
-
-@pytest.mark.parametrize("prep", ["rocprim", "custom"])
-def test_top_of_field_scalars(cref, prep):
+def test_top_of_field_scalars(cref):
     """Window widths that divide the 255-bit scalar width (3, 5, 15, 17) leave the top window holding only the carry
     of the signed recoding.  Scalars at and around the top of the field (r - 1, r - 2, 2^254 + k, all-ones low windows
-    so that the carry reaches the top) must match the CPU oracle, with both prep chains and both key kinds."""
-    import os
+    so that the carry reaches the top) must match the CPU oracle, with both prep chains (windows below 8 bits take the rocPRIM
+    sort, the others the short chain of prep_kernels.h) and both key kinds."""
     from accumulation_amd import CommitterKey, Context, VariableBaseMSM
     c = o.PALLAS
-    old = os.environ.get("AMSM_PREP")
-    os.environ["AMSM_PREP"] = prep
+    ctx = Context(c.curve_id)
+    n = 600
+    xy = cref.rng_points(c.curve_id, 21, n)
+    special = [c.r - 1, c.r - 2, 1 << 254, (1 << 254) + 1, (1 << 254) - 1, c.r - (1 << 237), (1 << 254) + (1 << 253) % 1,
+               c.r - 1 - (1 << 16), (1 << 238) - 1, (1 << 239) - 1, 0, 1]
+    ints = [special[i % len(special)] if i % 3 == 0 else o.rng_scalar(22, i) % c.r for i in range(n)]
+    sc = h.scalars_to_np(ints)
+    ref, rinf = cref.msm(c.curve_id, xy, sc, threads=4)
     try:
-        ctx = Context(c.curve_id)
-        n = 600
-        xy = cref.rng_points(c.curve_id, 21, n)
-        special = [c.r - 1, c.r - 2, 1 << 254, (1 << 254) + 1, (1 << 254) - 1, c.r - (1 << 237), (1 << 254) + (1 << 253) % 1,
-                   c.r - 1 - (1 << 16), (1 << 238) - 1, (1 << 239) - 1, 0, 1]
-        ints = [special[i % len(special)] if i % 3 == 0 else o.rng_scalar(22, i) % c.r for i in range(n)]
-        sc = h.scalars_to_np(ints)
-        ref, rinf = cref.msm(c.curve_id, xy, sc, threads=4)
-        try:
-            for w in (3, 5, 15, 17, 16):
-                ctx.set_window(w)
-                for flags in (1, 2):
-                    ck = CommitterKey.load(ctx, xy, None, flags)
-                    out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
-                    assert oinf == rinf and np.array_equal(out, ref), (prep, w, flags)
-                    ck.free()
-        finally:
-            ctx.set_window(0)
-        ctx.close()
+        for w in (3, 5, 15, 17, 16):
+            ctx.set_window(w)
+            for flags in (1, 2):
+                ck = CommitterKey.load(ctx, xy, None, flags)
+                out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
+                assert oinf == rinf and np.array_equal(out, ref), (w, flags)
+                ck.free()
     finally:
-        if old is None:
-            os.environ.pop("AMSM_PREP", None)
-        else:
-            os.environ["AMSM_PREP"] = old
+        ctx.set_window(0)
+    ctx.close()
 
 
-@pytest.mark.parametrize("prep", ["rocprim", "custom"])
-def test_prep_chain_variants_agree(cref, prep):
-    """The custom prep chain (prep_kernels.h) and its fallback (digits + rocPRIM sort + bounds + scan) feed
-    accumulate L0 the same buckets: both must reproduce the CPU oracle on uniform, all-equal and sparse scalars, with
-    precomputed and plain keys, on both curves."""
-    import os
+@pytest.mark.parametrize("window", [0, 5, 7], ids=["short_chain", "rocprim_5_bit", "rocprim_7_bit"])
+def test_prep_chain_variants_agree(cref, window):
+    """The short prep chain (prep_kernels.h) and its fallback for windows below 8 bits (digits + rocPRIM sort + bounds + scan: what
+    plain keys of up to 2^8 pairs and narrow window overrides take) feed accumulate L0 the same buckets: both must reproduce the
+    CPU oracle on uniform, all-equal and sparse scalars, with precomputed and plain keys, on both curves."""
     from accumulation_amd import CommitterKey, Context, VariableBaseMSM
-    old = os.environ.get("AMSM_PREP")
-    os.environ["AMSM_PREP"] = prep
-    try:
-        for c in (o.PALLAS, o.BLS12_381_G1):
-            ctx = Context(c.curve_id)
-            n = 6001
-            xy = cref.rng_points(c.curve_id, 11, n)
-            cases = {"uniform": cref.rng_scalars(12, n)}
-            eq = cases["uniform"].copy()
-            eq[:] = eq[0]
-            cases["all_equal"] = eq
-            sp = np.zeros_like(cases["uniform"])
-            sp[::97] = cases["uniform"][::97]
-            cases["sparse"] = sp
-            for name, sc in cases.items():
-                ref, rinf = cref.msm(c.curve_id, xy, sc, threads=4)
-                for flags in (1, 2):
-                    ck = CommitterKey.load(ctx, xy, None, flags)
-                    out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
-                    assert oinf == rinf and np.array_equal(out, ref), (prep, c.name, name, flags)
-                    ck.free()
-            ctx.close()
-    finally:
-        if old is None:
-            os.environ.pop("AMSM_PREP", None)
-        else:
-            os.environ["AMSM_PREP"] = old
+    for c in (o.PALLAS, o.BLS12_381_G1):
+        ctx = Context(c.curve_id)
+        ctx.set_window(window)
+        n = 6001
+        xy = cref.rng_points(c.curve_id, 11, n)
+        cases = {"uniform": cref.rng_scalars(12, n)}
+        eq = cases["uniform"].copy()
+        eq[:] = eq[0]
+        cases["all_equal"] = eq
+        sp = np.zeros_like(cases["uniform"])
+        sp[::97] = cases["uniform"][::97]
+        cases["sparse"] = sp
+        for name, sc in cases.items():
+            ref, rinf = cref.msm(c.curve_id, xy, sc, threads=4)
+            for flags in (1, 2):
+                ck = CommitterKey.load(ctx, xy, None, flags)
+                out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
+                assert oinf == rinf and np.array_equal(out, ref), (window, c.name, name, flags)
+                ck.free()
+        ctx.close()
 
 
 @pytest.mark.parametrize("log2n", [18, 20])

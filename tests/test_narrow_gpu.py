@@ -185,15 +185,14 @@ def test_grouped_msm(cref, c, kind):
         ctx.close()
 
 
-def test_round3_tables_still_work(cref):
-    """AMSM_NARROW=0: round 3's 20-bit table (a 15-bit top window spread by top_shift) and AMSM_BPL_PLAIN=0: plain keys on the
-    chunked pipeline -- the same points"""
+def test_plain_key_switch_gives_the_same_points(cref):
+    """AMSM_BPL_PLAIN=0 (a documented switch, include/amsm.h): plain keys on the chunked pipeline -- the same points"""
     from accumulation_amd import CommitterKey, Context, VariableBaseMSM
     c = o.PALLAS
     n = 1 << 20
     sc = cref.rng_scalars(0xAA00, n)
     res = []
-    for env in ({}, {"AMSM_NARROW": "0"}, {"AMSM_BPL_PLAIN": "0"}):
+    for env in ({}, {"AMSM_BPL_PLAIN": "0"}):
         os.environ.update(env)
         try:
             ctx = Context(c.curve_id)
@@ -226,7 +225,6 @@ def test_fold_of_a_narrow_key_through_its_window_multiples(cref):
         assert ck.precomputed and ck.window_bits == 20
         xy, inf = ck.read()
         plain = CommitterKey.load(ctx, xy, inf, PLAIN)
-        os.environ["AMSM_GLV"] = "0"  # (read once per process by the fold launcher: only effective if nothing folded before)
         for x, nbits in ((o.rng_scalar(0xAB00, 0) % (1 << 128), 128), (o.rng_scalar(0xAB00, 1) % c.r, 255), (c.r - 1, 255),
                          ((1 << 199) + (1 << 180) - 1, 255)):
             a = ck.fold(n_half, fr.to_limbs(x), nbits)
@@ -239,7 +237,6 @@ def test_fold_of_a_narrow_key_through_its_window_multiples(cref):
                 assert h.np_to_point(c, ga[i], bool(ia[i])) == o.add(c, P, o.mul(c, x % (1 << nbits), Q))
             a.free()
             b.free()
-        del os.environ["AMSM_GLV"]
         plain.free()
         ck.free()
     finally:

@@ -1,7 +1,8 @@
-"""A/B of pipeline knobs in ONE process (run-to-run noise between processes is ~5-10 %): each configuration is a
-fresh Context created under its environment overrides; configurations are measured round-robin.
+"""A/B of the library's documented switches (include/amsm.h "Environment") in ONE process: each configuration is a fresh Context
+created under its environment overrides; configurations are measured round-robin.  (A second context of a process gets other
+hardware queues than the first -- compare like positions, or use one process per configuration as tools/ab_share.py does.)
 
-    python tools/ab_pipeline.py "AMSM_K0=44" "AMSM_K0=32" "AMSM_L0_LDS_PAD=40000" ...
+    python tools/ab_pipeline.py "" "AMSM_BPL=0" "AMSM_SHARE_BUCKETS=0" ...
 """
 import os
 import sys

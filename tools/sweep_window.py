@@ -6,8 +6,8 @@ import sys as _s
 for log2n in [int(x) for x in _s.argv[1:]]:
     n = 1 << log2n
     for c in range(max(8, log2n - 6), min(21, log2n + 1)):
-        os.environ["AMSM_WINDOW"] = str(c)
         ctx = Context(ffi.AMSM_PALLAS)
+        ctx.set_window(c)  # (key creation and every MSM take this width: amsm_ctx_set_window)
         ck = CommitterKey.generate(ctx, 7, n, ffi.AMSM_BASES_PRECOMPUTE)
         vecs = [ctx.random_vector(100 + j, n, mont=False) for j in range(4)]
         VariableBaseMSM.multi_scalar_mul_batch(ck, vecs, mont=False)
