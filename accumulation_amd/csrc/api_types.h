@@ -204,6 +204,10 @@ struct amsm_ctx {
   bool shared_used[2] = {false, false};
   unsigned shared_rr = 0;
   unsigned long long n_shared = 0;  // long MSMs that ran over one bucket set
+  // the OPTIONAL tables of a key (the 512-points-per-generator direct-sum table, the 17-bit twin) are a decision, not a side effect
+  // (round 5): bytes one key may spend on them (amsm_ctx_set_table_budget; default: no limit) and how often one was denied
+  size_t table_budget = ~(size_t)0;
+  unsigned long long n_tables_denied = 0;
   bool profiling = false;
   float stage_ms[ST_COUNT] = {};  // mean over the MSMs of the last call
   float stage_acc[ST_COUNT] = {};
@@ -277,6 +281,9 @@ struct amsm_bases {
   // small keys (round 4): j 2^(4 w) G_i for j = 1 .. 8, w = 0 .. 63 at [((j - 1) 64 + w) n + i] -- every MSM over such a key that is
   // not grouped is a plain sum of table points (msm_kernels.h k_direct_sum); null: none
   u32* d_small = nullptr;
+  int direct_denied = 0;          // why a small key has no such table (api_keys.inc: TableDenied); 0: it has one, or never qualified
+  bool no_twin = false;           // AMSM_BASES_NO_TWIN
+  mutable int twin_denied = 0;    // a call needed the twin and was refused (flag / budget)
   mutable amsm_bases* alt = nullptr;
   mutable std::mutex alt_mu;
   // sharded key of a multi-device context: shard g (a single-device key on shard_ctx[g]'s device) holds generators

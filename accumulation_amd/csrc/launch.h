@@ -49,10 +49,10 @@ void launch_precompute_level(hipStream_t st, u32* table, u32 stride, u32 level, 
 template <class Fq>
 void launch_precompute_all_levels(hipStream_t st, u32* table, u32 n, u32 c, u32 W, u32* xyzz_scratch);
 // Direct sum (msm_kernels.h k_direct_sum): the 512-points-per-generator table of a small key from its window table (W levels of
-// plain c-bit windows, device radix; xyzz_scratch: 512 n records), and one MSM as cdiv(n * 64 / m, 256) partial records
-// (returned) for launch_fold_quad
+// plain c-bit windows, device radix), built in slabs of `slab_windows` of its 64 four-bit windows (xyzz_scratch: 8 * slab_windows * n
+// records), and one MSM as cdiv(n * 64 / m, 256) partial records (returned) for launch_fold_quad
 template <class Fq>
-void launch_ds_table(hipStream_t st, const u32* win_table, u32 n, u32 c, u32 W, u32* xyzz_scratch, u32* table);
+void launch_ds_table(hipStream_t st, const u32* win_table, u32 n, u32 c, u32 W, u32* xyzz_scratch, u32 slab_windows, u32* table);
 // nv <= DS_BATCH MSMs over the key in one launch: MSM v's `blocks` records (the return value, sized by the longest vector) at
 // partials[v * blocks ...].  group_shift >= 0 (nv = 1): two sums by that bit of the scalar's index (n a multiple of
 // 2 << group_shift): class c's `blocks` records are partials[c * blocks ...]

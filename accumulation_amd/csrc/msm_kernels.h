@@ -663,11 +663,13 @@ __global__ void __launch_bounds__(256) k_tv_sum(const u32* __restrict__ table, T
 // the canonical scalars of both fields; anything above is reported like a scalar that does not fit the other pipelines' windows).
 // level w = 2^(4 w) G from the key's WINDOW table (levels 2^(c l) G, plain c-bit windows): the level at or below bit 4 w, then
 // at most c - 1 doublings -- every (w, i) on its own lane (a chain of 252 doublings per generator from the generators alone)
+// (windows [w0, w0 + wn) of the 64: the table is built in slabs so that the XYZZ scratch stays bounded, round 5)
 template <class Fq>
-__global__ void __launch_bounds__(256) k_ds_levels(const u32* __restrict__ win_table, u32 n, u32 c, u32 W, u32* __restrict__ xyzz_out) {
+__global__ void __launch_bounds__(256)
+    k_ds_levels(const u32* __restrict__ win_table, u32 n, u32 c, u32 W, u32 w0, u32 wn, u32* __restrict__ xyzz_out) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * DS_W) return;
-  const u32 w = t / n, i = t - w * n;
+  if (t >= n * wn) return;
+  const u32 w = w0 + t / n, i = t % n;
   u32 l = (4u * w) / c;
   if (l >= W) l = W - 1u;
   const u32 dbl = 4u * w - c * l;

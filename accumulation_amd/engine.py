@@ -90,6 +90,13 @@ class Context:
         ffi.check(self._lib.amsm_ctx_memory(self._h, C.byref(ws), C.byref(live), C.byref(pooled)), "amsm_ctx_memory")
         return {"workspace_bytes": ws.value, "vectors_live_bytes": live.value, "vectors_pooled_bytes": pooled.value}
 
+    def set_table_budget(self, nbytes: int) -> None:
+        """bytes ONE key may spend on each of its optional tables (direct-sum table, twin): amsm_ctx_set_table_budget"""
+        ffi.check(self._lib.amsm_ctx_set_table_budget(self._h, nbytes), "amsm_ctx_set_table_budget")
+
+    def tables_denied(self) -> int:
+        return int(self._lib.amsm_ctx_tables_denied(self._h))
+
     def two_valued_msms(self) -> int:
         """MSMs of device vectors that took the two-valued form (every scalar 0 or one value v) so far"""
         return int(self._lib.amsm_ctx_two_valued_msms(self._h))
@@ -393,6 +400,14 @@ class CommitterKey:
         t, a, w = C.c_size_t(), C.c_size_t(), C.c_size_t()
         ffi.check(self.ctx._lib.amsm_bases_memory(self._h, C.byref(t), C.byref(a), C.byref(w)), "amsm_bases_memory")
         return {"table": t.value, "abi_copy": a.value, "twin": w.value}
+
+    def tables(self) -> dict:
+        """which tables the key holds, one by one, and why an optional one is missing (amsm_bases_tables)"""
+        out = (C.c_size_t * 7)()
+        ffi.check(self.ctx._lib.amsm_bases_tables(self._h, out), "amsm_bases_tables")
+        why = {0: None, 1: "flag", 2: "budget", 3: "allocation failed"}
+        return {"window_table": out[0], "direct_sum_table": out[1], "twin": out[2], "abi_copy": out[3], "levels": out[4],
+                "direct_sum_table_denied": why[out[5]], "twin_denied": why[out[6]]}
 
     def prebuild_twin(self) -> None:
         ffi.check(self.ctx._lib.amsm_bases_prebuild_twin(self.ctx._h, self._h), "amsm_bases_prebuild_twin")

@@ -31,6 +31,8 @@ AMSM_DEVICE_HOST = -1
 AMSM_BASES_DEFAULT = 0
 AMSM_BASES_PRECOMPUTE = 1
 AMSM_BASES_NO_PRECOMPUTE = 2
+AMSM_BASES_NO_DIRECT_TABLE = 4
+AMSM_BASES_NO_TWIN = 8
 
 _vp = C.c_void_p
 _u64p = C.POINTER(C.c_uint64)
@@ -99,6 +101,9 @@ SIGNATURES = {
     "amsm_fr_from_mont": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "amsm_bases_memory": (C.c_int, [_vp, _vp, _vp, _vp]),
     "amsm_bases_prebuild_twin": (C.c_int, [_vp, _vp]),
+    "amsm_bases_tables": (C.c_int, [_vp, _vp]),
+    "amsm_ctx_set_table_budget": (C.c_int, [_vp, _sz]),
+    "amsm_ctx_tables_denied": (C.c_ulonglong, [_vp]),
     "amsm_host_register": (C.c_int, [_vp, _sz]),
     "amsm_host_unregister": (C.c_int, [_vp]),
     "amsm_host_is_pinned": (C.c_int, [_vp]),

@@ -530,7 +530,10 @@ def key_bytes(ck, ctx, n):
     c = int(ck.window_bits)
     levels = (255 // c + 1) if (ck.precomputed and c) else 1
     m = ck.memory()
-    return {"table": m["table"], "levels": levels, "twin_17_bit_table": m["twin"]}
+    t = ck.tables()
+    return {"table": m["table"], "levels": levels, "twin_17_bit_table": m["twin"], "window_table": t["window_table"],
+            "direct_sum_table": t["direct_sum_table"], "direct_sum_table_denied": t["direct_sum_table_denied"],
+            "twin_denied": t["twin_denied"], "tables_denied_on_context": ctx.tables_denied()}
 
 
 def source_hash():

@@ -70,7 +70,14 @@ enum amsm_bases_flags {
   AMSM_BASES_PRECOMPUTE = 1,   /* keep 2^(c*w)*G_i for every window w resident in HBM (W x memory); creation fails with
                                   AMSM_E_OOM / AMSM_E_UNSUPPORTED (n * W >= 2^30) when the table cannot be built --
                                   only AMSM_BASES_DEFAULT falls back to a plain key (amsm_bases_precomputed() tells) */
-  AMSM_BASES_NO_PRECOMPUTE = 2 /* one copy of the key; windows are combined on the host */
+  AMSM_BASES_NO_PRECOMPUTE = 2, /* one copy of the key; windows are combined on the host */
+  /* Round 5 -- the OPTIONAL tables are the caller's decision (OR them into any of the above):
+   *   a precomputed key of up to 2^15 generators also holds 512 affine points per generator (32 KiB each: 1.07 GB for 2^15 Pallas
+   *   generators, 1.6 GB BLS12-381) from which its MSMs are summed without buckets (2-4x faster there);
+   *   a key with the 20-bit table (>= 2^20 generators) builds a 17-bit TWIN of about the same size (1 GiB at 2^20) on the first
+   *   call that needs it -- a range below a quarter of 2^20 pairs, a vector with skewed digits. */
+  AMSM_BASES_NO_DIRECT_TABLE = 4, /* never build the direct-sum table: such a key's MSMs take the windowed pipelines */
+  AMSM_BASES_NO_TWIN = 8          /* never build the twin: the calls that would need it return AMSM_E_UNSUPPORTED */
 };
 
 const char* amsm_strerror(int status);
@@ -162,6 +169,19 @@ int amsm_ctx_trim(amsm_ctx* ctx);
  * Sharded keys report the sum over their shards. */
 int amsm_bases_memory(const amsm_bases* bases, size_t* table_bytes, size_t* abi_copy_bytes, size_t* twin_bytes);
 int amsm_bases_prebuild_twin(amsm_ctx* ctx, const amsm_bases* bases);
+/* Which tables a key holds, one by one (round 5).  out[0] = the window table (W levels of affine points; the generators alone for a
+ * plain key), out[1] = the direct-sum table (0: none), out[2] = the twin (0: not built), out[3] = the C-ABI-radix copy, out[4] = W,
+ * out[5] = why there is no direct-sum table although the key qualified: 0 (there is one / it never qualified), 1
+ * AMSM_BASES_NO_DIRECT_TABLE, 2 the context's table budget, 3 the allocation failed; out[6] = the same for the twin when a call was
+ * refused one.  Sharded keys: sums over the shards, the largest reason code. */
+int amsm_bases_tables(const amsm_bases* bases, size_t out[7]);
+/* Bytes ONE key may spend on its optional tables (each table separately; default: no limit).  Keys created afterwards obey it; a
+ * table that does not fit is not built (direct sum) or refused (twin: AMSM_E_UNSUPPORTED from the call that needs it), and
+ * amsm_ctx_tables_denied counts it.  Eight ranks of a node each hold their own tables: budget accordingly. */
+int amsm_ctx_set_table_budget(amsm_ctx* ctx, size_t bytes_per_table);
+/* Tables denied so far by the budget or by a failed allocation (not by the caller's own flags): a key that silently stays on the
+ * 2-4x slower path is visible here. */
+unsigned long long amsm_ctx_tables_denied(const amsm_ctx* ctx);
 
 /* Per-stage device timings of the LAST msm call (hipEvent pairs on the context's stream).
  * Enable with on != 0; stage names: amsm_stage_name(i), i in [0, amsm_stage_count()). */

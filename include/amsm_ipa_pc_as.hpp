@@ -11,7 +11,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <exception>
 #include <future>
+#include <mutex>
 
 #include "amsm_hp_as.hpp"
 
@@ -570,14 +573,32 @@ class AtomicASForInnerProductArgPC {
     std::vector<const InputInstance*> all;
     for (auto& x : ins) all.push_back(&x);
     for (auto& x : olds) all.push_back(&x);
-    std::vector<std::future<std::optional<ipa_pc::SuccinctCheckPolynomial>>> futs;
+    // Ipa::succinct_check is host-only (sponge + amsm_host_lincomb: no device call, nothing of the context is written), so the
+    // checks may run side by side -- on at most as many threads as the host pool would use (one per instance was unbounded and
+    // oversubscribed a node's ranks: ADVICE r4); an exception of a worker surfaces only after every worker has finished
     auto one = [&ctx, &svk](const InputInstance* inst) {
       return Ipa::succinct_check(ctx, svk, inst->ipa_commitment, inst->point, inst->evaluation, inst->ipa_proof);
     };
-    for (size_t k = 1; k < all.size(); k++) futs.push_back(std::async(std::launch::async, one, all[k]));
-    std::vector<std::optional<ipa_pc::SuccinctCheckPolynomial>> cps;
-    if (!all.empty()) cps.push_back(one(all[0]));  // (the caller's thread takes the first)
-    for (auto& f : futs) cps.push_back(f.get());
+    std::vector<std::optional<ipa_pc::SuccinctCheckPolynomial>> cps(all.size());
+    const size_t n_workers = std::min<size_t>(all.size(), (size_t)amsm_host_threads() + 1);
+    std::atomic<size_t> next{0};
+    std::exception_ptr failure;
+    std::mutex failure_mu;
+    auto loop = [&] {
+      for (size_t k; (k = next.fetch_add(1)) < all.size();) {
+        try {
+          cps[k] = one(all[k]);
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(failure_mu);
+          if (!failure) failure = std::current_exception();
+        }
+      }
+    };
+    std::vector<std::future<void>> futs;
+    for (size_t t = 1; t < n_workers; t++) futs.push_back(std::async(std::launch::async, loop));
+    loop();  // (the caller's thread works too)
+    for (auto& f : futs) f.get();
+    if (failure) std::rethrow_exception(failure);
     for (size_t k = 0; k < all.size(); k++) {
       if (!cps[k]) {
         if (k >= ins.size()) throw MalformedAccumulator("Succinct check failed on accumulator.");

@@ -46,21 +46,25 @@ def test_counters_follow_the_table(cref, gens, flags, cases):
         ctx.close()
 
 
-def test_grouped_and_long_forms(cref):
-    """grouped MSMs take the same rows; a long plain-key MSM is cut into 2^20-pair ranges; a short range of the 20-bit key runs over
-    its twin (bucket-split at 2^16 .. 2^17 pairs)"""
+def test_grouped_forms(cref):
+    """grouped MSMs (two sums by one bit of the index: the IPA rounds) take the same rows; a short range of the 20-bit key runs over
+    its twin; the two sums add up to the ungrouped MSM"""
     from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    from tests import helpers as h
     ctx = Context(C.curve_id)
     try:
-        ck = CommitterKey.generate(ctx, 0x5EED6002, P(20))
-        for n, want in ((P(19) + 2, "bucket_per_lane"), (P(17), "bucket_split"), (P(15), "chunked")):
-            v = ctx.random_vector(0x5EED6200 + n % 97, n, mont=True)
-            name, d, (got, ginf) = took(ctx, lambda: VariableBaseMSM.multi_scalar_mul_grouped(ck, v, 3, mont=True))
-            assert name == want, (n, d)
-            a, ai = VariableBaseMSM.multi_scalar_mul(ck, v, mont=True)
-            s = o.add(C, *[__import__("tests.helpers", fromlist=["x"]).np_to_point(C, got[g], bool(ginf[g])) for g in (0, 1)])
-            assert s == __import__("tests.helpers", fromlist=["x"]).np_to_point(C, a, bool(ai)), n
-        assert ck.memory()["twin"] > 0  # the short ranges built it
-        ck.free()
+        for gens, cases in ((P(16), [(P(16), "bucket_split"), (P(15), "chunked")]),
+                            (P(20), [(P(19) + 2, "bucket_per_lane"), (P(20), "bucket_per_lane"), (P(15), "chunked")])):
+            ck = CommitterKey.generate(ctx, 0x5EED6002, gens)
+            for n, want in cases:
+                v = ctx.random_vector(0x5EED6200 + n % 97, n, mont=True)
+                name, d, (got, ginf) = took(ctx, lambda: VariableBaseMSM.multi_scalar_mul_grouped(ck, v, 3, mont=True))
+                assert name == want, (gens, n, d)
+                a, ai = VariableBaseMSM.multi_scalar_mul(ck, v, mont=True)
+                s = o.add(C, *[h.np_to_point(C, got[g], bool(ginf[g])) for g in (0, 1)])
+                assert s == h.np_to_point(C, a, bool(ai)), (gens, n)
+            if gens == P(20):
+                assert ck.tables()["twin"] > 0  # the short range built it
+            ck.free()
     finally:
         ctx.close()
