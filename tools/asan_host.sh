@@ -1,5 +1,6 @@
 #!/bin/bash
-# AddressSanitizer run of the library's HOST side (amsm_host_lincomb with its fixed-base cache, amsm_fr_*): the four
+# AddressSanitizer run of the library's HOST side (amsm_host_lincomb with its fixed-base cache, amsm_fr_*, and -- round 5 -- the whole
+# host backend behind the ABI: api_cpu.inc through tests/host_backend/): the four
 # translation units are compiled host-only (`--offload-host-only`, no device code, so no GPU ASAN / xnack is involved),
 # the device fat binaries they reference are stubbed, and tests/test_host_fr_cpu.py runs against that build.
 # Usage (from the repo root, CPU only): bash tools/asan_host.sh
@@ -25,7 +26,7 @@ sys.path.insert(0, "$R")
 import accumulation_amd.ffi as ffi
 ffi.LIB_PATH = "$D/libamsm_asan.so"
 import pytest
-sys.exit(pytest.main(["-x", "-q", "$R/tests/test_host_fr_cpu.py", "$R/tests/test_wire_format_cpu.py", "$R/tests/test_poseidon_cpu.py", "-p", "no:cacheprovider"]))
+sys.exit(pytest.main(["-x", "-q", "$R/tests/test_host_fr_cpu.py", "$R/tests/test_wire_format_cpu.py", "$R/tests/test_poseidon_cpu.py", "$R/tests/host_backend/test_host_context_cpu.py", "$R/tests/host_backend/test_host_msm_cpu.py", "$R/tests/host_backend/test_host_vec_cpu.py", "$R/tests/host_backend/test_host_ipa_cpu.py", "$R/tests/host_backend/test_host_hp_as_scheme_cpu.py", "$R/tests/host_backend/test_host_r1cs_nark_as_scheme_cpu.py", "-p", "no:cacheprovider"]))
 PY
 cd $R
 ASAN_LIB=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)

@@ -9,5 +9,5 @@ bash tools/profile_extra.sh > gpurun_out/profile_extra.log 2>&1
 python3 tools/bench_configs.py > gpurun_out/bench_configs.jsonl 2> gpurun_out/bench_configs.err
 bash tools/scheme_trace.sh > gpurun_out/scheme_trace.log 2>&1
 bash tools/small_trace.sh > gpurun_out/small_trace.log 2>&1
-python3 tools/ab_mid_sizes.py > gpurun_out/mid_sizes.log 2>&1
+python3 tools/mid_sizes.py > gpurun_out/mid_sizes.log 2>&1
 tail -c 400 gpurun_out/profile_round.log

@@ -1,5 +1,5 @@
 #!/bin/bash
-# ThreadSanitizer run of the library's HOST side (the host thread pool behind amsm_host_lincomb[_batch]): same host-only build as
+# ThreadSanitizer run of the library's HOST side (the host thread pool behind amsm_host_lincomb[_batch] and the host backend's parallel loops): same host-only build as
 # tools/asan_host.sh with -fsanitize=thread; tests/test_host_fr_cpu.py runs against it.  Usage (repo root, CPU only): bash tools/tsan_host.sh
 set -eu
 R=$(pwd)
@@ -23,7 +23,7 @@ sys.path.insert(0, "$R")
 import accumulation_amd.ffi as ffi
 ffi.LIB_PATH = "$D/libamsm_tsan.so"
 import pytest
-sys.exit(pytest.main(["-x", "-q", "$R/tests/test_host_fr_cpu.py", "-p", "no:cacheprovider"]))
+sys.exit(pytest.main(["-x", "-q", "$R/tests/test_host_fr_cpu.py", "$R/tests/host_backend/test_host_context_cpu.py", "$R/tests/host_backend/test_host_msm_cpu.py", "$R/tests/host_backend/test_host_vec_cpu.py", "$R/tests/host_backend/test_host_ipa_cpu.py", "$R/tests/host_backend/test_host_hp_as_scheme_cpu.py", "$R/tests/host_backend/test_host_r1cs_nark_as_scheme_cpu.py", "-p", "no:cacheprovider"]))
 PY
 cd $R
 TSAN_LIB=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.tsan-x86_64.so)
