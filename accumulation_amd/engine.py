@@ -401,6 +401,11 @@ class CommitterKey:
         ffi.check(self.ctx._lib.amsm_bases_memory(self._h, C.byref(t), C.byref(a), C.byref(w)), "amsm_bases_memory")
         return {"table": t.value, "abi_copy": a.value, "twin": w.value}
 
+    @property
+    def num_shards(self) -> int:
+        """1, or the number of devices the key is sharded over (a key made through a MultiContext)"""
+        return int(self.ctx._lib.amsm_bases_num_shards(self._h))
+
     def tables(self) -> dict:
         """which tables the key holds, one by one, and why an optional one is missing (amsm_bases_tables)"""
         out = (C.c_size_t * 7)()

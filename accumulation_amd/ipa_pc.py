@@ -215,7 +215,8 @@ class InnerProductArgPC:
         key = ck.comm_key
         log_n = n.bit_length() - 1
         assert n == 1 << log_n
-        fold_rounds = cls._fold_rounds(ctx, log_n)
+        # (a key sharded over several devices is never folded: a fold pairs generator i with i + n/2, which live on different devices)
+        fold_rounds = 0 if key.num_shards > 1 else cls._fold_rounds(ctx, log_n)
         u_l = ctx.vector(n)
         xs: List[int] = []
         l_vec, r_vec = [], []

@@ -250,7 +250,9 @@ struct InnerProductArgPC {
     // does not depend on the choice.
     size_t log_n = 0;
     while (((size_t)1 << log_n) < n) log_n++;
-    const size_t n_fold = fold_rounds(amsm_ctx_curve(ctx.get()), log_n);
+    // (a key sharded over the devices of a multi-device context is never folded -- a fold pairs generator i with i + n/2, which
+    // live on different devices: every round is one grouped MSM over the original sharded key, amsm.h amsm_ctx_create_multi)
+    const size_t n_fold = amsm_bases_num_shards(key.get()) > 1 ? 0 : fold_rounds(amsm_ctx_curve(ctx.get()), log_n);
     FrVector u(ctx, n);
     std::vector<Fr> xs;
     Proof proof;

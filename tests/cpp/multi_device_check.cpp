@@ -184,12 +184,31 @@ int main(int argc, char** argv) {
     for (int g = 0; g < n_shards; g++)
       for (size_t v = 0; v < K; v++) CHECK(amsm_dev_free(amsm_ctx_shard(multi, g), owned[k++]));
   }
-  // (7) what does not shard says so instead of crashing (one shard = an ordinary key)
+  // (7) grouped MSMs over the sharded key (round 5: every shard sums its part of both index classes) against the single-device
+  // grouped MSM: group periods below, at and above a shard's length, ragged lengths and offsets (the shard slices then start
+  // off the group period: msm_grouped_partial's head / tail pieces)
+  {
+    unsigned top = 0;
+    while (((size_t)2 << top) < n) top++;
+    struct G {
+      size_t off, cnt;
+      unsigned shift;
+    } cases[] = {{0, n, 0}, {0, n, 3}, {0, n, top}, {0, n, top > 1 ? top - 1 : 0}, {0, n > 64 ? n - 5 : n, 2}, {n > 64 ? (size_t)7 : 0, n > 64 ? n - 20 : n, 4},
+                 {w_off, w_n, top > 2 ? top - 2 : 1}, {s_off, s_n, 1}};
+    for (const G& gc : cases) {
+      if (gc.off + gc.cnt > n) continue;
+      uint8_t i1[2] = {0, 0}, iN[2] = {0, 0};
+      std::vector<uint64_t> x1(2 * L2), xN(2 * L2);
+      CHECK(amsm_msm_grouped_device(one, key1, gc.off, d_v[0], gc.cnt, 1, gc.shift, x1.data(), i1));
+      CHECK(amsm_msm_grouped_device(multi, keyN, gc.off, d_p[0], gc.cnt, 1, gc.shift, xN.data(), iN));
+      EXPECT(x1 == xN && i1[0] == iN[0] && i1[1] == iN[1]);
+    }
+  }
+  // (7b) what does not shard says so instead of crashing (one shard = an ordinary key)
   if (n_shards > 1) {
-    uint8_t inf2[2];
-    std::vector<uint64_t> xy(2 * L2);
-    EXPECT(amsm_msm_grouped_device(multi, keyN, 0, d_p[0], n, 1, 3, xy.data(), inf2) == AMSM_E_UNSUPPORTED);
     EXPECT(amsm_bases_device_ptr(keyN) == nullptr);
+    amsm_bases* folded = nullptr;
+    EXPECT(amsm_bases_fold(multi, keyN, n / 2, rnd.data(), 128, &folded) == AMSM_E_UNSUPPORTED);
     // a sharded key does not work with a foreign context
     EXPECT(amsm_msm_device(one, keyN, 0, d_v[0], n, 1, got.xy.data(), &got.inf) == AMSM_E_INVALID_ARG);
   }
