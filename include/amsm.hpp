@@ -42,7 +42,13 @@ class Context {
   explicit Context(int curve = AMSM_PALLAS, int device = 0, void* stream = nullptr) {
     check(amsm_ctx_create(&h_, curve, device, stream), "amsm_ctx_create");
   }
+  // One context over several devices (amsm_ctx_create_multi): keys loaded through it are sharded, every MSM / commit / grouped
+  // MSM / IPA round runs on all of them with one exchange of partial sums.  An empty list = the host backend.
+  Context(int curve, const std::vector<int>& devices) {
+    check(amsm_ctx_create_multi(&h_, curve, devices.data(), (int)devices.size()), "amsm_ctx_create_multi");
+  }
   ~Context() { amsm_ctx_destroy(h_); }
+  int num_devices() const { return amsm_ctx_num_devices(h_); }
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   amsm_ctx* get() const { return h_; }

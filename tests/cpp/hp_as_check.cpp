@@ -102,7 +102,7 @@ static Accumulator run_template(Context& ctx, const CommitterKey& ck, const std:
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, check_device());
+    Context ctx = check_context(AMSM_PALLAS);
     CommitterKey ck = PedersenCommitment::setup(ctx, VECTOR_LEN, 4242);
     struct Scenario {
       const char* name;

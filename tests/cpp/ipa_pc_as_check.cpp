@@ -98,7 +98,7 @@ static void print_fr(const char* name, const Fr& canonical) {
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, check_device());
+    Context ctx = check_context(AMSM_PALLAS);
     ipa_pc::FrX fr(AMSM_PALLAS);
     ipa_pc::CommitterKey pp = Ipa::setup(ctx, DEGREE, 0xABCDEF);
     // the polynomial commitment alone: open / check round trip and its two rejections (tests/test_ipa_gpu.py)

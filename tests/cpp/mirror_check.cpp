@@ -16,7 +16,7 @@ static void print_point(const char* name, const Affine& p) {
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, check_device());
+    Context ctx = check_context(AMSM_PALLAS);
     const size_t n = 1000;
     CommitterKey ck = PedersenCommitment::setup(ctx, n, 0x5EED1001ull);
     printf("supported_num_elems %zu\n", ck.supported_num_elems());

@@ -204,6 +204,21 @@ int main(int argc, char** argv) {
       EXPECT(x1 == xN && i1[0] == iN[0] && i1[1] == iN[1]);
     }
   }
+  // (7a) multi-offset MSMs (the IPA cross commitments, trivial_pc's witness commitments): runs of jobs over one key range share
+  // an exchange; mixed offsets and lengths, an empty job in the middle
+  {
+    const size_t offs[5] = {0, 0, w_off, s_off, n > 64 ? (size_t)9 : 0};
+    const size_t lens[5] = {n, n, w_n, 0, n > 64 ? n - 30 : n};
+    const void* vecs[5] = {d_v[0], d_v[1], d_v[2], d_v[0], d_v[1]};
+    const void* vecsN[5] = {d_p[0], d_p[1], d_p[2], d_p[0], d_p[1]};
+    std::vector<uint64_t> x1(5 * L2), xN(5 * L2);
+    uint8_t i1[5], iN[5];
+    CHECK(amsm_msm_multi_device(one, key1, 5, offs, vecs, lens, 1, x1.data(), i1));
+    const uint64_t before = amsm_ctx_collectives(multi);
+    CHECK(amsm_msm_multi_device(multi, keyN, 5, offs, vecsN, lens, 1, xN.data(), iN));
+    EXPECT(x1 == xN && memcmp(i1, iN, 5) == 0 && iN[3] == 1);
+    EXPECT(n_shards == 1 || amsm_ctx_collectives(multi) - before <= 4);
+  }
   // (7b) what does not shard says so instead of crashing (one shard = an ordinary key)
   if (n_shards > 1) {
     EXPECT(amsm_bases_device_ptr(keyN) == nullptr);

@@ -98,7 +98,7 @@ static void print_point(const char* name, const Affine& p) {
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, check_device());
+    Context ctx = check_context(AMSM_PALLAS);
     const size_t n_inst = NUM_INPUTS + 1;
     const Fr one = {1, 0, 0, 0};
     std::vector<r1cs_nark::Matrix::Row> A, B, C;

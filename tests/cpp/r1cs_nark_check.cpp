@@ -51,7 +51,7 @@ static void print_fr(const char* name, const Fr& x) {
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, check_device());
+    Context ctx = check_context(AMSM_PALLAS);
     hp_as::FrOps fr{AMSM_PALLAS};
     const size_t num_inputs = 5, num_constraints = 100, n_inst = num_inputs + 1;
     const Fr one = {1, 0, 0, 0};

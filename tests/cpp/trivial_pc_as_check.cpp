@@ -88,7 +88,7 @@ static void print_words(const char* name, const uint64_t* w, size_t n, int flag)
 
 int main() {
   try {
-    Context ctx(AMSM_PALLAS, check_device());
+    Context ctx = check_context(AMSM_PALLAS);
     CommitterKey pp = TrivialPC::setup(ctx, DEGREE, 0x7121A1);
     struct Scenario {
       const char* name;

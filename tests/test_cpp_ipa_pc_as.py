@@ -88,6 +88,11 @@ def test_cpp_ipa_pc_as_template_and_python_cross_check(built_lib):
     host = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMSM_CHECK_DEVICE="-1"))
     assert host.returncode == 0, host.stdout + host.stderr
     assert host.stdout == gpu
+    # ... and so does a multi-device context of two and of five shards (include/amsm.hpp Context(curve, devices))
+    for shards in ("2", "5"):
+        many = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMSM_CHECK_SHARDS=shards))
+        assert many.returncode == 0, many.stdout + many.stderr
+        assert many.stdout == gpu, shards
 
 
 def test_cpp_ipa_pc_as_template_and_python_cross_check_on_the_host_backend(built_lib):

@@ -126,3 +126,15 @@ def test_cpp_driver_on_both_backends_same_bytes(built_lib, tmp_path):
         g, _ = cpp_dump(tmp_path, scheme, lg, "harness", "poseidon", 0)
         hh, _ = cpp_dump(tmp_path, scheme, lg, "harness", "poseidon", -1)
         assert g == hh, scheme
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0", "0,0,0,0,0,0,0,0"], ids=["2_shards", "3_shards", "8_shards"])
+def test_cpp_driver_over_sharded_keys_same_bytes(built_lib, tmp_path, devices):
+    """`profile_as --devices a,b,..` (one multi-device context: sharded keys, one exchange per commit round / grouped MSM / IPA
+    round) against the single-device run: identical accumulators and proofs for all four schemes -- ipa_pc_as at BASELINE config
+    2's size, so that the 8-GPU form of every config has run through the C++ call sequence before the first real node does."""
+    for scheme, lg in (("hp_as", 18), ("r1cs_nark_as", 14), ("ipa_pc_as", 16 if devices.count(",") == 7 else 11), ("trivial_pc_as", 10)):
+        one, _ = cpp_dump(tmp_path, scheme, lg, "harness", "poseidon", 0)
+        many, _ = cpp_dump(tmp_path, scheme, lg, "harness", "poseidon", 0, extra=("--devices", devices))
+        assert one == many, (scheme, devices)

@@ -9,7 +9,8 @@
 //
 //   profile_as <scheme: trivial_pc_as | ipa_pc_as | hp_as | r1cs_nark_as | all> <log_min> <log_max>
 //              [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] [--curve 0|1] [--constant] [--no-roundtrip]
-//              [--device D] [--seed S] [--dump FILE]
+//              [--device D | --devices a,b,..] [--seed S] [--dump FILE]
+//   --devices 0,1,2,3  one context over four GPUs (sharded keys; a repeated id puts two shards on one GPU).
 //   --device -1  runs on the library's host backend (amsm.h AMSM_DEVICE_HOST: BASELINE.json config 1 "plumbing, no GPU").
 //   --seed S     varies the harness's random stream and the synthetic vectors (0: the bench's inputs).
 //   --dump FILE  ONE (scheme, size, shape): exactly one prove after the first accumulation, then FILE receives the serialised new
@@ -38,10 +39,15 @@ struct Opt {
   int log_min = 10, log_max = 10, reps = 3, curve = AMSM_PALLAS;
   bool constant = false, roundtrip = true;
   int device = 0;
+  std::vector<int> devices;  // --devices a,b,..: one multi-device context (sharded keys), amsm.h amsm_ctx_create_multi
   uint64_t seed = 0;
   std::string dump;
 };
 
+static Context make_context(const Opt& o) {
+  if (o.devices.size() >= 2) return Context(o.curve, o.devices);
+  return Context(o.curve, o.device);
+}
 static void dump_records(const Opt& o, const std::vector<uint8_t>& acc, const std::vector<uint8_t>& proof) {
   if (o.dump.empty()) return;
   FILE* f = fopen(o.dump.c_str(), "wb");
@@ -119,7 +125,7 @@ static double timed_proves(const Opt& o, F&& prove_once) {
 template <class Sponge>
 static void profile_hp(const Opt& o, int lg, bool harness_shape) {
   using AS = hp_as::ASForHadamardProducts<Sponge>;
-  Context ctx(o.curve, o.device);
+  Context ctx = make_context(o);
   hp_as::FrOps fr{o.curve};
   const size_t n = (size_t)1 << lg;
   HarnessRng hr(0xA11CE ^ o.seed);
@@ -183,7 +189,7 @@ template <class Sponge>
 static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
   using AS = r1cs_nark_as::ASForR1CSNark<Sponge>;
   using Nark = r1cs_nark::R1CSNark<Sponge>;
-  Context ctx(o.curve, o.device);
+  Context ctx = make_context(o);
   hp_as::FrOps fr{o.curve};
   const size_t n_con = (size_t)1 << lg, n_inputs = 5, n_inst = n_inputs + 1;
   const Fr one = {1, 0, 0, 0};
@@ -254,7 +260,7 @@ static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
 template <class Sponge>
 static void profile_nark(const Opt& o, int lg, bool make_zk) {
   using Nark = r1cs_nark::R1CSNark<Sponge>;
-  Context ctx(o.curve, o.device);
+  Context ctx = make_context(o);
   hp_as::FrOps fr{o.curve};
   const size_t n_con = (size_t)1 << lg, n_inputs = 5, n_inst = n_inputs + 1;
   const size_t n_wit = (n_con > 5 ? n_con - 5 : 1) + 1;  // a, b, then num_witness_variables - 1 copies of a
@@ -305,7 +311,7 @@ template <class Sponge>
 static void profile_ipa(const Opt& o, int lg, bool harness_shape) {
   using AS = ipa_pc_as::AtomicASForInnerProductArgPC<Sponge>;
   using Ipa = ipa_pc::InnerProductArgPC<Sponge>;
-  Context ctx(o.curve, o.device);
+  Context ctx = make_context(o);
   ipa_pc::FrX fr(o.curve);
   const size_t degree = ((size_t)1 << lg) - 1;
   HarnessRng hr(0xD1 ^ o.seed);
@@ -358,7 +364,7 @@ template <class Sponge>
 static void profile_trivial(const Opt& o, int lg, bool harness_shape) {
   using namespace trivial_pc_as;
   using AS = ASForTrivialPC<Sponge>;
-  Context ctx(o.curve, o.device);
+  Context ctx = make_context(o);
   hp_as::FrOps fr{o.curve};
   const size_t degree = ((size_t)1 << lg) - 1;
   HarnessRng hr(0x7121A1 ^ o.seed);
@@ -427,7 +433,7 @@ int main(int argc, char** argv) {
   Opt o;
   if (argc < 4) {
     fprintf(stderr, "usage: %s <scheme|all> <log_min> <log_max> [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] "
-                    "[--curve 0|1] [--constant] [--no-roundtrip] [--device D] [--seed S] [--dump FILE]\n", argv[0]);
+                    "[--curve 0|1] [--constant] [--no-roundtrip] [--device D | --devices a,b,..] [--seed S] [--dump FILE]\n", argv[0]);
     return 2;
   }
   o.scheme = argv[1];
@@ -442,6 +448,12 @@ int main(int argc, char** argv) {
     else if (a == "--constant") o.constant = true;
     else if (a == "--no-roundtrip") o.roundtrip = false;
     else if (a == "--device" && i + 1 < argc) o.device = atoi(argv[++i]);
+    else if (a == "--devices" && i + 1 < argc) {
+      for (const char* p = argv[++i]; *p;) {
+        o.devices.push_back((int)strtol(p, (char**)&p, 10));
+        if (*p == ',') p++;
+      }
+    }
     else if (a == "--seed" && i + 1 < argc) o.seed = strtoull(argv[++i], nullptr, 0);
     else if (a == "--dump" && i + 1 < argc) o.dump = argv[++i];
     else {
