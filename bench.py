@@ -21,7 +21,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/un
                   r1cs_nark_as at 2^18 constraints and hp_as at 2^22 through the C++ scheme drivers (tools/profile_as.cpp =
                   the reference's harness examples/scaling-as.rs:38-138): the harness's own shape (1 input + the same
                   accumulator twice, MakeZK::Enabled) and the lighter n_all = 2 no-zk shape, each verified, decided and
-                  serialised; measured after and outside the timed region (N = 1 only; --no-schemes skips).
+                  serialised; measured after and outside the timed region (--no-schemes skips).  N > 1: `accumulations_multi_device`,
+                  the same harness over one multi-device context of the N GPUs.
 
     python bench.py --gpus N --single-process [--devices 0,1,...]
 runs the N-GPU job from ONE process through the multi-device context of the C ABI (amsm_ctx_create_multi: key sharded over
@@ -349,22 +350,33 @@ def main() -> int:
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ctx, ck, vecs, curve_id, args, out.copy(), bool(inf.value), last.get("all"))
-        if world == 1 and not args.no_schemes and args.log2n == 20 and args.curve == "pallas":
-            result["accumulations"] = scheme_rates()
-        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_schemes and args.log2n == 20 and args.curve == "pallas":
+            if world == 1:
+                result["accumulations"] = scheme_rates()
+            else:
+                # the N-GPU form of BASELINE configs 2-5 (strong scaling: the same sizes as the N = 1 line's `accumulations`): ONE
+                # process over the N devices through amsm_ctx_create_multi, after the ranks' process group is gone (the other
+                # ranks have exited; this rank's key stays resident).  Outside the timed region, bounded, never fails the line.
+                result["accumulations_multi_device"] = scheme_rates([0] * world if args.one_gpu else list(range(world)))
+        print(json.dumps(result), flush=True)
     return 0
 
 
-def scheme_rates():
+def scheme_rates(devices=None):
     """accumulations/sec (one `prove` = one accumulation; BASELINE.json's second metric) through the C++ scheme drivers:
     tools/profile_as.cpp, the reference's harness (examples/scaling-as.rs:38-138), at the sizes of BASELINE.json's configs --
     the harness's shape (1 input + the same accumulator twice, zk) and the n_all = 2 no-zk shape -- after the timed region
-    and outside it.  Never fails the bench line: an error is reported in place."""
+    and outside it.  Never fails the bench line: an error is reported in place.
+    devices (N > 1): the same harness over ONE multi-device context (`profile_as --devices a,b,..`: keys sharded over the devices,
+    one exchange of partial records per commit round / grouped MSM / IPA round inside the library) -- Poseidon lines only, each run
+    bounded; the first run that does not come back ends the leg."""
     import subprocess
-    out = {"driver": "C++ (include/amsm_*.hpp) via tools/profile_as.cpp",
+    multi = ["--devices", ",".join(str(d) for d in devices)] if devices else []
+    out = {"driver": "C++ (include/amsm_*.hpp) via tools/profile_as.cpp" + (" --devices " + multi[1] if multi else ""),
            "sponge": "poseidon (ark-sponge PoseidonSponge<Fq> as the reference's harness instantiates it, examples/scaling-as.rs; "
                      "parameters restated as recalled: unpinned).  `sha256_standin_*` keys repeat the run on the cheaper "
                      "SHA-256 stand-in sponge: NOT the reference's transcript, shown for the sponge's share only"}
@@ -382,18 +394,26 @@ def scheme_rates():
                          "two-valued form (v * sum of generators, amsm_ctx_two_valued_msms) instead of a windowed MSM.  r1cs_nark_as: the "
                          "reference's DummyCircuit (src/r1cs_nark_as/mod.rs:1159-1188), whose A z / B z / C z are one value per row: "
                          "two-valued as well.  The `value` of this bench line is measured on uniform random scalars only")
+        gave_up = False
         for scheme, lg, extra in (("trivial_pc_as", 10, ["--reps", "5"]), ("ipa_pc_as", 16, ["--reps", "3"]),
                                   ("r1cs_nark_as", 18, ["--reps", "3"]), ("hp_as", 22, ["--reps", "3"]),
                                   ("hp_as", 22, ["--reps", "3", "--constant"])):
             tag = "_harness_constant_inputs" if "--constant" in extra else ""
             for sponge in ("poseidon", "sha256"):
-                if tag and sponge == "sha256":
+                if (tag or multi) and sponge == "sha256":
+                    continue
+                if gave_up:
+                    out[f"{scheme}_2^{lg}{tag}"] = {"error": "skipped: an earlier multi-device run did not come back"}
                     continue
                 try:
                     # (the stand-in runs report a prove time only: no need to serialise 268 MB of hp_as witness for them)
-                    more = ["--no-roundtrip"] if sponge == "sha256" else []
-                    p = subprocess.run([exe, scheme, str(lg), str(lg), "--sponge", sponge, *extra, *more], capture_output=True, text=True,
-                                       timeout=600)
+                    more = (["--no-roundtrip"] if sponge == "sha256" else []) + multi
+                    try:
+                        p = subprocess.run([exe, scheme, str(lg), str(lg), "--sponge", sponge, *extra, *more], capture_output=True,
+                                           text=True, timeout=240 if multi else 600)
+                    except subprocess.TimeoutExpired:
+                        gave_up = bool(multi)
+                        raise
                     if p.returncode != 0:
                         raise RuntimeError(p.stderr[-300:])
                     for line in p.stdout.splitlines():

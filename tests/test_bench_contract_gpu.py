@@ -83,7 +83,7 @@ def test_eight_rank_branch_on_one_gpu(built_lib, strong):
     """The driver's 8-GPU command line with all eight ranks on the one GPU of this box (gloo; numbers meaningless): rendezvous, the
     rank table, max-over-ranks timing, eight 832 MiB keys + eight workspaces + eight host pools side by side -- what the first real
     8-rank run would otherwise meet for the first time."""
-    args = ["--gpus", "8", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--one-gpu"] + (["--strong"] if strong else [])
+    args = ["--gpus", "8", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--one-gpu"] + (["--strong", "--no-schemes"] if strong else [])
     r = _torchrun(8, 29561 + int(strong), os.path.join(ROOT, "bench.py"), *args)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     d = _line(r.stdout)
@@ -102,6 +102,14 @@ def test_eight_rank_branch_on_one_gpu(built_lib, strong):
     assert cfg["ranks"][0]["host_pool_threads"] <= max(0, multiprocessing.cpu_count() // 8 - 1) or cfg["ranks"][0]["host_pool_threads"] == 0
     assert "gloo" in cfg["collective"] and "128-byte records" in cfg["collective"]
     assert cfg["value_cold"] and cfg["value_cold"] > 0
+    if not strong:  # the N-GPU form of the `accumulations` half: the C++ harness over ONE context of eight shards (all on GPU 0 here)
+        acc = d["accumulations_multi_device"]
+        assert "--devices 0,0,0,0,0,0,0,0" in acc["driver"] and "error" not in acc
+        for key in ("trivial_pc_as_2^10_n2_1in_1acc_nozk", "ipa_pc_as_2^16_harness_1in_2acc_zk", "ipa_pc_as_2^16_n2_1in_1acc_nozk",
+                    "r1cs_nark_as_2^18_harness_1in_2acc_zk", "r1cs_nark_as_2^18_n2_1in_1acc_nozk", "hp_as_2^22_harness_1in_2acc_zk",
+                    "hp_as_2^22_n2_1in_1acc_nozk"):
+            assert acc[key]["verified"] is True and acc[key]["accumulations_per_s"] > 0, (key, acc[key])
+            assert acc[key]["serialize_roundtrip"] is True, key
 
 
 def test_sharded_schemes_eight_ranks_on_one_gpu(built_lib):
