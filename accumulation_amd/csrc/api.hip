@@ -26,6 +26,7 @@
 
 #include "fp.h"
 #include "host_field.h"
+#include "host_glv.h"
 #include "host_poseidon.h"
 #include "host_serialize.h"
 #include "launch.h"

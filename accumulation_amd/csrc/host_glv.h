@@ -337,5 +337,84 @@ inline bool glv_digits(const Glv<Fq, Fr>& g, const u64 k[4], GlvDigits& out) {
   return true;
 }
 
+
+// ---- linear combinations on the host (the schemes' O(#inputs) group algebra): GLV halves + signed 4-bit windows ----------------------
+// One term of a combination: |k| (up to 4 words) times p, the sign already folded into p.
+template <class P>
+struct HTerm {
+  HXYZZ<P> p;
+  u64 k[4];
+};
+template <class P>
+inline HXYZZ<P> hx_neg(const HXYZZ<P>& p) {
+  HXYZZ<P> r = p;
+  r.y = h_neg<P>(p.y);
+  return r;
+}
+// k * p (k canonical, p not the identity) as terms: scalars of more than 136 bits are split into the two ~128-bit GLV halves
+// (k = k1 + k2 lambda, phi(x, y) = (beta x, y)): the Straus loop below then runs 128 doublings instead of 255
+template <class Fq, class Fr>
+inline void hx_push_terms(const Glv<Fq, Fr>* glv, const HXYZZ<Fq>& p, const u64 k[4], std::vector<HTerm<Fq>>& out) {
+  Big k1, k2;
+  if (glv && hx_scalar_bits(k) > 136 && glv->decompose(k, k1, k2) && big_bits(k1) <= 192 && big_bits(k2) <= 192) {
+    for (int h = 0; h < 2; h++) {
+      const Big& kk = h ? k2 : k1;
+      if (big_is_zero(kk)) continue;
+      HTerm<Fq> t;
+      t.p = p;
+      if (h) t.p.x = h_mul<Fq>(p.x, glv->beta);
+      if (kk.neg) t.p = hx_neg<Fq>(t.p);
+      for (int i = 0; i < 4; i++) t.k[i] = (u64)kk.w[2 * i] | ((u64)kk.w[2 * i + 1] << 32);
+      out.push_back(t);
+    }
+    return;
+  }
+  HTerm<Fq> t;
+  t.p = p;
+  memcpy(t.k, k, 32);
+  out.push_back(t);
+}
+// sum of the terms: shared doublings, signed 4-bit digits in [-8, 8] (a table of 8 multiples per term: 1 doubling + 6 additions,
+// mixed while the point is affine), one addition per non-zero digit
+template <class P>
+inline HXYZZ<P> hx_straus_signed(const HTerm<P>* terms, size_t n) {
+  if (n == 0) return hx_inf<P>();
+  std::vector<HXYZZ<P>> tab(n * 8);
+  std::vector<int8_t> dig(n * 66, 0);
+  int top = -1;
+  for (size_t j = 0; j < n; j++) {
+    const HXYZZ<P>& p = terms[j].p;
+    HXYZZ<P>* t = &tab[j * 8];
+    t[0] = p;
+    t[1] = hx_dbl<P>(p);
+    const bool affine = h_eq<P>(p.zz, h_one<P>()) && h_eq<P>(p.zzz, h_one<P>());
+    for (int d = 2; d < 8; d++) {
+      t[d] = t[d - 1];
+      if (affine) hx_madd<P>(t[d], p.x, p.y);
+      else t[d] = hx_add<P>(t[d], p);
+    }
+    int carry = 0;
+    int8_t* dg = &dig[j * 66];
+    for (int w = 0; w < 65; w++) {
+      int v = (w < 64 ? (int)hx_nibble(terms[j].k, w) : 0) + carry;
+      carry = v > 8 ? 1 : 0;
+      if (carry) v -= 16;
+      dg[w] = (int8_t)v;
+      if (v) top = std::max(top, w);
+    }
+  }
+  HXYZZ<P> acc = hx_inf<P>();
+  for (int w = top; w >= 0; w--) {
+    if (!hx_is_inf<P>(acc))
+      for (int t = 0; t < 4; t++) acc = hx_dbl<P>(acc);
+    for (size_t j = 0; j < n; j++) {
+      const int d = dig[j * 66 + w];
+      if (d > 0) acc = hx_add<P>(acc, tab[j * 8 + d - 1]);
+      else if (d < 0) acc = hx_add<P>(acc, hx_neg<P>(tab[j * 8 - d - 1]));
+    }
+  }
+  return acc;
+}
+
 }  // namespace host
 }  // namespace amsm

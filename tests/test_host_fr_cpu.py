@@ -69,6 +69,12 @@ def test_host_lincomb_vs_oracle(built_lib, c):
 
     edge = [0, 1, 2, 15, 16, 17, 255, 256, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 128, (1 << 129) + 1, c.r - 1, c.r - 2,
             0xF0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0 % c.r]
+    # (round 5: scalars above 136 bits go in as their two GLV halves with signed digits) the cube roots of unity and their
+    # neighbours -- halves of 0, 1 and -1 --, digit strings of all 8s / 9s / Fs (the signed recoding's carry chain), r - lambda
+    lam = next(pow(x, (c.r - 1) // 3, c.r) for x in range(2, 50) if pow(x, (c.r - 1) // 3, c.r) != 1)
+    edge += [lam, lam - 1, lam + 1, c.r - lam, lam * lam % c.r, (lam * lam + 1) % c.r, (1 << 136) - 1, 1 << 136, (1 << 137) + 5,
+             int("8" * 62, 16) % c.r, int("9" * 62, 16) % c.r, int("F" * 34, 16), int("F" * 32, 16), int("7" * 63, 16) % c.r,
+             (lam * 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF + 0x88888888888888888888888888888888) % c.r]
     for s in edge:
         assert lincomb([pts[0]], [s]) == expect([pts[0]], [s]), hex(s)
     assert lincomb([], []) is None
