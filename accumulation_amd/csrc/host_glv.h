@@ -205,6 +205,7 @@ struct Glv {
   HFe<Fq> beta;    // Montgomery form (C-ABI radix)
   HFe<Fr> lambda;  // Montgomery form
   Big a1, b1, a2, b2, r;
+  Big g1, g2;  // round(2^384 b2 / r), round(2^384 (-b1) / r): `decompose` multiplies and shifts instead of dividing
 
   // gen_xy: the curve's generator, affine, Montgomery form (N words x, N words y)
   void setup(const u64* gen_xy) {
@@ -283,6 +284,14 @@ struct Glv {
       HFe<Fr> s = h_add<Fr>(h_from_big<Fr>(a), h_mul<Fr>(h_from_big<Fr>(b), lambda));
       if (!h_is_zero<Fr>(s)) return;
     }
+    auto shl384 = [](const Big& a) {
+      Big t = big_zero();
+      for (int i = 0; i + 12 < Big::N; i++) t.w[i + 12] = a.w[i];
+      t.neg = a.neg;
+      return t;
+    };
+    g1 = big_div_round(shl384(b2), r);
+    g2 = big_div_round(shl384(big_negate(b1)), r);
     ok = true;
   }
 
@@ -290,8 +299,23 @@ struct Glv {
   bool decompose(const u64 k[4], Big& k1, Big& k2) const {
     if (!ok) return false;
     Big kk = big_from_u64(k, 4);
-    Big c1 = big_div_round(big_mul(b2, kk), r);
-    Big c2 = big_div_round(big_mul(big_negate(b1), kk), r);
+    // c_i = round(k g_i / 2^384): within one of round(b2 k / r), round(-b1 k / r) -- the halves stay below 2^131 either way and the
+    // identity k1 + k2 lambda = k is checked below (a bit-serial division here cost ~10 us per scalar: the host combinations of a
+    // scheme split dozens of them per call)
+    auto mul_shift = [](const Big& g, const Big& k) {
+      Big p = big_mul(g, k);
+      const bool neg = p.neg;
+      p.neg = false;
+      Big half = big_zero();
+      half.w[11] = 0x80000000u;  // 2^383
+      big_add_mag(p, p, half);
+      Big q = big_zero();
+      for (int i = 0; i + 12 < Big::N; i++) q.w[i] = p.w[i + 12];
+      q.neg = neg && !big_is_zero(q);
+      return q;
+    };
+    Big c1 = mul_shift(g1, kk);
+    Big c2 = mul_shift(g2, kk);
     k1 = big_sub(big_sub(kk, big_mul(c1, a1)), big_mul(c2, a2));
     k2 = big_sub(big_negate(big_mul(c1, b1)), big_mul(c2, b2));
     if (big_bits(k1) > 150 || big_bits(k2) > 150) return false;

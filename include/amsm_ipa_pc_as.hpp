@@ -309,8 +309,19 @@ struct InnerProductArgPC {
     return proof;
   }
 
-  static std::optional<SuccinctCheckPolynomial> succinct_check(Context& ctx, const SuccinctVerifierKey& svk, const Commitment& commitment,
-                                                              const Fr& point, const Fr& value, const Proof& proof) {
+  // The succinct check in two halves, so that several checks can put their point algebra into ONE batched call: `prepare` derives the
+  // round challenges (sponge only) and lists the two combinations the check compares -- the round commitment
+  // C + v h' + sum_j (x_j^-1 L_j + x_j R_j) (the inverses are full-size scalars: 2 log2(d+1) + 2 terms) and c U + v' h' --,
+  // `finish` compares their values.  Rejections that need no group arithmetic come back from `prepare` as an empty optional.
+  struct PendingCheck {
+    SuccinctCheckPolynomial poly;
+    Affine combined_comm, h_prime;
+    std::vector<const Affine*> round_pts, check_pts;  // (into this object, the proof and the key: all outlive the batch call)
+    std::vector<Fr> round_scs, check_scs;
+  };
+  static std::optional<std::unique_ptr<PendingCheck>> succinct_check_prepare(Context& ctx, const SuccinctVerifierKey& svk,
+                                                                             const Commitment& commitment, const Fr& point,
+                                                                             const Fr& value, const Proof& proof) {
     FrX fr(amsm_ctx_curve(ctx.get()));
     size_t log_d = 0;
     while (((size_t)1 << (log_d + 1)) <= svk.supported_degree + 1) log_d++;
@@ -318,32 +329,51 @@ struct InnerProductArgPC {
     if (proof.l_vec.size() != proof.r_vec.size() || proof.l_vec.size() != log_d) return {};
     if (proof.hiding_comm.has_value() != proof.rand.has_value()) return {};
     const Fr one = fr.one();
-    Affine combined_comm = commitment.comm;
+    std::unique_ptr<PendingCheck> pc(new PendingCheck());
+    pc->combined_comm = commitment.comm;
     if (proof.hiding_comm) {
-      Fr hch = fr.to_mont(Challenge(fr).point(combined_comm).scalar(point).scalar(value).point(*proof.hiding_comm).squeeze_canonical());
-      combined_comm = host_lincomb(ctx, {&combined_comm, &*proof.hiding_comm, &svk.s}, {one, hch, fr.neg(*proof.rand)});
+      Fr hch = fr.to_mont(Challenge(fr).point(pc->combined_comm).scalar(point).scalar(value).point(*proof.hiding_comm).squeeze_canonical());
+      pc->combined_comm = host_lincomb(ctx, {&commitment.comm, &*proof.hiding_comm, &svk.s}, {one, hch, fr.neg(*proof.rand)});
     }
-    Fr rc_canon = Challenge(fr).point(combined_comm).scalar(point).scalar(value).squeeze_canonical();
+    Fr rc_canon = Challenge(fr).point(pc->combined_comm).scalar(point).scalar(value).squeeze_canonical();
     Fr round_challenge = fr.to_mont(rc_canon);
-    Affine h_prime = host_lincomb(ctx, {&svk.h}, {round_challenge});
-    std::vector<const Affine*> pts{&combined_comm, &h_prime};
-    std::vector<Fr> scs{one, value};
-    SuccinctCheckPolynomial cp;
+    pc->h_prime = host_lincomb(ctx, {&svk.h}, {round_challenge});
+    pc->round_pts = {&pc->combined_comm, &pc->h_prime};
+    pc->round_scs = {one, value};
     for (size_t k = 0; k < proof.l_vec.size(); k++) {
       rc_canon = Challenge(fr).bytes(le_bytes(rc_canon, 16)).point(proof.l_vec[k]).point(proof.r_vec[k]).squeeze_canonical();
       if (rc_canon == Fr{0, 0, 0, 0}) return {};
       round_challenge = fr.to_mont(rc_canon);
-      cp.challenges.push_back(round_challenge);
-      pts.push_back(&proof.l_vec[k]);
-      pts.push_back(&proof.r_vec[k]);
-      scs.push_back(fr.inv(round_challenge));
-      scs.push_back(round_challenge);
+      pc->poly.challenges.push_back(round_challenge);
+      pc->round_pts.push_back(&proof.l_vec[k]);
+      pc->round_pts.push_back(&proof.r_vec[k]);
+      pc->round_scs.push_back(fr.inv(round_challenge));
+      pc->round_scs.push_back(round_challenge);
     }
-    Affine round_commitment = host_lincomb(ctx, pts, scs);
-    Fr v_prime = fr.mul(cp.evaluate(fr, point), proof.c);
-    Affine check_commitment = host_lincomb(ctx, {&proof.final_comm_key, &h_prime}, {proof.c, v_prime});
-    if (!(round_commitment == check_commitment)) return {};
-    return cp;
+    Fr v_prime = fr.mul(pc->poly.evaluate(fr, point), proof.c);
+    pc->check_pts = {&proof.final_comm_key, &pc->h_prime};
+    pc->check_scs = {proof.c, v_prime};
+    return std::optional<std::unique_ptr<PendingCheck>>(std::move(pc));
+  }
+  // the combinations of all pending checks in one amsm_host_lincomb_batch (their terms are shared out over the host pool);
+  // ok[k] = check k holds
+  static std::vector<bool> succinct_check_finish(Context& ctx, const std::vector<const PendingCheck*>& pending) {
+    std::vector<hp_as::LincombJob> jobs;
+    for (const PendingCheck* pc : pending) {
+      jobs.push_back({pc->round_pts, pc->round_scs});
+      jobs.push_back({pc->check_pts, pc->check_scs});
+    }
+    std::vector<Affine> res = jobs.empty() ? std::vector<Affine>() : hp_as::host_lincomb_batch(ctx, jobs);
+    std::vector<bool> ok(pending.size());
+    for (size_t k = 0; k < pending.size(); k++) ok[k] = res[2 * k] == res[2 * k + 1];
+    return ok;
+  }
+  static std::optional<SuccinctCheckPolynomial> succinct_check(Context& ctx, const SuccinctVerifierKey& svk, const Commitment& commitment,
+                                                              const Fr& point, const Fr& value, const Proof& proof) {
+    auto pc = succinct_check_prepare(ctx, svk, commitment, point, value, proof);
+    if (!pc) return {};
+    if (!succinct_check_finish(ctx, {pc->get()})[0]) return {};
+    return (*pc)->poly;
   }
 
   static bool check(const CommitterKey& vk, const Commitment& commitment, const Fr& point, const Fr& value, const Proof& proof) {
@@ -579,9 +609,9 @@ class AtomicASForInnerProductArgPC {
     // checks may run side by side -- on at most as many threads as the host pool would use (one per instance was unbounded and
     // oversubscribed a node's ranks: ADVICE r4); an exception of a worker surfaces only after every worker has finished
     auto one = [&ctx, &svk](const InputInstance* inst) {
-      return Ipa::succinct_check(ctx, svk, inst->ipa_commitment, inst->point, inst->evaluation, inst->ipa_proof);
+      return Ipa::succinct_check_prepare(ctx, svk, inst->ipa_commitment, inst->point, inst->evaluation, inst->ipa_proof);
     };
-    std::vector<std::optional<ipa_pc::SuccinctCheckPolynomial>> cps(all.size());
+    std::vector<std::optional<std::unique_ptr<typename Ipa::PendingCheck>>> pend(all.size());
     const size_t n_workers = std::min<size_t>(all.size(), (size_t)amsm_host_threads() + 1);
     std::atomic<size_t> next{0};
     std::exception_ptr failure;
@@ -589,7 +619,7 @@ class AtomicASForInnerProductArgPC {
     auto loop = [&] {
       for (size_t k; (k = next.fetch_add(1)) < all.size();) {
         try {
-          cps[k] = one(all[k]);
+          pend[k] = one(all[k]);
         } catch (...) {
           std::lock_guard<std::mutex> lk(failure_mu);
           if (!failure) failure = std::current_exception();
@@ -601,12 +631,21 @@ class AtomicASForInnerProductArgPC {
     loop();  // (the caller's thread works too)
     for (auto& f : futs) f.get();
     if (failure) std::rethrow_exception(failure);
+    // the point algebra of every check that got this far, in ONE batched call (round 5: three checks side by side used to run two
+    // of their 34-term combinations on one thread each, the pool being taken by the third)
+    std::vector<const typename Ipa::PendingCheck*> live;
+    for (auto& p : pend)
+      if (p) live.push_back(p->get());
+    std::vector<bool> ok = Ipa::succinct_check_finish(ctx, live);
+    size_t at = 0;
     for (size_t k = 0; k < all.size(); k++) {
-      if (!cps[k]) {
+      const bool good = pend[k].has_value() && ok[at];
+      if (pend[k].has_value()) at++;
+      if (!good) {
         if (k >= ins.size()) throw MalformedAccumulator("Succinct check failed on accumulator.");
         throw MalformedInput("Succinct check failed on input.");
       }
-      out.push_back(Check{*cps[k], all[k]->ipa_proof.final_comm_key});
+      out.push_back(Check{(*pend[k])->poly, all[k]->ipa_proof.final_comm_key});
     }
   }
   // combine_succinct_check_polynomials_and_commitments :254-346

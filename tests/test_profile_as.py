@@ -22,8 +22,9 @@ def build():
     libdir = os.path.join(ROOT, "accumulation_amd")
     if os.path.exists(EXE) and os.path.getmtime(EXE) > max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(libdir, "libamsm.so"))):
         return
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE,
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE + f".{os.getpid()}",
                            "-L", libdir, "-l:libamsm.so", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+    os.replace(EXE + f".{os.getpid()}", EXE)  # (atomic: pytest -n workers may build the same program at once)
 
 
 def test_profile_as_compiles(built_lib):

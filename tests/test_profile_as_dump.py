@@ -24,8 +24,9 @@ def build():
     src = os.path.join(ROOT, "tools", "profile_as.cpp")
     deps = [src] + [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", EXE, "-L", libdir,
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", EXE + f".{os.getpid()}", "-L", libdir,
                                "-l:libamsm.so", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+        os.replace(EXE + f".{os.getpid()}", EXE)  # (atomic: pytest -n workers may build the same program at once)
 
 
 def cpp_dump(tmp_path, scheme, lg, shape, sponge, device, seed=0, extra=()):

@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--after", default="", help="summarise from the LAST call of this entry point on (e.g. amsm_vec_random)")
     ap.add_argument("--mark", default="amsm_ctx_is_host", help="summarise the span between the last two calls of this entry point")
     ap.add_argument("--timeline", type=int, default=0, help="also print the first N calls of the span (start, duration, gap before)")
+    ap.add_argument("--min-us", type=float, default=0.0, help="timeline: only calls at least this long")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
@@ -99,7 +100,14 @@ def main():
     for k in sorted(inside, key=inside.get, reverse=True)[:25]:
         print(f"  {k:44s} {count[k]:5d} x {inside[k] / count[k] * 1e3:9.1f} us = {inside[k]:8.3f} ms")
     prev = sel[0][1]
-    for name, s_, e_ in sel[:a.timeline]:
+    shown = 0
+    for name, s_, e_ in sel:
+        if shown >= a.timeline:
+            break
+        if 1e3 * (e_ - s_) < a.min_us:
+            prev = max(prev, e_)
+            continue
+        shown += 1
         print(f"    {s_ - sel[0][1]:9.3f} ms  {name:40s} {1e3 * (e_ - s_):9.1f} us   gap {1e3 * max(0.0, s_ - prev):8.1f} us")
         prev = max(prev, e_)
     print("  largest gaps between calls (ms, before which call):", ", ".join(f"{g:.3f} {nm}" for g, nm in sorted(gaps, reverse=True)[:8]))

@@ -54,4 +54,6 @@ for curve, name in ((ffi.AMSM_PALLAS, "pallas"), (ffi.AMSM_BLS12_381_G1, "bls12_
     bench("r1cs_nark_as blinded commitments (2 / 2 / 2 / 3 terms, 128-bit)", [[1, g], [1, g], [1, g], [1, g, g * g % r]])
     bench("r1cs_nark_as beta combine (3 jobs x 4 terms, 128-bit)", [[1, scal(128), scal(128), scal(128)]] * 3)
     bench("one job of 34 terms, 128-bit (an ipa_pc succinct check)", [[scal(128) for _ in range(34)]])
+    chk = [1, scal(255)] + [scal(255) if i % 2 == 0 else scal(128) for i in range(32)]
+    bench("three ipa_pc succinct checks in one call (3 x (34 + 2) terms, half of them full-size inverses)", [chk, [scal(255), scal(255)]] * 3)
     ctx.close()
