@@ -9,10 +9,12 @@ import torch  # noqa: F401,E402
 
 from accumulation_amd import CommitterKey, Context, VariableBaseMSM, ffi  # noqa: E402
 
-for curve, name, sizes in ((ffi.AMSM_PALLAS, "pallas", (16, 17, 18, 19, 20, 21, 22)), (ffi.AMSM_BLS12_381_G1, "bls12_381", (18, 19, 20))):
+only = [int(a) for a in sys.argv[1:]]  # e.g. `mid_sizes.py 18 19`: those sizes, Pallas, precomputed only (for a rocprofv3 trace)
+for curve, name, sizes in ((ffi.AMSM_PALLAS, "pallas", tuple(only) or (16, 17, 18, 19, 20, 21, 22)),
+                           (ffi.AMSM_BLS12_381_G1, "bls12_381", () if only else (18, 19, 20))):
     for lg in sizes:
         for flags, kind in ((ffi.AMSM_BASES_PRECOMPUTE, "precomputed"), (ffi.AMSM_BASES_NO_PRECOMPUTE, "plain")):
-            if kind == "plain" and lg > 21:
+            if kind == "plain" and (lg > 21 or only):
                 continue
             ctx = Context(curve)
             n = 1 << lg
