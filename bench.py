@@ -307,8 +307,7 @@ def main() -> int:
                 "window_bits": int(ck.window_bits),
                 "pipeline": ("bucket-per-lane (k_prep_local_t + k_accum_bpl; skewed scalars re-run chunked)"
                              if ck.window_bits == 20 else "chunked (k_accum_l0 + k_accum_l1)"),
-                "window_widths": ("9 x 20 + 4 x 19 bits = 256 (MsmGeom::n_narrow)" if ck.window_bits == 20 and os.environ.get("AMSM_NARROW", "1") != "0"
-                                  else None),
+                "window_widths": "9 x 20 + 4 x 19 bits = 256 (MsmGeom::n_narrow)" if ck.window_bits == 20 else None,
                 "pipeline_stats": pipe,
                 "rccl_ranks": None if rank_info is None else (len(rank_info) if args.backend == "nccl" else 0),
                 "ranks": rank_info,
