@@ -245,6 +245,7 @@ struct amsm_ctx {
   DevBuf rec_send, rec_recv, stage;  // per device: this shard's partial records / the gathered ones / scalar slices
   hipEvent_t multi_fork = nullptr;
   unsigned long long n_collectives = 0;  // exchanges of partial records so far (amsm_ctx_collectives: one per sharded call)
+  uint64_t n_host_gathers = 0;  // grouped MSMs / IPA rounds over sharded keys: the shards' class sums folded on the host
   // ---- caching allocator behind amsm_dev_alloc / amsm_dev_free ----
   // hipMalloc / hipFree synchronise the device: a scheme driver that allocates its vectors per call (every `Vec<F>` the
   // reference builds) would serialise the GPU on each one.  Freed buffers go to size-keyed free lists and are handed out

@@ -104,7 +104,7 @@ int amsm_ctx_is_host(const amsm_ctx* ctx);
  * with ONE RCCL all-gather per call (communicators created from the device list; hipMemcpyPeerAsync when RCCL is
  * unavailable, AMSM_COLLECTIVE=peer, or a device is listed twice) and fold + normalise once.  Results are bit-identical to
  * the single-device ones.  Grouped MSMs and the IPA round shard too since round 5 (every shard sums its part of both index
- * classes, the round's scalars are peer-copied slice by slice: an `ipa_pc` opening over a sharded key runs every round as one
+ * classes -- its two sums come back to the host, where they are folded: no device exchange on that latency-bound path --, the round's scalars are peer-copied slice by slice: an `ipa_pc` opening over a sharded key runs every round as one
  * grouped MSM over the ORIGINAL key and never folds it).  Multi-offset MSMs go out as one sharded batch per run of jobs
  * over the same key range.  Entry points that do not shard (key folds, amsm_bases_device_ptr) return AMSM_E_UNSUPPORTED / NULL for a sharded key.
  * A device id may appear more than once (two shards on one GPU: how a 1-GPU box exercises this path).

@@ -1,5 +1,5 @@
 """ipa_pc / ipa_pc_as over a key SHARDED across the devices of a multi-device context (round 5: grouped MSMs and the IPA round shard
--- every shard sums its part of both index classes, one exchange of two records per round; the key is never folded).  On the one-GPU
+-- every shard sums its part of both index classes, the two sums per shard are folded on the host; the key is never folded).  On the one-GPU
 test box the shards share device 0; proofs and accumulators must equal the single-device ones bit for bit."""
 import numpy as np
 import pytest
@@ -28,7 +28,7 @@ def test_grouped_msm_over_a_sharded_key(devices, log_n):
             a = VariableBaseMSM.multi_scalar_mul_grouped(k1, v1, shift, mont=True)
             before = multi.collectives
             b = VariableBaseMSM.multi_scalar_mul_grouped(kN, vN, shift, mont=True)
-            assert multi.collectives - before == 1
+            assert multi.collectives - before == 0  # (the two class sums of every shard are folded on the host: no device exchange)
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (devices, log_n, shift)
         k1.free()
         kN.free()
@@ -57,8 +57,8 @@ def test_ipa_open_and_accumulate_over_a_sharded_key(devices, degree, make_zk):
             point = rng.field() % fr.r
             before = ctx.collectives if isinstance(ctx, MultiContext) else 0
             proof = IpaPC.open(pk.ipa_ck, poly, comm, point, rand, make_zk, rng)
-            if isinstance(ctx, MultiContext):  # one exchange per round + the final key's MSM (+ the hiding polynomial's commitment)
-                assert ctx.collectives - before >= (degree + 1).bit_length() - 1
+            if isinstance(ctx, MultiContext):  # the rounds fold their sums on the host; the final key's MSM (and the hiding
+                assert 1 <= ctx.collectives - before <= 3  # polynomial's commitment) are exchanges of records between the devices
             z = ctx.vector(degree + 1)
             from accumulation_amd.engine import _ptr
             ffi.check(ctx._lib.amsm_vec_powers(ctx._h, _ptr(fr.to_limbs(point)), degree + 1, z.ptr), "powers")
