@@ -392,12 +392,14 @@ def scheme_rates(devices=None):
                          "own inputs, vec![rand; n] (src/hp_as/mod.rs:189-190, :991-992): every commitment of such a vector takes the "
                          "two-valued form (v * sum of generators, amsm_ctx_two_valued_msms) instead of a windowed MSM.  r1cs_nark_as: the "
                          "reference's DummyCircuit (src/r1cs_nark_as/mod.rs:1159-1188), whose A z / B z / C z are one value per row: "
-                         "two-valued as well.  The `value` of this bench line is measured on uniform random scalars only")
+                         "two-valued as well; `r1cs_nark_as_..._uniform_witness` repeats it over a circuit whose rows are w_i * w_i = v_i "
+                         "with a random witness (A z, B z, C z uniform: the windowed pipelines; not the reference's harness).  The "
+                         "`value` of this bench line is measured on uniform random scalars only")
         gave_up = False
         for scheme, lg, extra in (("trivial_pc_as", 10, ["--reps", "5"]), ("ipa_pc_as", 16, ["--reps", "3"]),
-                                  ("r1cs_nark_as", 18, ["--reps", "3"]), ("hp_as", 22, ["--reps", "3"]),
-                                  ("hp_as", 22, ["--reps", "3", "--constant"])):
-            tag = "_harness_constant_inputs" if "--constant" in extra else ""
+                                  ("r1cs_nark_as", 18, ["--reps", "3"]), ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"]),
+                                  ("hp_as", 22, ["--reps", "3"]), ("hp_as", 22, ["--reps", "3", "--constant"])):
+            tag = "_harness_constant_inputs" if "--constant" in extra else ("_uniform_witness" if "--uniform" in extra else "")
             for sponge in ("poseidon", "sha256"):
                 if (tag or multi) and sponge == "sha256":
                     continue

@@ -8,7 +8,7 @@
 // configs 4, 5) get the same treatment here.
 //
 //   profile_as <scheme: trivial_pc_as | ipa_pc_as | hp_as | r1cs_nark_as | all> <log_min> <log_max>
-//              [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] [--curve 0|1] [--constant] [--no-roundtrip]
+//              [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] [--curve 0|1] [--constant] [--uniform] [--no-roundtrip]
 //              [--device D | --devices a,b,..] [--seed S] [--dump FILE]
 //   --devices 0,1,2,3  one context over four GPUs (sharded keys; a repeated id puts two shards on one GPU).
 //   --device -1  runs on the library's host backend (amsm.h AMSM_DEVICE_HOST: BASELINE.json config 1 "plumbing, no GPU").
@@ -38,6 +38,7 @@ struct Opt {
   std::string scheme = "all", shape = "both", sponge = "sha256";
   int log_min = 10, log_max = 10, reps = 3, curve = AMSM_PALLAS;
   bool constant = false, roundtrip = true;
+  bool uniform = false;  // r1cs_nark_as: a circuit whose A z, B z, C z are uniform random vectors (see profile_nark_as)
   int device = 0;
   std::vector<int> devices;  // --devices a,b,..: one multi-device context (sharded keys), amsm.h amsm_ctx_create_multi
   uint64_t seed = 0;
@@ -199,25 +200,40 @@ static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
   hp_as::Rng zk_rng = harness_shape ? hp_as::Rng([&hr]() { return hr.field(); }) : hp_as::Rng();
   Result r;
   auto t0 = Clock::now();
+  // The reference's DummyCircuit (num_constraints - 1 copies of a * b = c over TWO witness variables) makes A z, B z, C z one value
+  // per row: every commitment of the NARK and of the accumulation is a two-valued vector's (amsm_ctx_two_valued_msms).  --uniform
+  // runs the same schemes over a circuit whose vectors are uniform: constraint i is w_i * w_i = v_i over 2 (n - 1) witness variables
+  // (w random, v their squares), so A z = B z = w and C z = v are random field elements -- what a real circuit's rows look like to
+  // the MSM engine.  (Not the reference's harness: reported under its own key by bench.py.)
+  const size_t m = n_con - 1, n_wit = o.uniform ? 2 * m : 2;
   std::vector<r1cs_nark::Matrix::Row> A, B, C;
   for (size_t k = 0; k + 1 < n_con; k++) {
-    A.push_back({{one, n_inst + 0}});
-    B.push_back({{one, n_inst + 1}});
-    C.push_back({{one, 1}});
+    A.push_back({{one, n_inst + (o.uniform ? k : 0)}});
+    B.push_back({{one, n_inst + (o.uniform ? k : 1)}});
+    C.push_back({{one, o.uniform ? n_inst + m + k : 1}});
   }
   A.push_back({});
   B.push_back({});
   C.push_back({});
-  r1cs_nark::IndexProverKey ipk = Nark::index(ctx, A, B, C, n_inst, n_inst + 2, 31337);
+  r1cs_nark::IndexProverKey ipk = Nark::index(ctx, A, B, C, n_inst, n_inst + n_wit, 31337);
   auto keys = AS::index(ipk);
   r.index_ms = ms_since(t0);
+  uint64_t wit_seed = 0x77A0 + o.seed;
   auto make_input = [&]() {
     Fr a = hr.field(), b = hr.field();
     Fr am = fr.to_mont(a), bm = fr.to_mont(b), abm = fr.mul(am, bm), ab;
     check(amsm_fr_from_mont(o.curve, abm.data(), 1, ab.data()), "from_mont");
     std::vector<Fr> inst{one, ab};
     for (size_t k = 1; k < n_inputs; k++) inst.push_back(a);
-    auto wit = std::make_shared<FrVector>(ctx, std::vector<Fr>{am, bm});
+    std::shared_ptr<FrVector> wit;
+    if (o.uniform) {
+      wit = std::make_shared<FrVector>(ctx, n_wit);
+      char* w = static_cast<char*>(wit->ptr());
+      check(amsm_vec_random(ctx.get(), wit_seed++, m, 1, w), "amsm_vec_random");
+      check(amsm_vec_hadamard(ctx.get(), w, w, w + m * 32, m), "amsm_vec_hadamard");
+    } else {
+      wit = std::make_shared<FrVector>(ctx, std::vector<Fr>{am, bm});
+    }
     auto sp = AS::sponges(Sponge());
     r1cs_nark::Proof proof = Nark::prove(ipk, inst, wit, zk_rng, sp.nark);
     return r1cs_nark_as::Input{r1cs_nark_as::InputInstance{inst, proof.first_msg}, proof.second_msg};
@@ -253,7 +269,9 @@ static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
   if (!o.dump.empty()) dump_records(o, ser::serialize(ctx, res.first), ser::serialize(ctx, res.second));
   printf("Constraints: %zu\n", n_con);
   report(o, "r1cs_nark_as", lg, "log2_constraints",
-         harness_shape ? "harness: 1 input + 2x the same accumulator" : "n2: 1 input + 1 accumulator", harness_shape, r);
+         o.uniform ? (harness_shape ? "harness: 1 input + 2x the same accumulator, uniform witness" : "n2: 1 input + 1 accumulator, uniform witness")
+                   : (harness_shape ? "harness: 1 input + 2x the same accumulator" : "n2: 1 input + 1 accumulator"),
+         harness_shape, r);
 }
 
 // ---- the R1CS NARK on its own: examples/scaling-nark.rs:58-110 (profile_nark: index / prove / verify, proof size; main runs it
@@ -435,7 +453,7 @@ int main(int argc, char** argv) {
   Opt o;
   if (argc < 4) {
     fprintf(stderr, "usage: %s <scheme|all> <log_min> <log_max> [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] "
-                    "[--curve 0|1] [--constant] [--no-roundtrip] [--device D | --devices a,b,..] [--seed S] [--dump FILE]\n", argv[0]);
+                    "[--curve 0|1] [--constant] [--uniform] [--no-roundtrip] [--device D | --devices a,b,..] [--seed S] [--dump FILE]\n", argv[0]);
     return 2;
   }
   o.scheme = argv[1];
@@ -448,6 +466,7 @@ int main(int argc, char** argv) {
     else if (a == "--sponge" && i + 1 < argc) o.sponge = argv[++i];
     else if (a == "--curve" && i + 1 < argc) o.curve = atoi(argv[++i]);
     else if (a == "--constant") o.constant = true;
+    else if (a == "--uniform") o.uniform = true;
     else if (a == "--no-roundtrip") o.roundtrip = false;
     else if (a == "--device" && i + 1 < argc) o.device = atoi(argv[++i]);
     else if (a == "--devices" && i + 1 < argc) {
