@@ -139,3 +139,20 @@ def test_cpp_driver_over_sharded_keys_same_bytes(built_lib, tmp_path, devices):
         one, _ = cpp_dump(tmp_path, scheme, lg, "harness", "poseidon", 0)
         many, _ = cpp_dump(tmp_path, scheme, lg, "harness", "poseidon", 0, extra=("--devices", devices))
         assert one == many, (scheme, devices)
+
+
+# ---- the uniform-witness circuit of `profile_as --uniform` (rows w_i * w_i = v_i: what bench.py reports beside the harness's two-valued lines)
+@pytest.mark.parametrize("shape", ["n2", "harness"])
+def test_uniform_witness_circuit_on_the_host_backend(built_lib, tmp_path, shape):
+    (acc, proof), out = cpp_dump(tmp_path, "r1cs_nark_as", 7, shape, "poseidon", -1, extra=("--uniform",))
+    assert "uniform witness" in out and '"serialize_roundtrip_decides": true' in out
+    assert len(acc) > 2 * 32 * (1 << 7)  # the blinded witness (2 (n - 1) variables) and the hp vectors are in the accumulator
+
+
+@pytest.mark.gpu
+def test_uniform_witness_circuit_same_bytes_on_both_backends_and_over_shards(built_lib, tmp_path):
+    g, out = cpp_dump(tmp_path, "r1cs_nark_as", 14, "harness", "poseidon", 0, extra=("--uniform",))
+    assert '"serialize_roundtrip_decides": true' in out
+    hh, _ = cpp_dump(tmp_path, "r1cs_nark_as", 14, "harness", "poseidon", -1, extra=("--uniform",))
+    many, _ = cpp_dump(tmp_path, "r1cs_nark_as", 14, "harness", "poseidon", 0, extra=("--uniform", "--devices", "0,0,0"))
+    assert g == hh and g == many
