@@ -244,6 +244,10 @@ struct amsm_ctx {
   void** rccl_comms = nullptr;   // ncclComm_t per shard
   DevBuf rec_send, rec_recv, stage;  // per device: this shard's partial records / the gathered ones / scalar slices
   hipEvent_t multi_fork = nullptr;
+  // vectors whose unit scalars are summed apart during the current msm_multi_split_xyzz call: [first byte, one past the last) of
+  // their scalars -- msm_enqueue sets MsmGeom::skip_ones for every (range of a) vector that lies inside one
+  std::vector<std::pair<const char*, const char*>> skip_ones_ranges;
+  unsigned long long n_ones_split = 0;  // MSMs that took that form (amsm_ctx_unit_scalar_msms)
   unsigned long long n_collectives = 0;  // exchanges of partial records so far (amsm_ctx_collectives: one per sharded call)
   uint64_t n_host_gathers = 0;  // grouped MSMs / IPA rounds over sharded keys: the shards' class sums folded on the host
   // ---- caching allocator behind amsm_dev_alloc / amsm_dev_free ----

@@ -242,10 +242,13 @@ void launch_vec_fill(hipStream_t st, u32* out, const u32 v[8], u32 n) {
                      make_uint4(v[4], v[5], v[6], v[7]), n);
 }
 
-void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16) {
-  static_assert(TV_PROBE_WORDS == TV_WORDS && TV_EXC_SLOTS == TV_EXC_MAX, "launch.h mirrors vec_kernels.h");
+void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out16, const u32 one[8]) {
+  static_assert(TV_PROBE_WORDS == TV_WORDS && TV_EXC_SLOTS == TV_EXC_MAX && TV_ONES_SAMPLE_COUNT == TV_ONES_SAMPLES,
+                "launch.h mirrors vec_kernels.h");
   const u32 blocks = std::max(1u, std::min(512u, (n + 1023u) / 1024u));
-  hipLaunchKernelGGL(k_tv_probe, dim3(blocks), dim3(256), 0, st, scalars, n, out16);
+  TvOne o;
+  memcpy(o.w, one, 32);
+  hipLaunchKernelGGL(k_tv_probe, dim3(blocks), dim3(256), 0, st, scalars, n, out16, o);
 }
 
 #define AMSM_FR_LAUNCHERS(FR)                                                                                        \

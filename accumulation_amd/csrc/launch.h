@@ -91,7 +91,10 @@ bool launch_points_fold_tab(hipStream_t st, const u32* table, u32 stride, u32 c,
 
 // two-valued vectors (vec_kernels.h k_tv_probe, msm_kernels.h k_tv_sum): exact probe into TV_PROBE_WORDS zeroed words, and the
 // sum of the generators with non-zero scalars as `blocks` partial records
-void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out_words);  // TV_PROBE_WORDS words, zeroed
+// out_words: TV_PROBE_WORDS words, zeroed; one: the unit scalar as the vector stores it (word 4 of the output counts how many of
+// TV_ONES_SAMPLE_COUNT evenly spaced scalars equal it)
+constexpr u32 TV_ONES_SAMPLE_COUNT = 1024;
+void launch_tv_probe(hipStream_t st, const u32* scalars, u32 n, u32* out_words, const u32 one[8]);
 // nv <= 8 vectors in one launch: vector v's `blocks` partial records at parts + v * blocks, its exception records (8 slots of
 // 8 + 2 W words: scalar | generator in the C-ABI radix) at exc + v * 8 slots; probes[v] = the vector's k_tv_probe words
 template <class Fq>

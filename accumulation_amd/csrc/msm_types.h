@@ -56,6 +56,9 @@ struct MsmGeom {
   u32 bpl;           // 1: bucket-per-lane pipeline (k_prep_local_t + k_accum_bpl; 20-bit windows), 2: bucket-split pipeline
                      // (k_prep_local_s + k_accum_bps; small and medium MSMs), 0: chunked pipeline
   u32 bps_log2_l;    // bucket-split: log2 of the lanes per bucket
+  u32 skip_ones;     // round 5: scalars equal to ONE emit no entries (their generators are summed apart, k_tv_sum: ark-ec's
+                     // multi_scalar_mul adds the bases of unit scalars directly too) -- a witness with a share of boolean wires
+                     // would otherwise put all of them into bucket 1 of the lowest window
   u32 red_s;         // buckets per reduce lane
   u32 red_threads;   // reduce lanes per set
 };
@@ -81,6 +84,7 @@ AMSM_GEOM_FN u32 window_exponent(const MsmGeom& g, u32 w) { return window_expone
 // the parameters of the signed-digit walk (vec_kernels.h: digit_step), as every kernel that walks scalars receives them
 struct DigitWalk {
   u32 c, W, n_narrow, top_shift;
+  u32 skip_ones;  // (k_skew_probe: unit scalars are not looked at -- numerous ones are summed apart, few ones skew nothing)
 };
 AMSM_GEOM_FN DigitWalk digit_walk_of(const MsmGeom& g) {
   DigitWalk d;
@@ -88,6 +92,7 @@ AMSM_GEOM_FN DigitWalk digit_walk_of(const MsmGeom& g) {
   d.W = g.W;
   d.n_narrow = g.n_narrow;
   d.top_shift = g.top_shift;
+  d.skip_ones = g.skip_ones;
   return d;
 }
 // narrow windows a width-c walk over 256 bits needs (0 when the widths divide evenly; ~0u when c - 1 is not narrow enough)

@@ -18,6 +18,14 @@ namespace amsm {
 // recoding's carry for the next window and shifts s.  Window w is c bits wide, or c - 1 (MsmGeom::n_narrow: the top windows,
 // digit doubled); the legacy short top window of a top_shift key is spread by its shift.  A scalar that does not fit the
 // windows (non-canonical: >= 2^255) leaves carry = 1 behind the last window -- the callers' `rest`.
+// canonical s == 1 -> 0 (MsmGeom::skip_ones: the unit scalars' generators are summed apart)
+template <class Fr>
+AMSM_DEV void fe_drop_one(Fe<Fr>& s) {
+  u32 rest = s.v[0] ^ 1u;
+#pragma unroll
+  for (int k = 1; k < 8; k++) rest |= s.v[k];
+  if (rest == 0u) s.v[0] = 0u;
+}
 template <class Fr>
 AMSM_DEV u32 digit_step(Fe<Fr>& s, const DigitWalk& dw, u32 w, u32& carry, u32& neg) {
   const u32 c = dw.c, W = dw.W;
@@ -479,6 +487,7 @@ __global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ sca
   const u32 i = (u32)(((u64)t * n) / PROBE_SAMPLES);
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
   if (mont) s = fe_from_mont<Fr>(s);
+  if (dw.skip_ones) fe_drop_one<Fr>(s);
   u32 carry = 0;
   dw.top_shift = 0;  // (the legacy short top window is looked at unshifted: the histogram only asks how many samples share a digit)
   for (u32 w = 0; w < dw.W; w++) {
@@ -517,12 +526,30 @@ AMSM_DEV bool tv_words_equal(const u32* a, const u32* b) {
   for (int k = 0; k < 8; k++) eq = eq && a[k] == b[k];
   return eq;
 }
-__global__ void __launch_bounds__(256) k_tv_probe(const u32* __restrict__ scalars, u32 n, u32* __restrict__ out) {
+// out[4] (round 5): how many of TV_ONES_SAMPLES evenly spaced scalars equal ONE as stored (`one`: the unit in the vector's
+// representation, canonical or Montgomery) -- a vector with a share of unit scalars (boolean wires of an R1CS witness) is not
+// two-valued, but its ones are summed apart (MsmGeom::skip_ones).
+constexpr u32 TV_ONES_SAMPLES = 1024;
+struct TvOne {
+  u32 w[8];
+};
+__global__ void __launch_bounds__(256) k_tv_probe(const u32* __restrict__ scalars, u32 n, u32* __restrict__ out, TvOne one) {
   __shared__ u32 cand[3];
   __shared__ u32 minv;
   __shared__ u32 vw[8];
   const u32 t = threadIdx.x;
   const uint4* s4 = (const uint4*)scalars;
+  if (blockIdx.x == 0) {  // (before any early exit below)
+    u32 cnt = 0;
+    for (u32 k = 0; k < TV_ONES_SAMPLES / 256u; k++) {
+      const u32 i = (u32)(((unsigned long long)(t + 256u * k) * n) / TV_ONES_SAMPLES);
+      const uint4 a = s4[2 * (size_t)i], b = s4[2 * (size_t)i + 1];
+      if (a.x == one.w[0] && a.y == one.w[1] && a.z == one.w[2] && a.w == one.w[3] && b.x == one.w[4] && b.y == one.w[5] &&
+          b.z == one.w[6] && b.w == one.w[7])
+        cnt++;
+    }
+    if (cnt) atomicAdd(&out[4], cnt);
+  }
   // which of this lane's (at most four) head scalars are non-zero
   u32 nz = 0;
   for (u32 k = 0; k < TV_HEAD / 256u; k++) {
@@ -620,6 +647,7 @@ __global__ void __launch_bounds__(256)
   if (i >= g.n) return;
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
   if (mont) s = fe_from_mont<Fr>(s);
+  if (g.skip_ones) fe_drop_one<Fr>(s);
   // first bucket set of this scalar's group (grouped MSM: two sums over index classes in one pass)
   const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * sets_per_group(g);
   u32 carry = 0;

@@ -109,7 +109,8 @@ class Context:
         ffi.check(self._lib.amsm_ctx_pipeline_stats_small(self._h, C.byref(c), C.byref(d)), "amsm_ctx_pipeline_stats_small")
         return {"bucket_per_lane": a.value, "fallbacks": b.value, "bucket_split": c.value, "bucket_split_fallbacks": d.value,
                 "direct_sum": int(self._lib.amsm_ctx_direct_sum_msms(self._h)),
-                "shared_bucket_sets": int(self._lib.amsm_ctx_shared_bucket_msms(self._h))}
+                "shared_bucket_sets": int(self._lib.amsm_ctx_shared_bucket_msms(self._h)),
+                "unit_scalar_sums": int(self._lib.amsm_ctx_unit_scalar_msms(self._h))}
 
     def trim(self):
         """Release the MSM workspace and every cached buffer (amsm_ctx_trim); live vectors and keys stay."""

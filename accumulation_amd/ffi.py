@@ -51,6 +51,7 @@ SIGNATURES = {
     "amsm_ctx_collective": (C.c_char_p, [_vp]),
     "amsm_ctx_collectives": (C.c_ulonglong, [_vp]),
     "amsm_ctx_two_valued_msms": (C.c_ulonglong, [_vp]),
+    "amsm_ctx_unit_scalar_msms": (C.c_ulonglong, [_vp]),
     "amsm_ctx_direct_sum_msms": (C.c_ulonglong, [_vp]),
     "amsm_ctx_shared_bucket_msms": (C.c_ulonglong, [_vp]),
     "amsm_ctx_pipeline_stats": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),

@@ -210,7 +210,7 @@ def main() -> int:
         ms_host = (time.perf_counter() - t1) / 5 * 1e3
         # ... and the same host slices handed over back to back, the way the reference's provers call `commit`
         # (src/hp_as/mod.rs:372-385): amsm_msm_batch overlaps the upload of vector v + 1 with MSM v
-        ms_host_batch = pipe = plain_rate = ms_dev_batch12 = None
+        ms_host_batch = pipe = plain_rate = witness_rate = ms_dev_batch12 = None
         if world == 1:
             h_vecs = [v.download() for v in vecs]
             VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(3)])
@@ -237,6 +237,20 @@ def main() -> int:
                 plain_rate = 12 * n / (time.perf_counter() - t1)  # (batches of 12, like the host-slice lines above)
                 if "all" in last and not np.array_equal(pp[:4], last["all"][0][:4]):
                     raise SystemExit("plain-key MSM differs from the precomputed-key MSM")
+                # ... and over a vector that looks like an R1CS witness: 10 % of the scalars are boolean wires (0 or 1).  ark-ec adds
+                # the bases of unit scalars directly; here they are summed apart since round 5 (amsm_ctx_unit_scalar_msms) -- before,
+                # all of them landed in bucket 1 of the lowest window and this batch ran 2.3x slower than the uniform one
+                hw = vecs[0].download().copy()
+                pick = np.random.default_rng(SEED_SCALARS).random(n) < 0.1
+                bits = np.zeros_like(hw)
+                bits[:, 0] = np.random.default_rng(SEED_SCALARS + 1).integers(0, 2, n)
+                hw[pick] = bits[pick]
+                wv = ctx.upload(hw)
+                VariableBaseMSM.multi_scalar_mul_batch(ck_plain, [wv] * 3, mont=False)
+                t1 = time.perf_counter()
+                VariableBaseMSM.multi_scalar_mul_batch(ck_plain, [wv] * 12, mont=False)
+                witness_rate = 12 * n / (time.perf_counter() - t1)
+                wv.free()
                 ck_plain.free()
 
     if world > 1:
@@ -303,6 +317,7 @@ def main() -> int:
                                             "faster than pageable ones and ran up to 27 % slower (profiles/r05_host_slices.md)",
                 # no precomputed multiples (one copy of the key, a bucket set per window): the variable-base rate
                 "pairs_per_s_plain_key": None if plain_rate is None else round(plain_rate, 1),
+                "pairs_per_s_plain_key_witness_10pct_booleans": None if witness_rate is None else round(witness_rate, 1),
                 "key_bytes": key_bytes(ck, ctx, n),
                 "window_bits": int(ck.window_bits),
                 "pipeline": ("bucket-per-lane (k_prep_local_t + k_accum_bpl; skewed scalars re-run chunked)"

@@ -126,6 +126,12 @@ unsigned long long amsm_ctx_collectives(const amsm_ctx* ctx);
  * with a non-zero scalar).  ark-ec's multi_scalar_mul special-cases the scalars 0 and 1 the same way (ark-ec ^0.2.0 msm, not
  * in /root/reference: Cargo.toml:15); the reference's hp_as inputs are `vec![rand; n]` (src/hp_as/mod.rs:189-190). */
 unsigned long long amsm_ctx_two_valued_msms(const amsm_ctx* ctx);
+/* MSMs of device vectors whose UNIT scalars were summed apart (round 5): a vector that is not two-valued but holds a share of
+ * ones -- the boolean wires of an R1CS witness -- would put all of them into bucket 1 of the lowest window (2.2x slower than a
+ * uniform vector at 2^18 pairs with 10 % booleans).  The same exact pass that tests for two-valued vectors counts the ones among
+ * 1024 evenly spaced scalars; from 8 up the generators under unit scalars are summed by themselves (n_ones additions) and the
+ * windowed pipelines skip those scalars -- what ark-ec's multi_scalar_mul does with them.  Results do not depend on it. */
+unsigned long long amsm_ctx_unit_scalar_msms(const amsm_ctx* ctx);
 /* MSMs that were summed straight from a small key's table of digit multiples (round 4: precomputed keys of up to 2^15 generators --
  * AMSM_DIRECT_SUM_MAX_LOG2, at most 16, 0 turns it off -- also hold j 2^(4w) G_i for j = 1 .. 8, w = 0 .. 63, 512 affine points per
  * generator, so that an MSM is one launch of mixed additions and a tree: no buckets, no sort, no dependence on the digit

@@ -1,5 +1,5 @@
 """Randomised differential test of the MSM entry points against the CPU oracle (longer than the pytest suite wants to be):
-random sizes, window overrides, key kinds, base offsets, scalar distributions (uniform / few distinct / sparse / top of
+random sizes, window overrides, key kinds, base offsets, scalar distributions (uniform / few distinct / sparse / boolean-heavy witness / top of
 the field), single / batch / multi / grouped calls, both curves.  Usage: python tools/fuzz_msm.py [seconds] [seed]"""
 import os
 import sys
@@ -56,6 +56,14 @@ def scalars(c, n, kind):
         m = rs.rand(n) < 0.05
         out[m] = base[m]
         return out
+    if kind == "witness":  # uniform values with a share of boolean wires (round 5: their unit scalars are summed apart)
+        frac = float(rs.choice([0.01, 0.1, 0.5, 0.9]))
+        m = rs.rand(n) < frac
+        out = base.copy()
+        bits = np.zeros_like(base)
+        bits[:, 0] = rs.randint(0, 2, size=n) if rs.rand() < 0.7 else 1
+        out[m] = bits[m]
+        return out
     if kind == "top":
         sp = h.scalars_to_np([c.r - 1, c.r - 2, 1 << 254, (1 << 254) - 1, 1, 0, (1 << 128) - 1])
         return sp[rs.randint(0, len(sp), size=n)]
@@ -73,7 +81,7 @@ while time.time() < t_end:
         ck = CommitterKey.load(ctx, xy, None, flags)
         off = int(rs.randint(0, n_key // 2)) if rs.rand() < 0.3 else 0
         n = n_key - off if rs.rand() < 0.5 else int(rs.randint((n_key - off) // 4 + 1, n_key - off + 1))
-        sc = cref.rng_scalars(int(rs.randint(1 << 30)), n)
+        sc = scalars(c, n, "witness") if rs.rand() < 0.3 else cref.rng_scalars(int(rs.randint(1 << 30)), n)
         k = int(rs.randint(0, 40))
         if k:
             edge = h.scalars_to_np([c.r - 1, c.r - 2, (1 << 254) - 1 if c.r > (1 << 254) else (1 << 253), 1, 0, 2, (1 << 128) - 1,
@@ -105,7 +113,7 @@ while time.time() < t_end:
             xy[rs.randint(0, n_key, size=k)] = adv[c.name][rs.randint(0, len(adv[c.name]), size=k)]
             n_adv += 1
         ck = CommitterKey.load(ctx, xy, None, 1)
-        kind = str(rs.choice(["uniform", "few", "sparse", "top"]))
+        kind = str(rs.choice(["uniform", "few", "sparse", "top", "witness"]))
         mode = str(rs.choice(["single", "batch", "multi", "grouped", "grouped"]))
         off = int(rs.randint(0, n_key)) if rs.rand() < 0.3 else 0
         n = int(rs.randint(1, n_key - off + 1))
@@ -216,7 +224,7 @@ while time.time() < t_end:
     flags = int(rs.choice([1, 2]))
     ctx.set_window(w)
     ck = CommitterKey.load(ctx, xy, None, flags)
-    kind = str(rs.choice(["uniform", "few", "sparse", "top"]))
+    kind = str(rs.choice(["uniform", "few", "sparse", "top", "witness"]))
     mode = str(rs.choice(["single", "batch", "multi", "grouped"]))
     off = int(rs.randint(0, n_key)) if rs.rand() < 0.3 else 0
     n = int(rs.randint(1, n_key - off + 1))
