@@ -274,6 +274,20 @@ class ASForR1CSNark {
     const FrVector& w = *acc.witness.r1cs_blinded_witness;
     FrVector za = dk.a->vec_mul(d_in, w), zb = dk.b->vec_mul(d_in, w), zc = dk.c->vec_mul(d_in, w);
     const AccumulatorWitnessRandomness* rnd = acc.witness.randomness ? &*acc.witness.randomness : nullptr;
+    // The three commitments of this check and the three of the nested hp_as decision (src/hp_as/mod.rs:894-925) are six MSMs over
+    // the same key: ONE batch (one fill and one drain of the device pipeline instead of two) when the vectors are of one length --
+    // the same verdict as `comm_check && HP::decide(..)`.
+    const hp_as::InputWitness& hw = acc.witness.hp_witness;
+    if (hw.a_vec && hw.b_vec && hw.a_vec->len() == za.len() && hw.b_vec->len() == za.len()) {
+      FrVector product = hp_as::compute_hp(*hw.a_vec, *hw.b_vec);
+      const auto* hr = hw.randomness ? &*hw.randomness : nullptr;
+      auto cd = PedersenCommitment::commit_batch(ck, {&za, &zb, &zc, hw.a_vec.get(), hw.b_vec.get(), &product},
+                                                 {rnd ? &rnd->sigma_a : nullptr, rnd ? &rnd->sigma_b : nullptr, rnd ? &rnd->sigma_c : nullptr,
+                                                  hr ? &hr->rand_1 : nullptr, hr ? &hr->rand_2 : nullptr, hr ? &hr->rand_3 : nullptr});
+      const hp_as::InputInstance& hi = acc.instance.hp_instance;
+      return cd[0] == acc.instance.comm_a && cd[1] == acc.instance.comm_b && cd[2] == acc.instance.comm_c && cd[3] == hi.comm_1 &&
+             cd[4] == hi.comm_2 && cd[5] == hi.comm_3;
+    }
     auto cd = PedersenCommitment::commit_batch(
         ck, {&za, &zb, &zc}, {rnd ? &rnd->sigma_a : nullptr, rnd ? &rnd->sigma_b : nullptr, rnd ? &rnd->sigma_c : nullptr});
     const Affine &ca = cd[0], &cb = cd[1], &cc = cd[2];
