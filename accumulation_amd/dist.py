@@ -30,7 +30,10 @@ class HipEngine:
         import torch
         self.ctx, self.ck = ctx, ck
         self.record_bytes = int(ctx._lib.amsm_partial_bytes(ctx._h))
-        self._partial = torch.empty(self.record_bytes, dtype=torch.uint8, device=f"cuda:{ctx.device}")
+        # (a context of the library's host backend keeps its "device" memory on the host: the records are CPU tensors, the exchange
+        # runs over gloo -- tests/test_dist_cpu.py drives the product library this way without a GPU)
+        self._dev = "cpu" if int(ctx.device) < 0 else f"cuda:{ctx.device}"
+        self._partial = torch.empty(self.record_bytes, dtype=torch.uint8, device=self._dev)
 
     def partial(self, scalars, mont: bool):
         """scalars: FrVector (this rank's slice).  Returns a uint8 CUDA tensor holding the record."""
@@ -56,7 +59,7 @@ class HipEngine:
         from . import ffi
         k = len(vecs)
         # torch.empty: no fill kernel on torch's stream that could land after the engine's write on its own stream
-        out = torch.empty(max(k, 1) * self.record_bytes, dtype=torch.uint8, device=f"cuda:{self.ctx.device}")
+        out = torch.empty(max(k, 1) * self.record_bytes, dtype=torch.uint8, device=self._dev)
         ptrs = (C.c_void_p * max(k, 1))(*[v.ptr for v in vecs])
         ffi.check(self.ctx._lib.amsm_msm_partial_batch_device(self.ctx._h, self.ck._h, 0, ptrs, k, vecs[0].n if k else 0,
                                                               1 if mont else 0, C.c_void_p(out.data_ptr())),

@@ -99,3 +99,52 @@ def test_sharded_msm_world2_gloo(n, cref):
     for rank, out, inf, outs, infs in res:
         assert inf == rinf and out == ref.tolist(), rank
         assert infs == [rinf, rinf2, rinf] and outs == [ref.tolist(), ref2.tolist(), ref.tolist()], rank
+
+
+# ---- the PRODUCT engine on the library's host backend (round 5): the same two-rank exchange, no stand-in ----------------------------
+def _worker_host_backend(rank, world, init_file, n, q):
+    from accumulation_amd import CommitterKey, Context, ffi
+    from accumulation_amd.dist import HipEngine
+    from oracle import cref
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        c = o.PALLAS
+        xy = cref.rng_points(c.curve_id, 0x5EED1001, n)
+        sc, sc2 = cref.rng_scalars(0x5EED0001, n), cref.rng_scalars(0x5EED0002, n)
+        lo, hi = shard_bounds(n, rank, world)
+        ctx = Context(ffi.AMSM_PALLAS, device=ffi.AMSM_DEVICE_HOST)
+        ck = CommitterKey.load(ctx, xy[lo:hi], None, ffi.AMSM_BASES_DEFAULT)
+        sm = ShardedMSM(HipEngine(ctx, ck))
+        a, b = ctx.upload(sc[lo:hi]), ctx.upload(sc2[lo:hi])
+        out, inf = sm.msm(a, mont=False)
+        outs, infs = sm.msm_batch([a, b, a], mont=False)
+        q.put((rank, out.tolist(), bool(inf), np.asarray(outs).tolist(), [bool(x) for x in infs]))
+        ck.free()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [2, 5000])
+def test_sharded_msm_world2_gloo_on_the_host_backend(n, cref, built_lib):
+    """accumulation_amd.dist.HipEngine over a host-backend context (libamsm.so itself: amsm_msm_partial[_batch]_device,
+    amsm_partials_combine[_batch]) on two gloo ranks without a GPU -- the N > 1 torchrun form of the product, not of a stand-in"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "init")
+        procs = [ctx.Process(target=_worker_host_backend, args=(r, world, init_file, n, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    c = o.PALLAS
+    pts = cref.rng_points(c.curve_id, 0x5EED1001, n)
+    ref, rinf = cref.msm(c.curve_id, pts, cref.rng_scalars(0x5EED0001, n))
+    ref2, rinf2 = cref.msm(c.curve_id, pts, cref.rng_scalars(0x5EED0002, n))
+    for rank, out, inf, outs, infs in res:
+        assert inf == rinf and out == ref.tolist(), rank
+        assert infs == [rinf, rinf2, rinf] and outs == [ref.tolist(), ref2.tolist(), ref.tolist()], rank

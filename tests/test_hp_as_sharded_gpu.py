@@ -57,7 +57,7 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()
 
 
-def _worker(rank, world, init_file, make_zk, q, N=N, digest=False):
+def _worker(rank, world, init_file, make_zk, q, N=N, digest=False, device=0):
     """digest: the witness slices travel back as SHA-256 (config-size runs: 2^22 elements)"""
     import torch.distributed as dist
     from accumulation_amd import CommitterKey, Context, PedersenCommitment, ffi
@@ -65,7 +65,7 @@ def _worker(rank, world, init_file, make_zk, q, N=N, digest=False):
     from accumulation_amd.hp_as import ASForHadamardProducts as AS
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     try:
-        ctx = Context(ffi.AMSM_PALLAS)
+        ctx = Context(ffi.AMSM_PALLAS, device=device)
         tmp = CommitterKey.generate(ctx, KEY_SEED, N + 1, ffi.AMSM_BASES_NO_PRECOMPUTE)
         xy, _ = tmp.read()
         ck = ShardedCommitterKey.from_global(ctx, xy[:N], hiding_generator=xy[N].copy())
@@ -84,21 +84,22 @@ def _worker(rank, world, init_file, make_zk, q, N=N, digest=False):
         dist.destroy_process_group()
 
 
-def run_sharded_vs_unsharded(make_zk, world, N=N, digest=False, timeout=600):
+def run_sharded_vs_unsharded(make_zk, world, N=N, digest=False, timeout=600, device=0):
+    """device: 0 = the GPU; ffi.AMSM_DEVICE_HOST = every rank on the library's host backend (tests/host_backend/: no GPU needed)"""
     import torch.multiprocessing as mp
     from accumulation_amd import CommitterKey, Context, PedersenCommitment, ffi
     from accumulation_amd.hp_as import ASForHadamardProducts as AS
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     with tempfile.TemporaryDirectory() as d:
-        procs = [mpc.Process(target=_worker, args=(r, world, os.path.join(d, "init"), make_zk, q, N, digest)) for r in range(world)]
+        procs = [mpc.Process(target=_worker, args=(r, world, os.path.join(d, "init"), make_zk, q, N, digest, device)) for r in range(world)]
         for p in procs:
             p.start()
         got = dict(q.get(timeout=timeout) for _ in range(world))
         for p in procs:
             p.join(timeout=120)
             assert p.exitcode == 0
-    ctx = Context(ffi.AMSM_PALLAS)
+    ctx = Context(ffi.AMSM_PALLAS, device=device)
     tmp = CommitterKey.generate(ctx, KEY_SEED, N + 1, ffi.AMSM_BASES_NO_PRECOMPUTE)
     xy, _ = tmp.read()
     ck = CommitterKey.load(ctx, xy[:N], None, ffi.AMSM_BASES_DEFAULT, hiding_generator=xy[N].copy())

@@ -66,13 +66,13 @@ def _run(ctx, ck, make_zk, NUM_CONSTRAINTS=NUM_CONSTRAINTS):
             "hp_a": acc2.witness.hp_witness.a_vec.download()}
 
 
-def _worker(rank, world, init_file, make_zk, q, NUM_CONSTRAINTS=NUM_CONSTRAINTS, digest=False):
+def _worker(rank, world, init_file, make_zk, q, NUM_CONSTRAINTS=NUM_CONSTRAINTS, digest=False, device=0):
     import torch.distributed as dist
     from accumulation_amd import CommitterKey, Context, ffi
     from accumulation_amd.dist import ShardedCommitterKey
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     try:
-        ctx = Context(ffi.AMSM_PALLAS)
+        ctx = Context(ffi.AMSM_PALLAS, device=device)
         tmp = CommitterKey.generate(ctx, KEY_SEED, NUM_CONSTRAINTS + 1, ffi.AMSM_BASES_NO_PRECOMPUTE)
         xy, _ = tmp.read()
         ck = ShardedCommitterKey.from_global(ctx, xy[:NUM_CONSTRAINTS], hiding_generator=xy[NUM_CONSTRAINTS].copy())
@@ -85,13 +85,14 @@ def _worker(rank, world, init_file, make_zk, q, NUM_CONSTRAINTS=NUM_CONSTRAINTS,
         dist.destroy_process_group()
 
 
-def run_sharded_vs_unsharded(make_zk, world, NUM_CONSTRAINTS=NUM_CONSTRAINTS, digest=False, timeout=600):
+def run_sharded_vs_unsharded(make_zk, world, NUM_CONSTRAINTS=NUM_CONSTRAINTS, digest=False, timeout=600, device=0):
+    """device: 0 = the GPU; ffi.AMSM_DEVICE_HOST = every rank on the library's host backend (tests/host_backend/: no GPU needed)"""
     import torch.multiprocessing as mp
     from accumulation_amd import CommitterKey, Context, ffi
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     with tempfile.TemporaryDirectory() as d:
-        procs = [mpc.Process(target=_worker, args=(r, world, os.path.join(d, "init"), make_zk, q, NUM_CONSTRAINTS, digest))
+        procs = [mpc.Process(target=_worker, args=(r, world, os.path.join(d, "init"), make_zk, q, NUM_CONSTRAINTS, digest, device))
                  for r in range(world)]
         for p in procs:
             p.start()
@@ -99,7 +100,7 @@ def run_sharded_vs_unsharded(make_zk, world, NUM_CONSTRAINTS=NUM_CONSTRAINTS, di
         for p in procs:
             p.join(timeout=120)
             assert p.exitcode == 0
-    ctx = Context(ffi.AMSM_PALLAS)
+    ctx = Context(ffi.AMSM_PALLAS, device=device)
     tmp = CommitterKey.generate(ctx, KEY_SEED, NUM_CONSTRAINTS + 1, ffi.AMSM_BASES_NO_PRECOMPUTE)
     xy, _ = tmp.read()
     ck = CommitterKey.load(ctx, xy[:NUM_CONSTRAINTS], None, ffi.AMSM_BASES_DEFAULT, hiding_generator=xy[NUM_CONSTRAINTS].copy())
