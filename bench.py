@@ -411,10 +411,15 @@ def scheme_rates(devices=None):
                          "with a random witness (A z, B z, C z uniform: the windowed pipelines; not the reference's harness).  The "
                          "`value` of this bench line is measured on uniform random scalars only")
         gave_up = False
-        for scheme, lg, extra in (("trivial_pc_as", 10, ["--reps", "5"]), ("ipa_pc_as", 16, ["--reps", "3"]),
+        for scheme, lg, extra in (("trivial_pc_as", 10, ["--reps", "5"]), ("trivial_pc_as", 10, ["--reps", "5", "--device", "-1"]),
+                                  ("ipa_pc_as", 16, ["--reps", "3"]),
                                   ("r1cs_nark_as", 18, ["--reps", "3"]), ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"]),
                                   ("hp_as", 22, ["--reps", "3"]), ("hp_as", 22, ["--reps", "3", "--constant"])):
             tag = "_harness_constant_inputs" if "--constant" in extra else ("_uniform_witness" if "--uniform" in extra else "")
+            if "--device" in extra:  # BASELINE config 1 as it reads ("plumbing, no GPU"): the library's host backend behind the same ABI
+                if multi:
+                    continue
+                tag = "_host_backend"
             for sponge in ("poseidon", "sha256"):
                 if (tag or multi) and sponge == "sha256":
                     continue

@@ -35,7 +35,7 @@ def test_default_line_n1(built_lib):
     assert d["cpu_baseline"]["timed_batch_msms_checked"] == 12  # every MSM of the timed batch against the CPU result
     acc = {k: v for k, v in d["accumulations"].items() if isinstance(v, dict) and "accumulations_per_s" in v}
     # 4 schemes x 2 shapes + hp_as again with the reference harness's constant inputs (the two-valued form)
-    assert len(acc) == 12 and all(v.get("verified") for v in acc.values()), d["accumulations"]  # (incl. the two uniform-witness r1cs_nark_as lines)
+    assert len(acc) == 14 and all(v.get("verified") for v in acc.values()), d["accumulations"]  # (incl. the two uniform-witness r1cs_nark_as lines and trivial_pc_as on the host backend)
     assert sum(1 for k in acc if k.endswith("_harness_constant_inputs")) == 2
     assert all(v["sponge"] == "poseidon" for v in acc.values())  # the reference's sponge, not the SHA-256 stand-in
     assert len(d["accumulations"]["sha256_standin_prove_ms"]) == 8
