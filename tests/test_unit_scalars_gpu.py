@@ -129,3 +129,27 @@ def test_views_that_share_memory_with_a_vector_that_keeps_its_ones():
         assert np.array_equal(out[0], ref)
     finally:
         ctx.close()
+
+
+def test_witness_like_vectors_over_a_sharded_key():
+    """a multi-device context (three shards on GPU 0): every shard probes and sums the unit scalars of ITS slice; same results as
+    the single-device context and the oracle"""
+    from accumulation_amd import CommitterKey, Context, MultiContext, VariableBaseMSM
+    curve = ffi.AMSM_PALLAS
+    n = (1 << 18) + 3
+    one, multi = Context(curve), MultiContext(curve, (0, 0, 0))
+    try:
+        k1 = CommitterKey.generate(one, 0x0E59, n, ffi.AMSM_BASES_PRECOMPUTE | ffi.AMSM_BASES_NO_DIRECT_TABLE)
+        xy, inf = k1.read()
+        kN = CommitterKey.load(multi, xy, inf, ffi.AMSM_BASES_PRECOMPUTE | ffi.AMSM_BASES_NO_DIRECT_TABLE)
+        w, u = _witness(n, 0.2, 41), cref.rng_scalars(42, n)
+        a = VariableBaseMSM.multi_scalar_mul_batch(k1, [one.upload(w), one.upload(u)], mont=False)
+        b = VariableBaseMSM.multi_scalar_mul_batch(kN, [multi.upload(w), multi.upload(u)], mont=False)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for j, vec in enumerate((w, u)):
+            ref, ref_inf = cref.msm(curve, xy, vec)
+            assert np.array_equal(b[0][j], ref) and bool(b[1][j]) == bool(ref_inf)
+        assert one.pipeline_stats()["unit_scalar_sums"] == 1
+    finally:
+        one.close()
+        multi.close()
