@@ -87,8 +87,8 @@ AMSM_DEV u32 lds_count(u32* ctr, u32 idx) {
 template <class Fr, class F>
 AMSM_DEV u32 scalar_entries(const u32* __restrict__ scalars, int mont, const MsmGeom& g, u32 i, F&& f) {
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
+  if (g.skip_ones) fe_drop_stored_one<Fr>(s, mont);
   if (mont) s = fe_from_mont<Fr>(s);
-  if (g.skip_ones) fe_drop_one<Fr>(s);
   // first bucket set of this scalar's group (grouped MSM: two sums over index classes in one pass)
   const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * sets_per_group(g);
   u32 carry = 0;
@@ -226,8 +226,8 @@ __global__ void __launch_bounds__(512)
     u32 i = blockIdx.x * pg.SPB + r * T + t;
     if (i < g.n) {
       sreg[r] = fe_load<Fr>(scalars + (size_t)i * 8);
+      if (g.skip_ones) fe_drop_stored_one<Fr>(sreg[r], mont);
       if (mont) sreg[r] = fe_from_mont<Fr>(sreg[r]);
-      if (g.skip_ones) fe_drop_one<Fr>(sreg[r]);
       const u32 bad = scalar_entries_unrolled_reg<Fr, MAXW>(sreg[r], g, i, [&](int w, u32 key, u32) {
         u32 rank = atomicAdd(&cnt[key >> pg.SH], 1u);
         rk[r][w >> 1] |= rank << ((w & 1) * 16);

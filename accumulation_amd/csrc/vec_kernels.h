@@ -18,13 +18,17 @@ namespace amsm {
 // recoding's carry for the next window and shifts s.  Window w is c bits wide, or c - 1 (MsmGeom::n_narrow: the top windows,
 // digit doubled); the legacy short top window of a top_shift key is spread by its shift.  A scalar that does not fit the
 // windows (non-canonical: >= 2^255) leaves carry = 1 behind the last window -- the callers' `rest`.
-// canonical s == 1 -> 0 (MsmGeom::skip_ones: the unit scalars' generators are summed apart)
+// MsmGeom::skip_ones: a scalar that IS the unit AS STORED (canonical 1, or the Montgomery form of 1) becomes 0 -- exactly the test
+// k_tv_sum applies when it sums those scalars' generators apart (a non-reduced representation of 1 fails both and stays in the windows)
 template <class Fr>
-AMSM_DEV void fe_drop_one(Fe<Fr>& s) {
-  u32 rest = s.v[0] ^ 1u;
+AMSM_DEV void fe_drop_stored_one(Fe<Fr>& s, int mont) {
+  u32 rest = 0;
 #pragma unroll
-  for (int k = 1; k < 8; k++) rest |= s.v[k];
-  if (rest == 0u) s.v[0] = 0u;
+  for (int k = 0; k < 8; k++) rest |= s.v[k] ^ (mont ? Fr::one(k) : (k == 0 ? 1u : 0u));
+  if (rest == 0u) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) s.v[k] = 0u;
+  }
 }
 template <class Fr>
 AMSM_DEV u32 digit_step(Fe<Fr>& s, const DigitWalk& dw, u32 w, u32& carry, u32& neg) {
@@ -486,8 +490,8 @@ __global__ void __launch_bounds__(1024) k_skew_probe(const u32* __restrict__ sca
   if (t == 0) worst = 0;
   const u32 i = (u32)(((u64)t * n) / PROBE_SAMPLES);
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
+  if (dw.skip_ones) fe_drop_stored_one<Fr>(s, mont);
   if (mont) s = fe_from_mont<Fr>(s);
-  if (dw.skip_ones) fe_drop_one<Fr>(s);
   u32 carry = 0;
   dw.top_shift = 0;  // (the legacy short top window is looked at unshifted: the histogram only asks how many samples share a digit)
   for (u32 w = 0; w < dw.W; w++) {
@@ -646,8 +650,8 @@ __global__ void __launch_bounds__(256)
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.n) return;
   Fe<Fr> s = fe_load<Fr>(scalars + (size_t)i * 8);
+  if (g.skip_ones) fe_drop_stored_one<Fr>(s, mont);
   if (mont) s = fe_from_mont<Fr>(s);
-  if (g.skip_ones) fe_drop_one<Fr>(s);
   // first bucket set of this scalar's group (grouped MSM: two sums over index classes in one pass)
   const u32 set0 = ((g.groups > 1u) ? ((i >> g.group_shift) & 1u) : 0u) * sets_per_group(g);
   u32 carry = 0;

@@ -153,3 +153,31 @@ def test_witness_like_vectors_over_a_sharded_key():
     finally:
         one.close()
         multi.close()
+
+
+def test_a_non_reduced_montgomery_one_stays_in_the_windows():
+    """Montgomery-form scalars: R mod r is the unit the separate sum looks for; R mod r + r represents 1 as well (below 2^256) but is
+    not that pattern -- the sum does not take it and the pipelines must not drop it (both apply the SAME test to the stored words)"""
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM
+    from oracle import pyref as o
+    curve, c = ffi.AMSM_PALLAS, o.PALLAS
+    ctx = Context(curve)
+    try:
+        n = 1 << 17
+        key = CommitterKey.generate(ctx, 0x0E5A, n, ffi.AMSM_BASES_PRECOMPUTE | ffi.AMSM_BASES_NO_DIRECT_TABLE)
+        xy, _ = key.read()
+        w = _witness(n, 0.3, 51, ones_only=True)
+        up = cref.fr_to_mont(curve, w).copy()
+        odd = ((1 << 256) % c.r) + c.r
+        assert odd < (1 << 256)
+        where = [5, 4097, n // 2 + 1, n - 3]
+        for i in where:
+            up[i] = [(odd >> (64 * k)) & ((1 << 64) - 1) for k in range(4)]
+            w[i] = [1, 0, 0, 0]
+        before = ctx.pipeline_stats()["unit_scalar_sums"]
+        out, oinf = VariableBaseMSM.multi_scalar_mul_batch(key, [ctx.upload(up)], mont=True)
+        assert ctx.pipeline_stats()["unit_scalar_sums"] - before == 1
+        ref, ref_inf = cref.msm(curve, xy, w)
+        assert np.array_equal(out[0], ref) and bool(oinf[0]) == bool(ref_inf)
+    finally:
+        ctx.close()
