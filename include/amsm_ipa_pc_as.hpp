@@ -228,9 +228,12 @@ struct InnerProductArgPC {
     std::optional<Affine> hiding_comm;
     std::optional<Fr> proof_rand;
     if (hiding) {
-      std::vector<Fr> hp_host;
-      for (size_t i = 0; i < n; i++) hp_host.push_back(fr.to_mont(rng()));
-      FrVector hp0(ctx, hp_host);
+      // d + 1 random coefficients: drawn in canonical form, uploaded as they are and taken to Montgomery form by ONE device kernel
+      // (a Montgomery product with R^2: x R^2 R^-1 = x R) -- one amsm_fr_to_mont call per coefficient was 1.6 ms of a 2^16 prove
+      std::vector<Fr> hp_canon(n);
+      for (size_t i = 0; i < n; i++) hp_canon[i] = rng();
+      FrVector hp_raw(ctx, hp_canon);
+      FrVector hp0 = combine2(ctx, hp_raw.ptr(), n, fr.to_mont(one), hp_raw.ptr(), 0, zero, n);
       Fr hv = inner_product(ctx, hp0.ptr(), z.ptr(), n);
       FrVector shift(ctx, std::vector<Fr>{fr.neg(hv)});  // random polynomial that vanishes at `point`
       FrVector hp = combine2(ctx, hp0.ptr(), n, one, shift.ptr(), 1, one, n);

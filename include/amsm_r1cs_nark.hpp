@@ -244,9 +244,12 @@ struct R1CSNark {
       compute_challenge(fr, ipk.index_info.matrices_hash, input, first, sponge);  // gamma is squeezed but unused
       return Proof{first, SecondRoundMessage{witness, {}}};
     }
-    std::vector<Fr> r_host;  // :168-172
-    for (size_t i = 0; i < witness->len(); i++) r_host.push_back(fr.to_mont(rng()));
-    FrVector r(ctx, r_host);
+    // :168-172 -- drawn in canonical form and taken to Montgomery form on the device (one Montgomery product with R^2 per element,
+    // one kernel: a witness-length loop of single-element amsm_fr_to_mont calls was ~25 ns per variable on the host)
+    std::vector<Fr> r_canon(witness->len());
+    for (size_t i = 0; i < r_canon.size(); i++) r_canon[i] = rng();
+    FrVector r_raw(ctx, r_canon);
+    FrVector r = hp_as::combine_vectors(ctx, {&r_raw}, {fr.to_mont(fr.one())});
     FrVector zeros(ctx, std::vector<Fr>(input.size(), fr.zero()));
     FrVector r_a = ipk.a->vec_mul(zeros, r), r_b = ipk.b->vec_mul(zeros, r), r_c = ipk.c->vec_mul(zeros, r);
     Fr a_bl = fr.to_mont(rng()), b_bl = fr.to_mont(rng()), c_bl = fr.to_mont(rng());
