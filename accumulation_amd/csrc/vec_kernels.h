@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256) k_vec_random(u32* __restrict__ out, u64 s
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fe<Fr> s;
-  rng_scalar(seed, i, s.v);
+  rng_scalar_fr<Fr>(seed, i, s.v);
   if (mont) s = fe_to_mont<Fr>(s);
   fe_store<Fr>(out + (size_t)i * 8, s);
 }

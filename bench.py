@@ -297,7 +297,7 @@ def main() -> int:
             "config": {
                 "workload": (f"ONE 2^{args.log2n}-pair {args.curve} MSM per step, point-sharded over {world} GPUs"
                              if (args.strong and world > 1) else f"2^{args.log2n}-pair {args.curve} MSM per GPU") +
-                            f" (north_star size; uniform 254-bit scalars, "
+                            f" (north_star size; scalars uniform in [0, r), "
                             f"G_i = k_i*G), key resident{'' if args.no_precompute else ' + precomputed window multiples'}",
                 "pairs_per_gpu": n,
                 "curve": args.curve,

@@ -488,6 +488,27 @@ void ark_rng_scalars(u64 seed, size_t n, u64* out) {
   }
 }
 
+/* The SCALAR stream of amsm_vec_random since round 6 (accumulation_amd/csrc/rng.h:rng_scalar_fr): uniform in [0, r) of the
+ * curve's scalar field by rejection -- candidate t of scalar i = words (t << 40) + 4 i .. + 3 masked to 255 bits, the first
+ * one below r wins; after 64 rejections candidate 63 with bit 254 cleared.  ark_rng_scalars above stays the 254-bit
+ * MULTIPLIER stream of the synthetic committer keys (G_i = k_i G). */
+int ark_rng_scalars_fr(int curve, u64 seed, size_t n, u64* out) {
+  if (curve < 0 || curve > 1) return -1;
+  curves_init();
+  const field_t* fr = &g_curves[curve].fr;
+  for (size_t i = 0; i < n; i++) {
+    u64* o = out + 4 * i;
+    int ok = 0;
+    for (u64 t = 0; t < 64 && !ok; t++) {
+      for (int k = 0; k < 4; k++) o[k] = rng_word(seed, (t << 40) + 4 * i + k);
+      o[3] &= ((u64)1 << 63) - 1;
+      ok = !geq(o, fr->m, 4);
+    }
+    if (!ok) o[3] &= ((u64)1 << 62) - 1;
+  }
+  return 0;
+}
+
 typedef struct {
   const curve_t* cv;
   u64 seed;

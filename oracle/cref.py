@@ -34,6 +34,8 @@ def load():
         lib.ark_msm_window_bits.argtypes = [sz]
         lib.ark_rng_scalars.restype = None
         lib.ark_rng_scalars.argtypes = [u64, sz, vp]
+        lib.ark_rng_scalars_fr.restype = C.c_int
+        lib.ark_rng_scalars_fr.argtypes = [C.c_int, u64, sz, vp]
         lib.ark_rng_points.restype = C.c_int
         lib.ark_rng_points.argtypes = [C.c_int, u64, sz, C.c_int, vp]
         lib.ark_fr_hadamard.restype = C.c_int
@@ -85,6 +87,13 @@ def msm(curve_id: int, bases_xy: np.ndarray, scalars: np.ndarray, is_inf: Option
 def rng_scalars(seed: int, n: int) -> np.ndarray:
     out = np.empty((n, 4), dtype=np.uint64)
     load().ark_rng_scalars(seed, n, _p(out))
+    return out
+
+
+def rng_frs(curve_id: int, seed: int, n: int) -> np.ndarray:
+    """the scalar stream of amsm_vec_random: uniform in [0, r) (oracle/pyref.py:rng_fr)"""
+    out = np.empty((n, 4), dtype=np.uint64)
+    assert load().ark_rng_scalars_fr(curve_id, seed, n, _p(out)) == 0
     return out
 
 

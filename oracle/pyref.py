@@ -319,7 +319,8 @@ def mont_constants(m: int, limbs: int) -> dict:
 # Deterministic synthetic inputs.  Counter-based splitmix64 so that Python (numpy),
 # C (oracle/ark_msm.c) and HIP (accumulation_amd/csrc/gen.hip) produce identical streams.
 #   word(seed, j) = mix(seed * 0xD1342543DE82EF95 + j * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019)
-#   scalar_i     = words 4i..4i+3 as LE u64 limbs, top limb masked to 62 bits (< 2^254 < r)
+#   scalar_i     = words 4i..4i+3 as LE u64 limbs, top limb masked to 62 bits (< 2^254 < r): the multiplier stream;
+#   rng_fr       = the scalar stream, uniform in [0, r) (round 6)
 # --------------------------------------------------------------------------------------
 
 
@@ -342,6 +343,24 @@ def rng_scalar(seed: int, i: int) -> int:
 
 def rng_scalars(seed: int, n: int) -> List[int]:
     return [rng_scalar(seed, i) for i in range(n)]
+
+
+def rng_fr(c: "Curve", seed: int, i: int) -> int:
+    """The SCALAR stream of amsm_vec_random since round 6 (accumulation_amd/csrc/rng.h:rng_scalar_fr): uniform in [0, r) by
+    rejection -- candidate t of scalar i = words (t << 40) + 4 i .. + 3 masked to 255 bits, the first one below r wins; after 64
+    rejections candidate 63 with bit 254 cleared.  rng_scalar above stays the 254-bit MULTIPLIER stream of rng_points."""
+    v = 0
+    for t in range(64):
+        limbs = [rng_word(seed, (t << 40) + 4 * i + k) for k in range(4)]
+        limbs[3] &= (1 << 63) - 1
+        v = limbs_to_int(limbs)
+        if v < c.r:
+            return v
+    return v & ((1 << 254) - 1)
+
+
+def rng_frs(c: "Curve", seed: int, n: int) -> List[int]:
+    return [rng_fr(c, seed, i) for i in range(n)]
 
 
 def rng_points(c: Curve, seed: int, n: int) -> List[Point]:

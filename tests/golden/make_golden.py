@@ -37,7 +37,7 @@ def case(c, name, pts, scalars, note=""):
 
 def seeded_case(c, name, seed_pts, seed_sc, n):
     pts = o.rng_points(c, seed_pts, n)
-    sc = o.rng_scalars(seed_sc, n)
+    sc = o.rng_frs(c, seed_sc, n)  # the scalar stream of amsm_vec_random: uniform in [0, r) (round 6)
     res = o.msm_pippenger(c, pts, sc)
     xy, inf = o.point_to_mont_limbs(c, res)
     return {"name": name, "n": n, "seed_points": seed_pts, "seed_scalars": seed_sc,

@@ -28,11 +28,11 @@ def test_msm_vectors_vs_oracles(cref, curve):
         if case["kind"] == "seeded":
             sp, ss, n = av.seeded_msm_inputs(c, case)
             xy = cref.rng_points(c.curve_id, sp, n)
-            sc = cref.rng_scalars(ss, n)
+            sc = cref.rng_frs(c.curve_id, ss, n)
             got, inf = cref.msm(c.curve_id, xy, sc, threads=8)
             assert h.np_to_point(c, got, inf) == av.pt(case["expected"]), ("seeded", n)
             if n <= 64:
-                assert o.msm_naive(c, o.rng_points(c, sp, n), o.rng_scalars(ss, n)) == av.pt(case["expected"])
+                assert o.msm_naive(c, o.rng_points(c, sp, n), o.rng_frs(c, ss, n)) == av.pt(case["expected"])
         else:
             pts, sc = [av.pt(p) for p in case["points"]], av.ints(case["scalars"])
             assert o.msm_naive(c, pts, sc) == av.pt(case["expected"]), case["name"]

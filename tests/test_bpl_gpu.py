@@ -218,7 +218,8 @@ def test_bls12_381_at_2p20(cref):
         ck = CommitterKey.generate(ctx, 0x5EED1002, N)
         assert ck.window_bits == 20
         xy, _ = ck.read()
-        sc = cref.rng_scalars(91, N)  # 45 % of these exceed 2^254: the recoding's carry lands in the 13th window
+        sc = cref.rng_frs(c.curve_id, 91, N)  # uniform in [0, r): 45 % of these exceed 2^254 -- the recoding's carry lands in the 13th window
+        assert 0.40 < float((sc[:, 3] >> np.uint64(62)).astype(bool).mean()) < 0.50
         got, inf = VariableBaseMSM.multi_scalar_mul(ck, sc)
         st = ctx.pipeline_stats()
         assert st["bucket_per_lane"] == 1 and st["fallbacks"] == 0

@@ -46,8 +46,8 @@ def _mirror_matches_oracle(cref, device):
 
     xy = cref.rng_points(c.curve_id, 0x5EED1001, n + 1)
     H = h.np_to_point(c, xy[n], 0)
-    a, b = cref.rng_scalars(11, n), cref.rng_scalars(12, n)
-    a2, b2 = cref.rng_scalars(13, n), cref.rng_scalars(14, n)
+    a, b = cref.rng_frs(c.curve_id, 11, n), cref.rng_frs(c.curve_id, 12, n)  # (FrVector::random: the scalar stream)
+    a2, b2 = cref.rng_frs(c.curve_id, 13, n), cref.rng_frs(c.curve_id, 14, n)
 
     def msm(sc):
         out_, inf = cref.msm(c.curve_id, xy[:n], h.scalars_to_np(sc), threads=4)

@@ -58,7 +58,7 @@ def test_golden_seeded_device_key(ctxs, c):
         xy, inf = ck.read(0, 8)
         exp_xy, _ = h.points_to_np(c, o.rng_points(c, case["seed_points"], 8))
         assert np.array_equal(xy, exp_xy) and not inf.any()
-        sc = h.scalars_to_np(o.rng_scalars(case["seed_scalars"], case["n"]))
+        sc = h.scalars_to_np(o.rng_frs(c, case["seed_scalars"], case["n"]))
         out, oinf = VariableBaseMSM.multi_scalar_mul(ck, sc)
         assert [hex(int(v)) for v in out] == case["expected_mont_limbs"], case["name"]
         # scalars generated on the device too

@@ -123,12 +123,21 @@ def test_seeded_streams_agree_and_match_golden(c, cref):
     """Python and C generate identical synthetic inputs; MSM over them matches the committed result."""
     g = h.load_golden()["curves"][c.name]
     assert cref.rng_scalars(77, 9).tolist() == h.scalars_to_np(o.rng_scalars(77, 9)).tolist()
+    # the scalar stream (round 6): uniform in [0, r) by rejection, the same in Python and C; every value below r, and the top bit
+    # (2^254) set about as often as r / 2^255 says (0.906 of BLS12-381's scalars lie below 2^255 * 0.906; Pallas: never set)
+    fr = cref.rng_frs(c.curve_id, 77, 4096)
+    assert fr[:64].tolist() == h.scalars_to_np(o.rng_frs(c, 77, 64)).tolist()
+    vals = h.np_to_ints(fr)
+    assert max(vals) < c.r
+    top = sum(v >> 254 for v in vals) / len(vals)
+    assert abs(top - (c.r - (1 << 254)) / c.r) < 0.03
+    assert abs(sum(vals) / len(vals) / c.r - 0.5) < 0.02
     pts_c = cref.rng_points(c.curve_id, 0x5EED1001, 12)
     pts_p, _ = h.points_to_np(c, o.rng_points(c, 0x5EED1001, 12))
     assert np.array_equal(pts_c, pts_p)
     for case in g["seeded"]:
         xy = cref.rng_points(c.curve_id, case["seed_points"], case["n"])
-        sc = cref.rng_scalars(case["seed_scalars"], case["n"])
+        sc = cref.rng_frs(c.curve_id, case["seed_scalars"], case["n"])
         out, oinf = cref.msm(c.curve_id, xy, sc, threads=4)
         assert [hex(int(v)) for v in out] == case["expected_mont_limbs"], case["name"]
 

@@ -29,7 +29,7 @@ def msm_cases(c):
     for i, n in enumerate([1, 2, 31, 32, 33, 255]):
         sp, ss = 0x5EEDA000 + i, 0x5EEDB000 + i
         cases.append({"kind": "seeded", "n": n, "seed_points": sp, "seed_scalars": ss,
-                      "expected": hp(o.msm_pippenger(c, o.rng_points(c, sp, n), o.rng_scalars(ss, n)))})
+                      "expected": hp(o.msm_pippenger(c, o.rng_points(c, sp, n), o.rng_frs(c, ss, n)))})
     pts = o.rng_points(c, 0x5EEDC000, 8)
     edge = [("all_zero_scalars", pts, [0] * 8), ("all_one_scalars", pts, [1] * 8), ("all_r_minus_1", pts, [c.r - 1] * 8),
             ("duplicate_bases", [pts[0]] * 8, o.rng_scalars(0x5EEDC001, 8)),

@@ -3,7 +3,8 @@
 //! NOT COMPILED in the build image (no Rust toolchain there) -- see Cargo.toml.  One file per vector kind:
 //!
 //!   ark_msm.json        VariableBaseMSM::multi_scalar_mul on both curves: seeded cases in the synthetic stream of
-//!                       accumulation_amd/csrc/rng.h (scalars: splitmix64 words masked to 254 bits; points: scalar * generator)
+//!                       accumulation_amd/csrc/rng.h (scalars: uniform in [0, r) by rejection of 255-bit candidates, `rng_frs`;
+//!                       points: 254-bit multiplier * generator)
 //!                       and explicit edge cases (0, 1, r - 1, duplicate and opposite bases, the identity)
 //!   ark_serialize.json  CanonicalSerialize of scalars and points (compressed and uncompressed), both curves
 //!   ark_poseidon.json   PoseidonSponge::<Fq>::new(): absorb / squeeze transcripts over every Absorbable the schemes use
@@ -39,6 +40,16 @@ fn rng_scalar_words(seed: u64, i: u64) -> [u64; 4] {
         w[k] = rng_word(seed, 4 * i + k as u64);
     }
     w[3] &= (1u64 << 62) - 1;
+    w
+}
+
+/// candidate `t` of scalar `i` of the SCALAR stream (rng.h: rng_scalar_fr; oracle/pyref.py: rng_fr): 255 bits
+fn rng_fr_words(seed: u64, i: u64, t: u64) -> [u64; 4] {
+    let mut w = [0u64; 4];
+    for k in 0..4 {
+        w[k] = rng_word(seed, (t << 40) + 4 * i + k as u64);
+    }
+    w[3] &= (1u64 << 63) - 1;
     w
 }
 
@@ -89,7 +100,7 @@ macro_rules! curve_impl {
                 }
             }
             pub fn scalar_from_words(w: [u64; 4]) -> Fr {
-                // the stream is 254 bits wide: below r on both curves (Pallas r = 2^254 + ..., BLS12-381 r = 0x73ed... x 2^240),
+                // the multiplier stream is 254 bits wide: below r on both curves (Pallas r = 2^254 + ..., BLS12-381 r = 0x73ed... x 2^240),
                 // so the reduction below never changes a value
                 let mut bytes = [0u8; 32];
                 for k in 0..4 {
@@ -99,6 +110,23 @@ macro_rules! curve_impl {
             }
             pub fn rng_scalars(seed: u64, n: usize) -> Vec<Fr> {
                 (0..n).map(|i| scalar_from_words(rng_scalar_words(seed, i as u64))).collect()
+            }
+            /// the scalar stream of amsm_vec_random: uniform in [0, r) -- the first 255-bit candidate below r (ark-ff 0.2's
+            /// `from_repr` returns None for a value that is not below the modulus); after 64 rejections candidate 63 with bit
+            /// 254 cleared (never reached in practice: probability < 2^-64)
+            pub fn rng_frs(seed: u64, n: usize) -> Vec<Fr> {
+                (0..n as u64)
+                    .map(|i| {
+                        for t in 0..64u64 {
+                            if let Some(x) = Fr::from_repr(<$bigint>::new(rng_fr_words(seed, i, t))) {
+                                return x;
+                            }
+                        }
+                        let mut w = rng_fr_words(seed, i, 63);
+                        w[3] &= (1u64 << 62) - 1;
+                        scalar_from_words(w)
+                    })
+                    .collect()
             }
             pub fn rng_points(seed: u64, n: usize) -> Vec<G> {
                 let g = G::prime_subgroup_generator();
@@ -113,7 +141,7 @@ macro_rules! curve_impl {
                 let mut cases: Vec<String> = Vec::new();
                 for (i, n) in [1usize, 2, 31, 32, 33, 255, 1000, 4096, 65536].iter().enumerate() {
                     let (sp, ss) = (0x5EED_A000u64 + i as u64, 0x5EED_B000u64 + i as u64);
-                    let r = msm(&rng_points(sp, *n), &rng_scalars(ss, *n));
+                    let r = msm(&rng_points(sp, *n), &rng_frs(ss, *n));
                     cases.push(format!(
                         "{{\"kind\": \"seeded\", \"n\": {}, \"seed_points\": {}, \"seed_scalars\": {}, \"expected\": {}}}",
                         n, sp, ss, json_point(&r, xy)
