@@ -59,6 +59,7 @@ def main() -> int:
     ap.add_argument("--no-precompute", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-schemes", action="store_true", help="skip the accumulations/sec lines (second half of the metric)")
+    ap.add_argument("--no-bls", action="store_true", help="skip config.pairs_per_s_bls12_381_2p20 (BASELINE config 3's MSM)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-gpu: functional check of the N > 1 path with every rank on GPU 0 (numbers meaningless)")
     ap.add_argument("--one-gpu", action="store_true")
@@ -364,6 +365,13 @@ def main() -> int:
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ctx, ck, vecs, curve_id, args, out.copy(), bool(inf.value), last.get("all"))
+        if world == 1 and not args.no_bls and args.log2n == 20 and args.curve == "pallas" and not args.no_precompute:
+            # BASELINE config 3's MSM (2^20 pairs, BLS12-381 G1: the 384-bit field path), after and outside the timed region
+            for v in vecs:
+                v.free()
+            ck.free()
+            ctx.trim()
+            result["config"].update(bls12_381_line(args, check=not args.no_cpu_baseline))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -378,6 +386,105 @@ def main() -> int:
                 result["accumulations_multi_device"] = scheme_rates([0] * world if args.one_gpu else list(range(world)))
         print(json.dumps(result), flush=True)
     return 0
+
+
+# accumulations/sec: (scheme, log2 size, profile_as options, key suffix, CPU leg) -- BASELINE.json's configs 1-5 in order, plus
+# the variants the `inputs` note explains.  CPU leg = (log2 size, shapes) of the SAME harness on the library's host backend
+# (`--device -1`: product code, never oracle/): the full size where one run fits the leg's time box on the GPU box's host, else
+# the largest size that does -- the entry names the size it ran; nothing is extrapolated.
+SCHEME_RUNS = (
+    ("trivial_pc_as", 10, ["--reps", "5"], "", (10, "both")),                                   # config 1 on the GPU context
+    ("trivial_pc_as", 10, ["--reps", "5", "--device", "-1"], "_host_backend", None),           # config 1 as it reads: no GPU
+    ("ipa_pc_as", 16, ["--reps", "3"], "", (16, "both")),                                       # config 2
+    ("ipa_pc_as", 20, ["--reps", "2", "--curve", "1"], "_bls12_381", (16, "n2")),               # config 3 (BLS12-381 G1)
+    ("r1cs_nark_as", 18, ["--reps", "3"], "", (18, "both")),                                    # config 4
+    ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"], "_uniform_witness", (18, "n2")),
+    ("hp_as", 22, ["--reps", "3"], "", (22, "n2")),                                             # config 5
+    ("hp_as", 22, ["--reps", "3", "--constant"], "_harness_constant_inputs", (20, "n2")),
+)
+CPU_LEG_TIMEOUT_S = 70  # per run; the runs go side by side on disjoint cores (cpu_scheme_rates)
+
+
+def _json_lines(stdout):
+    return [json.loads(line[5:]) for line in stdout.splitlines() if line.startswith("JSON ")]
+
+
+def _shape_key(r):
+    return "harness_1in_2acc_zk" if r["shape"].startswith("harness") else "n2_1in_1acc_nozk"
+
+
+def _scheme_entry(r):
+    rt = r["serialize_roundtrip_decides"]  # null when the harness skipped the check (--no-roundtrip)
+    return {"accumulations_per_s": round(r["accumulations_per_s"], 2), "prove_ms": round(r["prove_ms"], 3),
+            "verify_ms": round(r["verify_ms"], 3), "decide_ms": round(r["decide_ms"], 3),
+            "index_ms": round(r["index_ms"], 1), "zk": r["zk"], "sponge": r["sponge"],
+            "curve": "bls12_381_g1" if r.get("curve") == 1 else "pallas",
+            "accumulator_bytes": r["accumulator_bytes"],
+            "verified": bool(r["verified"] and r["decided"]),
+            "serialize_roundtrip": "skipped" if rt is None else bool(rt)}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_scheme_rates(exe, out):
+    """The CPU side of accumulations/sec (the reference's harness times prove / verify / decide on the CPU, examples/scaling-as.rs:94-122):
+    every GPU entry of `out` gets a `cpu` sub-object from the SAME profile_as command on the library's host backend (--device -1).  The
+    runs are separate processes with AMSM_HOST_THREADS helpers each, started side by side when the host has cores for all of them (a GPU
+    box: 128-256 cores), else one after the other; each bounded by CPU_LEG_TIMEOUT_S.  One repetition, no warm-up (--cold)."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [(scheme, lg, extra, tag, cpu) for scheme, lg, extra, tag, cpu in SCHEME_RUNS if cpu is not None]
+    cores = os.cpu_count() or 1
+    threads = max(1, min(16, cores // len(jobs) if cores >= 4 * len(jobs) else cores))  # caller + helpers per run
+    side_by_side = max(1, min(len(jobs), cores // threads))
+    out["cpu"] = {"backend": "libamsm.so host backend (AMSM_DEVICE_HOST: window-parallel signed-digit Pippenger, vector loops on the host pool; "
+                             "product code -- not oracle/, not ark-ec)", "threads_per_run": threads, "runs_side_by_side": side_by_side,
+                  "host_cores": cores, "cpu_model": cpu_model(), "repetitions": 1,
+                  "note": "`cpu.log2_size` names the size the CPU run used when the full size does not fit the time box; rates are never extrapolated"}
+
+    def run(job):
+        scheme, lg, extra, tag, (cpu_lg, shapes) = job
+        args = [a for a in extra if a not in ("--device", "-1")]
+        args = [a for i, a in enumerate(args) if not (a == "--reps" or (i > 0 and args[i - 1] == "--reps"))]
+        cmd = [exe, scheme, str(cpu_lg), str(cpu_lg), "--sponge", "poseidon", "--device", "-1", "--reps", "1", "--cold", "--no-roundtrip",
+               "--shape", shapes, *args]
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=CPU_LEG_TIMEOUT_S,
+                               env=dict(os.environ, AMSM_HOST_THREADS=str(threads - 1)))
+            if p.returncode != 0:
+                raise RuntimeError(p.stderr[-300:])
+            return job, _json_lines(p.stdout), time.perf_counter() - t0, None
+        except Exception as e:  # noqa: BLE001
+            return job, [], time.perf_counter() - t0, f"{type(e).__name__}: {str(e)[:200]}"
+
+    with ThreadPoolExecutor(max_workers=side_by_side) as ex:
+        results = list(ex.map(run, jobs))
+    for (scheme, lg, extra, tag, (cpu_lg, shapes)), lines, wall, err in results:
+        for shape in ("harness_1in_2acc_zk", "n2_1in_1acc_nozk"):
+            key = f"{scheme}_2^{lg}_{shape}{tag}"
+            if key not in out or not isinstance(out[key], dict):
+                continue
+            r = next((x for x in lines if _shape_key(x) == shape), None)
+            if r is None:
+                out[key]["cpu"] = ({"error": err, "log2_size": cpu_lg} if err else
+                                   {"not_run": f"the CPU leg runs the {shapes} shape of this entry only (time box)", "log2_size": cpu_lg})
+                continue
+            e = {"log2_size": cpu_lg, "full_size": cpu_lg == lg, "accumulations_per_s": round(r["accumulations_per_s"], 4),
+                 "prove_ms": round(r["prove_ms"], 2), "verify_ms": round(r["verify_ms"], 2), "decide_ms": round(r["decide_ms"], 2),
+                 "index_ms": round(r["index_ms"], 1), "verified": bool(r["verified"] and r["decided"]), "threads": threads,
+                 "run_wall_s": round(wall, 1)}
+            if cpu_lg == lg:
+                e["gpu_over_cpu_prove"] = round(r["prove_ms"] / out[key]["prove_ms"], 1)
+            out[key]["cpu"] = e
 
 
 def scheme_rates(devices=None):
@@ -411,15 +518,9 @@ def scheme_rates(devices=None):
                          "with a random witness (A z, B z, C z uniform: the windowed pipelines; not the reference's harness).  The "
                          "`value` of this bench line is measured on uniform random scalars only")
         gave_up = False
-        for scheme, lg, extra in (("trivial_pc_as", 10, ["--reps", "5"]), ("trivial_pc_as", 10, ["--reps", "5", "--device", "-1"]),
-                                  ("ipa_pc_as", 16, ["--reps", "3"]),
-                                  ("r1cs_nark_as", 18, ["--reps", "3"]), ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"]),
-                                  ("hp_as", 22, ["--reps", "3"]), ("hp_as", 22, ["--reps", "3", "--constant"])):
-            tag = "_harness_constant_inputs" if "--constant" in extra else ("_uniform_witness" if "--uniform" in extra else "")
-            if "--device" in extra:  # BASELINE config 1 as it reads ("plumbing, no GPU"): the library's host backend behind the same ABI
-                if multi:
-                    continue
-                tag = "_host_backend"
+        for scheme, lg, extra, tag, _cpu in SCHEME_RUNS:
+            if multi and ("--device" in extra or "--curve" in extra):
+                continue  # the host backend has no devices to spread over; BASELINE config 3 names ONE GPU
             for sponge in ("poseidon", "sha256"):
                 if (tag or multi) and sponge == "sha256":
                     continue
@@ -437,24 +538,16 @@ def scheme_rates(devices=None):
                         raise
                     if p.returncode != 0:
                         raise RuntimeError(p.stderr[-300:])
-                    for line in p.stdout.splitlines():
-                        if not line.startswith("JSON "):
-                            continue
-                        r = json.loads(line[5:])
-                        shape = "harness_1in_2acc_zk" if r["shape"].startswith("harness") else "n2_1in_1acc_nozk"
+                    for r in _json_lines(p.stdout):
+                        shape = _shape_key(r)
                         if sponge == "sha256":  # the stand-in: prove time only, never the reported rate
                             out.setdefault("sha256_standin_prove_ms", {})[f"{scheme}_2^{lg}_{shape}{tag}"] = round(r["prove_ms"], 3)
                             continue
-                        rt = r["serialize_roundtrip_decides"]  # null when the harness skipped the check (--no-roundtrip)
-                        out[f"{scheme}_2^{lg}_{shape}{tag}"] = {
-                            "accumulations_per_s": round(r["accumulations_per_s"], 2), "prove_ms": round(r["prove_ms"], 3),
-                            "verify_ms": round(r["verify_ms"], 3), "decide_ms": round(r["decide_ms"], 3),
-                            "index_ms": round(r["index_ms"], 1), "zk": r["zk"], "sponge": r["sponge"],
-                            "accumulator_bytes": r["accumulator_bytes"],
-                            "verified": bool(r["verified"] and r["decided"]),
-                            "serialize_roundtrip": "skipped" if rt is None else bool(rt)}
+                        out[f"{scheme}_2^{lg}_{shape}{tag}"] = _scheme_entry(r)
                 except Exception as e:  # noqa: BLE001
                     out[f"{scheme}_2^{lg}{tag}" + ("" if sponge == "poseidon" else "_sha256")] = {"error": f"{type(e).__name__}: {e}"}
+        if not multi:
+            cpu_scheme_rates(exe, out)
     except Exception as e:  # noqa: BLE001
         out["error"] = f"{type(e).__name__}: {e}"
     return out
@@ -512,6 +605,68 @@ def main_single_process(args) -> int:
     print(json.dumps(result), flush=True)
     ctx.close()
     return 0
+
+
+def bls12_381_line(args, check=True):
+    """config.pairs_per_s_bls12_381_2p20: the same batch protocol as `value` (K steps = one amsm_msm_batch_device call after
+    preheat + W warm-up steps) on a 2^20-pair BLS12-381 G1 MSM, scalars uniform in [0, r) (0.45 of them above 2^254: the recoding's
+    carry reaches a 13th window), every MSM of the batch compared bit for bit with the CPU restatement.  Never fails the line."""
+    import ctypes as C
+
+    import torch
+
+    from accumulation_amd import CommitterKey, Context, VariableBaseMSM, ffi
+    from accumulation_amd.engine import _ptr
+    out = {}
+    try:
+        n, n_distinct = 1 << 20, 4
+        ctx = Context(ffi.AMSM_BLS12_381_G1, device=0)
+        t0 = time.time()
+        ck = CommitterKey.generate(ctx, SEED_POINTS + 1, n, ffi.AMSM_BASES_PRECOMPUTE)
+        t_key = time.time() - t0
+        vecs = [ctx.random_vector(SEED_SCALARS + 1000 * j + 7, n, mont=False) for j in range(n_distinct)]
+
+        def run(k):
+            return VariableBaseMSM.multi_scalar_mul_batch(ck, [vecs[i % n_distinct] for i in range(k)], mont=False)
+
+        run(16)
+        run(args.warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pts, infs = run(args.steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        o1 = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+        i1 = C.c_uint8(0)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ffi.check(ctx._lib.amsm_msm_device(ctx._h, ck._h, 0, vecs[0].ptr, n, 0, _ptr(o1), C.byref(i1)), "amsm_msm_device")
+        ms_sync = (time.perf_counter() - t0) / 5 * 1e3
+        hv = [v.download() for v in vecs]
+        out = {"pairs_per_s_bls12_381_2p20": round(n * args.steps / el, 1), "ms_per_msm_bls12_381_2p20": round(el / args.steps * 1e3, 4),
+               "bls12_381_2p20": {"ms_per_msm_synchronous_call": round(ms_sync, 4), "key_setup_s": round(t_key, 3),
+                                  "window_bits": int(ck.window_bits), "key_bytes": ck.memory()["table"],
+                                  "scalars": "uniform in [0, r)", "scalars_above_2^254": round(float((hv[0][:, 3] >> np.uint64(62)).astype(bool).mean()), 4),
+                                  "pipeline_stats": ctx.pipeline_stats(), "steps": args.steps,
+                                  "seeds": {"scalars": SEED_SCALARS + 7, "points": SEED_POINTS + 1}}}
+        if check:
+            from oracle import cref
+            xy, _ = ck.read(0, n)
+            threads = max(1, min(os.cpu_count() or 1, -(-255 // cref.load().ark_msm_window_bits(n))))
+            t0 = time.perf_counter()
+            refs = [cref.msm(ffi.AMSM_BLS12_381_G1, xy, h, threads=threads) for h in hv]
+            t_cpu = time.perf_counter() - t0
+            ok = all(np.array_equal(pts[k], refs[k % n_distinct][0]) and bool(infs[k]) == bool(refs[k % n_distinct][1]) for k in range(len(pts)))
+            ok = ok and np.array_equal(o1, refs[0][0])
+            out["bls12_381_2p20"].update({"gpu_result_bit_exact_vs_cpu": bool(ok), "timed_batch_msms_checked": len(pts),
+                                          "cpu_pairs_per_s": round(n_distinct * n / t_cpu, 1), "cpu_threads": threads, "cpu_kind": "port"})
+        for v in vecs:
+            v.free()
+        ck.free()
+        ctx.close()
+    except Exception as e:  # noqa: BLE001
+        out["bls12_381_2p20_error"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def metric_name(args):

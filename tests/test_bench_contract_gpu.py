@@ -35,7 +35,26 @@ def test_default_line_n1(built_lib):
     assert d["cpu_baseline"]["timed_batch_msms_checked"] == 12  # every MSM of the timed batch against the CPU result
     acc = {k: v for k, v in d["accumulations"].items() if isinstance(v, dict) and "accumulations_per_s" in v}
     # 4 schemes x 2 shapes + hp_as again with the reference harness's constant inputs (the two-valued form)
-    assert len(acc) == 14 and all(v.get("verified") for v in acc.values()), d["accumulations"]  # (incl. the two uniform-witness r1cs_nark_as lines and trivial_pc_as on the host backend)
+    # (incl. the two uniform-witness r1cs_nark_as lines, trivial_pc_as on the host backend and -- round 6 -- config 3: ipa_pc_as at 2^20 on BLS12-381)
+    assert len(acc) == 16 and all(v.get("verified") for v in acc.values()), d["accumulations"]
+    assert acc["ipa_pc_as_2^20_n2_1in_1acc_nozk_bls12_381"]["curve"] == "bls12_381_g1"
+    # the CPU side of every entry: the same harness on the library's host backend, size and threads named, no silent extrapolation
+    cpu = d["accumulations"]["cpu"]
+    assert cpu["threads_per_run"] >= 1 and cpu["cpu_model"] and cpu["host_cores"] >= 1
+    for k, v in acc.items():
+        if k.endswith("_host_backend"):
+            assert "cpu" not in v
+            continue
+        c = v["cpu"]
+        assert "log2_size" in c and ("not_run" in c or (c["verified"] is True and c["accumulations_per_s"] > 0)), (k, c)
+        assert ("gpu_over_cpu_prove" in c) == bool(c.get("full_size")), (k, c)
+    for k in ("trivial_pc_as_2^10_harness_1in_2acc_zk", "ipa_pc_as_2^16_n2_1in_1acc_nozk", "r1cs_nark_as_2^18_n2_1in_1acc_nozk",
+              "hp_as_2^22_n2_1in_1acc_nozk", "ipa_pc_as_2^20_n2_1in_1acc_nozk_bls12_381"):
+        assert acc[k]["cpu"].get("verified") is True, (k, acc[k]["cpu"])
+    # BASELINE config 3's MSM beside the headline: BLS12-381 G1 at 2^20, scalars uniform in [0, r), bit-exact
+    cfg = d["config"]
+    assert cfg["pairs_per_s_bls12_381_2p20"] > 1e8 and cfg["bls12_381_2p20"]["gpu_result_bit_exact_vs_cpu"] is True
+    assert cfg["bls12_381_2p20"]["timed_batch_msms_checked"] == 12 and 0.40 < cfg["bls12_381_2p20"]["scalars_above_2^254"] < 0.50
     assert sum(1 for k in acc if k.endswith("_harness_constant_inputs")) == 2
     assert all(v["sponge"] == "poseidon" for v in acc.values())  # the reference's sponge, not the SHA-256 stand-in
     assert len(d["accumulations"]["sha256_standin_prove_ms"]) == 8

@@ -9,7 +9,9 @@
 //
 //   profile_as <scheme: trivial_pc_as | ipa_pc_as | hp_as | r1cs_nark_as | all> <log_min> <log_max>
 //              [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] [--curve 0|1] [--constant] [--uniform] [--no-roundtrip]
-//              [--device D | --devices a,b,..] [--seed S] [--dump FILE]
+//              [--device D | --devices a,b,..] [--seed S] [--dump FILE] [--cold]
+//   --cold       no warm-up repetitions (the prove before the timed ones, the decide before the timed one): the CPU legs of
+//                bench.py, where a repetition costs seconds and there are no clocks or caches to warm.
 //   --devices 0,1,2,3  one context over four GPUs (sharded keys; a repeated id puts two shards on one GPU).
 //   --device -1  runs on the library's host backend (amsm.h AMSM_DEVICE_HOST: BASELINE.json config 1 "plumbing, no GPU").
 //   --seed S     varies the harness's random stream and the synthetic vectors (0: the bench's inputs).
@@ -37,7 +39,7 @@ static double ms_since(Clock::time_point t0) { return std::chrono::duration<doub
 struct Opt {
   std::string scheme = "all", shape = "both", sponge = "sha256";
   int log_min = 10, log_max = 10, reps = 3, curve = AMSM_PALLAS;
-  bool constant = false, roundtrip = true;
+  bool constant = false, roundtrip = true, cold = false;
   bool uniform = false;  // r1cs_nark_as: a circuit whose A z, B z, C z are uniform random vectors (see profile_nark_as)
   int device = 0;
   std::vector<int> devices;  // --devices a,b,..: one multi-device context (sharded keys), amsm.h amsm_ctx_create_multi
@@ -97,10 +99,11 @@ static void report(const Opt& o, const char* scheme, int log_size, const char* s
   printf("JSON {\"kind\": \"profile_as\", \"scheme\": \"%s\", \"%s\": %d, \"shape\": \"%s\", \"zk\": %s, \"sponge\": \"%s\", "
          "\"index_ms\": %.3f, \"prove_ms\": %.3f, \"verify_ms\": %.3f, \"decide_ms\": %.3f, \"accumulations_per_s\": %.3f, "
          "\"accumulator_bytes\": %zu, \"instance_bytes\": %zu, \"witness_bytes\": %zu, \"verified\": %s, \"decided\": %s, "
-         "\"serialize_roundtrip_decides\": %s, \"reps\": %d}\n",
+         "\"serialize_roundtrip_decides\": %s, \"reps\": %d, \"curve\": %d, \"host_backend\": %s, \"host_pool_threads\": %d}\n",
          scheme, size_name, log_size, shape, zk ? "true" : "false", o.sponge.c_str(), r.index_ms, r.prove_ms, r.verify_ms,
          r.decide_ms, 1000.0 / r.prove_ms, r.acc_bytes, r.inst_bytes, r.wit_bytes, r.verified ? "true" : "false",
-         r.decided ? "true" : "false", !o.roundtrip ? "null" : (r.roundtrip ? "true" : "false"), o.reps);
+         r.decided ? "true" : "false", !o.roundtrip ? "null" : (r.roundtrip ? "true" : "false"), o.reps, o.curve,
+         (o.devices.size() < 2 && o.device < 0) ? "true" : "false", amsm_host_threads());
   fflush(stdout);
 }
 
@@ -120,7 +123,7 @@ static double median_ms(int reps, F&& f) {
 template <class F>
 static double timed_proves(const Opt& o, F&& prove_once) {
   if (!o.dump.empty()) return median_ms(1, prove_once);
-  prove_once();
+  if (!o.cold) prove_once();
   return median_ms(o.reps, prove_once);
 }
 
@@ -166,7 +169,7 @@ static void profile_hp(const Opt& o, int lg, bool harness_shape) {
   t0 = Clock::now();
   r.verified = AS::verify(ctx, keys.verifier_key, ii, oi, res.first.instance, res.second);
   r.verify_ms = ms_since(t0);
-  AS::decide(*keys.decider_key, res.first);
+  if (!o.cold) AS::decide(*keys.decider_key, res.first);
   t0 = Clock::now();
   r.decided = AS::decide(*keys.decider_key, res.first);
   r.decide_ms = ms_since(t0);
@@ -250,7 +253,7 @@ static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
   t0 = Clock::now();
   r.verified = AS::verify(ctx, keys.vk, ii, oi, res.first.instance, res.second);
   r.verify_ms = ms_since(t0);
-  AS::decide(*keys.dk, res.first);
+  if (!o.cold) AS::decide(*keys.dk, res.first);
   t0 = Clock::now();
   r.decided = AS::decide(*keys.dk, res.first);
   r.decide_ms = ms_since(t0);
@@ -360,7 +363,7 @@ static void profile_ipa(const Opt& o, int lg, bool harness_shape) {
   t0 = Clock::now();
   r.verified = AS::verify(ctx, keys.vk, inputs, old, res.first, res.second);
   r.verify_ms = ms_since(t0);
-  AS::decide(keys.dk, res.first);
+  if (!o.cold) AS::decide(keys.dk, res.first);
   t0 = Clock::now();
   r.decided = AS::decide(keys.dk, res.first);
   r.decide_ms = ms_since(t0);
@@ -409,7 +412,7 @@ static void profile_trivial(const Opt& o, int lg, bool harness_shape) {
   t0 = Clock::now();
   r.verified = AS::verify(ctx, keys.verifier_key, ii, oi, res.first.instance, res.second);
   r.verify_ms = ms_since(t0);
-  AS::decide(keys.prover_key, res.first);
+  if (!o.cold) AS::decide(keys.prover_key, res.first);
   t0 = Clock::now();
   r.decided = AS::decide(keys.prover_key, res.first);
   r.decide_ms = ms_since(t0);
@@ -453,7 +456,7 @@ int main(int argc, char** argv) {
   Opt o;
   if (argc < 4) {
     fprintf(stderr, "usage: %s <scheme|all> <log_min> <log_max> [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] "
-                    "[--curve 0|1] [--constant] [--uniform] [--no-roundtrip] [--device D | --devices a,b,..] [--seed S] [--dump FILE]\n", argv[0]);
+                    "[--curve 0|1] [--constant] [--uniform] [--no-roundtrip] [--device D | --devices a,b,..] [--seed S] [--dump FILE] [--cold]\n", argv[0]);
     return 2;
   }
   o.scheme = argv[1];
@@ -468,6 +471,7 @@ int main(int argc, char** argv) {
     else if (a == "--constant") o.constant = true;
     else if (a == "--uniform") o.uniform = true;
     else if (a == "--no-roundtrip") o.roundtrip = false;
+    else if (a == "--cold") o.cold = true;
     else if (a == "--device" && i + 1 < argc) o.device = atoi(argv[++i]);
     else if (a == "--devices" && i + 1 < argc) {
       for (const char* p = argv[++i]; *p;) {
