@@ -16,12 +16,12 @@ def test_cpu_leg_fills_every_entry(built_lib, monkeypatch):
     libdir = os.path.join(ROOT, "accumulation_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "profile_as.cpp"),
                            "-o", exe, "-L", libdir, "-l:libamsm.so", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
-    runs = (("trivial_pc_as", 10, ["--reps", "5"], "", (6, "both")),
+    runs = (("trivial_pc_as", 10, ["--reps", "5"], "", 6),
             ("trivial_pc_as", 10, ["--reps", "5", "--device", "-1"], "_host_backend", None),
-            ("ipa_pc_as", 16, ["--reps", "3"], "", (7, "both")),
-            ("ipa_pc_as", 20, ["--reps", "2", "--curve", "1"], "_bls12_381", (6, "n2")),
-            ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"], "_uniform_witness", (8, "n2")),
-            ("hp_as", 9, ["--reps", "3"], "", (9, "n2")))
+            ("ipa_pc_as", 16, ["--reps", "3"], "", 7),
+            ("ipa_pc_as", 20, ["--reps", "2", "--curve", "1"], "_bls12_381", 6),
+            ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"], "_uniform_witness", 8),
+            ("hp_as", 9, ["--reps", "3"], "", 9))
     monkeypatch.setattr(bench, "SCHEME_RUNS", runs)
     out = {}
     for scheme, lg, _, tag, _cpu in runs:
@@ -32,11 +32,10 @@ def test_cpu_leg_fills_every_entry(built_lib, monkeypatch):
     assert "cpu" not in out["trivial_pc_as_2^10_n2_1in_1acc_nozk_host_backend"]  # that entry IS the host backend
     for key in ("trivial_pc_as_2^10_harness_1in_2acc_zk", "trivial_pc_as_2^10_n2_1in_1acc_nozk", "ipa_pc_as_2^16_harness_1in_2acc_zk",
                 "ipa_pc_as_2^16_n2_1in_1acc_nozk", "ipa_pc_as_2^20_n2_1in_1acc_nozk_bls12_381",
-                "r1cs_nark_as_2^18_n2_1in_1acc_nozk_uniform_witness", "hp_as_2^9_n2_1in_1acc_nozk"):
+                "r1cs_nark_as_2^18_n2_1in_1acc_nozk_uniform_witness", "r1cs_nark_as_2^18_harness_1in_2acc_zk_uniform_witness",
+                "hp_as_2^9_n2_1in_1acc_nozk"):
         c = out[key]["cpu"]
         assert c["verified"] is True and c["accumulations_per_s"] > 0 and c["threads"] == out["cpu"]["threads_per_run"], (key, c)
         assert c["full_size"] == (key.startswith("hp_as")), key
         assert ("gpu_over_cpu_prove" in c) == c["full_size"]  # a ratio only where both sides ran the same size
-    # shapes the time box leaves out say so instead of carrying a number
-    assert "not_run" in out["hp_as_2^9_harness_1in_2acc_zk"]["cpu"]
-    assert "not_run" in out["ipa_pc_as_2^20_harness_1in_2acc_zk_bls12_381"]["cpu"]
+    assert out["hp_as_2^9_harness_1in_2acc_zk"]["cpu"]["verified"] and out["ipa_pc_as_2^20_harness_1in_2acc_zk_bls12_381"]["cpu"]["log2_size"] == 6
