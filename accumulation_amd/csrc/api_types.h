@@ -21,6 +21,7 @@ struct DevBuf {
 namespace tune {
 constexpr int K0_MAX = 32;                 // largest chunk of accumulate L0 (24 -> 805, 32 -> 811-816 M pairs/s in 2^20 batches)
 constexpr amsm::u32 K1 = 1024;             // buckets with more partials than this go to the workgroup-per-bucket path (extreme skew)
+constexpr size_t ONESHOT_RANGE = (size_t)1 << 19;  // amsm_msm_oneshot: pairs per range (upload of range j + 1 beside the MSM of range j)
 constexpr int TAIL_QUAD_HIDDEN_LOG2 = 17;  // bucket tables up to 2^this take the quad tail inside a batch too (2^16 234 -> 283 M pairs/s)
 }  // namespace tune
 
@@ -224,6 +225,9 @@ struct amsm_ctx {
   DevBuf stage_ring[STAGE_RING];
   hipEvent_t up_ev[STAGE_RING] = {};
   hipStream_t s_copy = nullptr;
+  // amsm_msm_oneshot (round 6): the generators arrive WITH the call (`multi_scalar_mul(&[G], &[BigInt])`); they are imported range by
+  // range into this grow-only buffer (the call's temporary plain key) behind the copy stream, and their infinity flags here
+  DevBuf oneshot_table, oneshot_inf;
   DevBuf xyzz_scratch;  // unconverted sums of large key folds / precompute levels (launch.h: batch_affine_pays)
   // two-valued device vectors (api_pipeline.inc: msm_two_valued_pass): every scalar is 0 or one value v -> v * (sum of the
   // generators with a non-zero scalar), on its own stream beside the batch's other MSMs.  AMSM_TWO_VALUED=0 turns it off.

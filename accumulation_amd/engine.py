@@ -460,6 +460,22 @@ class VariableBaseMSM:
         return out, bool(inf.value)
 
     @staticmethod
+    def multi_scalar_mul_oneshot(ctx, bases_xy: np.ndarray, scalars: np.ndarray, bases_is_inf=None, mont: bool = False
+                                 ) -> Tuple[np.ndarray, bool]:
+        """`VariableBaseMSM::multi_scalar_mul(&[G], &[BigInt])` literally: host bases AND host scalars belong to this call only
+        (amsm_msm_oneshot); min(len(bases), len(scalars)) pairs, as ark-ec takes them."""
+        xy = np.ascontiguousarray(bases_xy, dtype=np.uint64).reshape(-1, 2 * ctx.fq_limbs)
+        s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        flags = None if bases_is_inf is None else np.ascontiguousarray(bases_is_inf, dtype=np.uint8)
+        assert flags is None or flags.shape[0] == xy.shape[0]
+        out = np.zeros((2 * ctx.fq_limbs,), dtype=np.uint64)
+        inf = C.c_uint8(0)
+        ffi.check(ctx._lib.amsm_msm_oneshot(ctx._h, _ptr(xy) if xy.size else None, None if flags is None else _ptr(flags), xy.shape[0],
+                                            _ptr(s) if s.size else None, s.shape[0], 1 if mont else 0, _ptr(out), C.byref(inf)),
+                  "amsm_msm_oneshot")
+        return out, bool(inf.value)
+
+    @staticmethod
     def multi_scalar_mul_batch(bases: CommitterKey, vectors: Sequence[FrVector], mont: bool = True, base_off: int = 0):
         if hasattr(bases, "sharded"):  # dist.ShardedCommitterKey: per-rank partials + one all-gather
             assert base_off == 0

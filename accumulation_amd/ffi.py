@@ -132,6 +132,7 @@ SIGNATURES = {
     "amsm_dev_free": (C.c_int, [_vp, _vp]),
     "amsm_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),
     "amsm_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "amsm_msm_oneshot": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_vec_random": (C.c_int, [_vp, C.c_uint64, _sz, C.c_int, _vp]),
     "amsm_vec_hadamard": (C.c_int, [_vp, _vp, _vp, _vp, _sz]),
     "amsm_vec_combine": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _vp, _sz, _vp, _sz]),

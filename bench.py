@@ -211,8 +211,9 @@ def main() -> int:
         ms_host = (time.perf_counter() - t1) / 5 * 1e3
         # ... and the same host slices handed over back to back, the way the reference's provers call `commit`
         # (src/hp_as/mod.rs:372-385): amsm_msm_batch overlaps the upload of vector v + 1 with MSM v
-        ms_host_batch = pipe = plain_rate = witness_rate = ms_dev_batch12 = None
+        ms_host_batch = pipe = plain_rate = witness_rate = ms_dev_batch12 = oneshot = None
         if world == 1:
+            oneshot = oneshot_line(ctx, ck, h_scalars, n, out.copy(), bool(inf.value))
             h_vecs = [v.download() for v in vecs]
             VariableBaseMSM.multi_scalar_mul_batch_host(ck, [h_vecs[i % n_distinct] for i in range(3)])
             reps = 12
@@ -319,6 +320,10 @@ def main() -> int:
                 # no precomputed multiples (one copy of the key, a bucket set per window): the variable-base rate
                 "pairs_per_s_plain_key": None if plain_rate is None else round(plain_rate, 1),
                 "pairs_per_s_plain_key_witness_10pct_booleans": None if witness_rate is None else round(witness_rate, 1),
+                # the ark-ec call shape itself: multi_scalar_mul(&[G], &[BigInt]) with BOTH slices in host memory, nothing resident
+                # (amsm_msm_oneshot): PCIe-bound -- its rate against 96 B per pair over the H2D rate measured in this run
+                "pairs_per_s_oneshot_host_bases": None if oneshot is None else oneshot.get("pairs_per_s"),
+                "oneshot_host_bases": oneshot,
                 "key_bytes": key_bytes(ck, ctx, n),
                 "window_bits": int(ck.window_bits),
                 "pipeline": ("bucket-per-lane (k_prep_local_t + k_accum_bpl; skewed scalars re-run chunked)"
@@ -607,6 +612,48 @@ def main_single_process(args) -> int:
     print(json.dumps(result), flush=True)
     ctx.close()
     return 0
+
+
+def oneshot_line(ctx, ck, h_scalars, n, ref_xy, ref_inf):
+    """amsm_msm_oneshot on the bench inputs: generators (read back from the key: C-ABI Montgomery limbs, as a Rust `&[G]` holds them)
+    and scalars both in pageable host memory, five blocking calls; the result must equal the resident-key MSM's.  Beside it the
+    link: one blocking upload of the same 96 B per pair, so that the line says what fraction of the PCIe bound the call reaches."""
+    import ctypes as C
+
+    from accumulation_amd import VariableBaseMSM
+    from accumulation_amd.engine import _ptr
+    try:
+        xy, inf = ck.read(0, n)
+        assert not inf.any()
+        got, ginf = VariableBaseMSM.multi_scalar_mul_oneshot(ctx, xy, h_scalars)  # (sizes the one-shot buffer)
+        if not (np.array_equal(got, ref_xy) and bool(ginf) == bool(ref_inf)):
+            return {"error": "one-shot MSM differs from the resident-key MSM"}
+        t = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            VariableBaseMSM.multi_scalar_mul_oneshot(ctx, xy, h_scalars)
+            t.append(time.perf_counter() - t0)
+        ms = sorted(t)[len(t) // 2] * 1e3
+        d = C.c_void_p()
+        nbytes = xy.nbytes + h_scalars.nbytes
+        both = np.concatenate([xy.reshape(-1), h_scalars.reshape(-1)])
+        ffi_lib = ctx._lib
+        if ffi_lib.amsm_dev_alloc(ctx._h, nbytes, C.byref(d)) != 0:
+            return {"pairs_per_s": round(n / (ms * 1e-3), 1), "ms_per_call": round(ms, 4)}
+        ffi_lib.amsm_dev_upload(ctx._h, d, _ptr(both), nbytes)
+        t = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ffi_lib.amsm_dev_upload(ctx._h, d, _ptr(both), nbytes)
+            t.append(time.perf_counter() - t0)
+        ffi_lib.amsm_dev_free(ctx._h, d)
+        up_ms = sorted(t)[len(t) // 2] * 1e3
+        return {"pairs_per_s": round(n / (ms * 1e-3), 1), "ms_per_call": round(ms, 4), "bytes_per_pair": nbytes // n,
+                "h2d_ms_same_bytes": round(up_ms, 4), "h2d_GB_per_s": round(nbytes / (up_ms * 1e-3) / 1e9, 2),
+                "fraction_of_h2d_bound": round(up_ms / ms, 3), "ranges": -(-n // (1 << 19)),
+                "note": "pageable host slices; key = none (plain generators imported per call, no precomputed multiples)"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def bls12_381_line(args, check=True):

@@ -235,6 +235,18 @@ void amsm_bases_free(amsm_bases* bases);
  * out_xy_mont: 2 * limbs u64 (zeroed when the result is the identity); out_is_inf: 1 byte. */
 int amsm_msm(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const uint64_t* scalars, size_t n,
              int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
+/* The literal `VariableBaseMSM::multi_scalar_mul(bases: &[G], scalars: &[BigInt]) -> G::Projective` (ext, ark-ec ^0.2.0,
+ * Cargo.toml:15; SURVEY.md section 8(b) "where a replacement can attach (1)": a `[patch]` of ark-ec's msm body): BOTH slices are
+ * host memory and belong to this call only -- no amsm_bases handle, nothing left resident (the generators pass through a
+ * grow-only buffer of the context that amsm_ctx_trim releases).  Uses min(n_bases, n_scalars) pairs like ark-ec; identity bases
+ * (is_inf[i] != 0, or x = y = 0) and zero scalars contribute nothing; n = 0 returns the identity.  Ranges of 2^19 pairs: the
+ * generators (64 / 96 B each) and scalars (32 B) of range j + 1 cross the link while range j's MSM runs over a plain key (no
+ * precomputed multiples: they would cost more than the MSM), so a long call is bound by the link -- 96 B per Pallas pair -- not by
+ * upload + MSM in series (bench.py: config.pairs_per_s_oneshot_host_bases and its fraction of the measured H2D rate).  A caller
+ * whose generators are a static committer key should amsm_bases_load them ONCE instead.
+ * Multi-device contexts split the pairs over the devices; the host backend computes it on the host cores. */
+int amsm_msm_oneshot(amsm_ctx* ctx, const uint64_t* bases_xy_mont, const uint8_t* bases_is_inf, size_t n_bases,
+                     const uint64_t* scalars, size_t n_scalars, int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
 /* Same with the scalar vector already resident in HBM (device pointer, n * 32 bytes, 16-byte
  * aligned) -- the form the field-vector kernels below feed, and the form bench.py times. */
 int amsm_msm_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_off, const void* d_scalars, size_t n,

@@ -155,6 +155,19 @@ struct VariableBaseMSM {
     out.infinity = inf != 0;
     return out;
   }
+  // the ark-ec call shape itself: `multi_scalar_mul(bases: &[G], scalars: &[BigInt])` -- both host slices, nothing kept
+  // (amsm_msm_oneshot).  bases_xy: n * 2 * limbs u64 (x_mont | y_mont), is_inf: n flags or null; min(n_bases, scalars.size()) pairs.
+  static Affine multi_scalar_mul(Context& ctx, const uint64_t* bases_xy, const uint8_t* is_inf, size_t n_bases,
+                                 const std::vector<Fr>& scalars) {
+    Affine out;
+    out.xy.assign(2 * (size_t)ctx.fq_limbs(), 0);
+    uint8_t inf = 0;
+    check(amsm_msm_oneshot(ctx.get(), bases_xy, is_inf, n_bases, reinterpret_cast<const uint64_t*>(scalars.data()), scalars.size(), 0,
+                           out.xy.data(), &inf),
+          "amsm_msm_oneshot");
+    out.infinity = inf != 0;
+    return out;
+  }
   // device-resident Montgomery scalars (the form the vector kernels produce)
   static Affine multi_scalar_mul(const CommitterKey& bases, const FrVector& scalars_mont) {
     Affine out;

@@ -54,6 +54,8 @@ def test_default_line_n1(built_lib):
     # BASELINE config 3's MSM beside the headline: BLS12-381 G1 at 2^20, scalars uniform in [0, r), bit-exact
     cfg = d["config"]
     assert cfg["pairs_per_s_bls12_381_2p20"] > 1e8 and cfg["bls12_381_2p20"]["gpu_result_bit_exact_vs_cpu"] is True
+    # the ark-ec call shape (host bases + host scalars per call): PCIe-bound, and the line says how close to the link it gets
+    assert cfg["pairs_per_s_oneshot_host_bases"] > 5e7 and 0.2 < cfg["oneshot_host_bases"]["fraction_of_h2d_bound"] <= 1.05, cfg["oneshot_host_bases"]
     assert cfg["bls12_381_2p20"]["timed_batch_msms_checked"] == 12 and 0.40 < cfg["bls12_381_2p20"]["scalars_above_2^254"] < 0.50
     assert sum(1 for k in acc if k.endswith("_harness_constant_inputs")) == 2
     assert all(v["sponge"] == "poseidon" for v in acc.values())  # the reference's sponge, not the SHA-256 stand-in
