@@ -252,6 +252,8 @@ struct amsm_ctx {
   // their scalars -- msm_enqueue sets MsmGeom::skip_ones for every (range of a) vector that lies inside one
   std::vector<std::pair<const char*, const char*>> skip_ones_ranges;
   unsigned long long n_ones_split = 0;  // MSMs that took that form (amsm_ctx_unit_scalar_msms)
+  size_t replicate_below = 0;             // amsm_ctx_set_replicate_below: keys up to this many generators are replicated, not sharded
+  unsigned long long n_replicated = 0;    // MSMs of batch calls over replicated keys that ran off the primary device
   unsigned long long n_collectives = 0;  // exchanges of partial records so far (amsm_ctx_collectives: one per sharded call)
   uint64_t n_host_gathers = 0;  // grouped MSMs / IPA rounds over sharded keys: the shards' class sums folded on the host
   // ---- caching allocator behind amsm_dev_alloc / amsm_dev_free ----
@@ -299,6 +301,9 @@ struct amsm_bases {
   // [bound[g], bound[g + 1]); n is the total, d_table stays null
   std::vector<amsm_bases*> shards;
   std::vector<size_t> bound;
+  // REPLICATED key of a multi-device context (AMSM_BASES_REPLICATE, round 6): this object is the PRIMARY device's ordinary key;
+  // replicas[g] (g >= 1, owned) is the same key on shard_ctx[g]'s device, replicas[0] stays null.  Empty: not replicated.
+  std::vector<amsm_bases*> replicas;
   const amsm_ctx* owner = nullptr;
 };
 

@@ -207,6 +207,14 @@ class MultiContext(Context):
     def num_devices(self) -> int:
         return len(self.devices)
 
+    def set_replicate_below(self, n_generators: int):
+        """keys of up to n_generators created from now on are REPLICATED on every device (ffi.AMSM_BASES_REPLICATE) instead of sharded"""
+        ffi.check(self._lib.amsm_ctx_set_replicate_below(self._h, n_generators), "amsm_ctx_set_replicate_below")
+
+    @property
+    def replicated_msms(self) -> int:
+        return int(self._lib.amsm_ctx_replicated_msms(self._h))
+
     @property
     def collective(self) -> str:
         return self._lib.amsm_ctx_collective(self._h).decode()

@@ -33,6 +33,7 @@ AMSM_BASES_PRECOMPUTE = 1
 AMSM_BASES_NO_PRECOMPUTE = 2
 AMSM_BASES_NO_DIRECT_TABLE = 4
 AMSM_BASES_NO_TWIN = 8
+AMSM_BASES_REPLICATE = 16
 
 _vp = C.c_void_p
 _u64p = C.POINTER(C.c_uint64)
@@ -132,6 +133,9 @@ SIGNATURES = {
     "amsm_dev_free": (C.c_int, [_vp, _vp]),
     "amsm_dev_upload": (C.c_int, [_vp, _vp, _vp, _sz]),
     "amsm_dev_download": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "amsm_ctx_set_replicate_below": (C.c_int, [_vp, _sz]),
+    "amsm_bases_replicas": (C.c_int, [_vp]),
+    "amsm_ctx_replicated_msms": (C.c_ulonglong, [_vp]),
     "amsm_msm_oneshot": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_vec_random": (C.c_int, [_vp, C.c_uint64, _sz, C.c_int, _vp]),
     "amsm_vec_hadamard": (C.c_int, [_vp, _vp, _vp, _vp, _sz]),

@@ -77,7 +77,15 @@ enum amsm_bases_flags {
    *   a key with the 20-bit table (>= 2^20 generators) builds a 17-bit TWIN of about the same size (1 GiB at 2^20) on the first
    *   call that needs it -- a range below a quarter of 2^20 pairs, a vector with skewed digits. */
   AMSM_BASES_NO_DIRECT_TABLE = 4, /* never build the direct-sum table: such a key's MSMs take the windowed pipelines */
-  AMSM_BASES_NO_TWIN = 8          /* never build the twin: the calls that would need it return AMSM_E_UNSUPPORTED */
+  AMSM_BASES_NO_TWIN = 8,         /* never build the twin: the calls that would need it return AMSM_E_UNSUPPORTED */
+  /* Round 6 -- multi-device contexts only (ignored elsewhere): every device holds the WHOLE key instead of a shard of it, and the
+   * entry points that carry several independent MSMs over one key (amsm_msm_batch_device, amsm_msm_batch,
+   * amsm_pedersen_commit_batch) deal them to the devices round-robin -- MSM v runs whole on device v mod n_dev, no partial sums,
+   * no exchange, results in call order.  What a SMALL key wants: point-sharding 2^18 generators 8 ways leaves 2^15 pairs per GPU
+   * per MSM (the latency regime), while `r1cs_nark_as::prove` issues 2-8 independent commitments per round
+   * (src/r1cs_nark_as/r1cs_nark/mod.rs:216-218,234-236,251,261; src/r1cs_nark_as/mod.rs:394-410).  Every other entry point uses
+   * the primary device's copy, so such a key is accepted wherever a single-device key is (grouped MSMs, the IPA round, key folds). */
+  AMSM_BASES_REPLICATE = 16
 };
 
 const char* amsm_strerror(int status);
@@ -116,6 +124,13 @@ int amsm_ctx_num_devices(const amsm_ctx* ctx);
  * like `ctx` itself): lets the caller allocate / fill / transform scalar vectors ON device g with the ordinary entry
  * points, e.g. the slices amsm_msm_batch_sharded_device takes.  NULL when g is out of range. */
 amsm_ctx* amsm_ctx_shard(amsm_ctx* ctx, int g);
+/* Keys of up to `n_generators` generators created through this multi-device context from now on are REPLICATED
+ * (AMSM_BASES_REPLICATE) instead of sharded, whatever their flags; 0 (the default): only keys that ask for it. */
+int amsm_ctx_set_replicate_below(amsm_ctx* ctx, size_t n_generators);
+/* Devices that hold a full copy of this key: 1 for single-device and sharded keys, n_dev for a replicated one. */
+int amsm_bases_replicas(const amsm_bases* bases);
+/* MSMs of batch calls over replicated keys that ran on a device other than the primary so far. */
+unsigned long long amsm_ctx_replicated_msms(const amsm_ctx* ctx);
 /* "rccl", "peer-copy" (multi-device contexts) or "none". */
 const char* amsm_ctx_collective(const amsm_ctx* ctx);
 /* Exchanges of partial records (one RCCL all-gather, or one round of peer copies) this multi-device context has run:

@@ -156,3 +156,17 @@ def test_uniform_witness_circuit_same_bytes_on_both_backends_and_over_shards(bui
     hh, _ = cpp_dump(tmp_path, "r1cs_nark_as", 14, "harness", "poseidon", -1, extra=("--uniform",))
     many, _ = cpp_dump(tmp_path, "r1cs_nark_as", 14, "harness", "poseidon", 0, extra=("--uniform", "--devices", "0,0,0"))
     assert g == hh and g == many
+
+
+@pytest.mark.gpu
+def test_cpp_driver_over_replicated_keys_same_bytes(built_lib, tmp_path):
+    """`profile_as --devices 0 x 8 --replicate-below 18` (amsm.h AMSM_BASES_REPLICATE: every device holds the whole key, the
+    independent MSMs of a commit round are dealt to the devices, no exchange) against the single-device run at BASELINE config 4's
+    size: r1cs_nark_as at 2^18 constraints over the circuit with a uniform witness (windowed MSMs, not the harness's two-valued
+    ones) and over the harness's own circuit; hp_as at 2^16; identical accumulators and proofs."""
+    dev8 = ("--devices", "0,0,0,0,0,0,0,0", "--replicate-below", "18")
+    for scheme, lg, extra in (("r1cs_nark_as", 18, ("--uniform",)), ("r1cs_nark_as", 18, ()), ("hp_as", 16, ())):
+        for shape in ("harness", "n2"):
+            one, _ = cpp_dump(tmp_path, scheme, lg, shape, "poseidon", 0, extra=extra)
+            many, _ = cpp_dump(tmp_path, scheme, lg, shape, "poseidon", 0, extra=extra + dev8)
+            assert one == many, (scheme, shape, extra)

@@ -13,6 +13,7 @@
 //   --cold       no warm-up repetitions (the prove before the timed ones, the decide before the timed one): the CPU legs of
 //                bench.py, where a repetition costs seconds and there are no clocks or caches to warm.
 //   --devices 0,1,2,3  one context over four GPUs (sharded keys; a repeated id puts two shards on one GPU).
+//   --replicate-below L  (with --devices) keys of up to 2^L generators are replicated on every device, batches of MSMs dealt round-robin.
 //   --device -1  runs on the library's host backend (amsm.h AMSM_DEVICE_HOST: BASELINE.json config 1 "plumbing, no GPU").
 //   --seed S     varies the harness's random stream and the synthetic vectors (0: the bench's inputs).
 //   --dump FILE  ONE (scheme, size, shape): exactly one prove after the first accumulation, then FILE receives the serialised new
@@ -44,11 +45,18 @@ struct Opt {
   int device = 0;
   std::vector<int> devices;  // --devices a,b,..: one multi-device context (sharded keys), amsm.h amsm_ctx_create_multi
   uint64_t seed = 0;
+  int replicate_log2 = -1;  // --replicate-below
   std::string dump;
 };
 
 static Context make_context(const Opt& o) {
-  if (o.devices.size() >= 2) return Context(o.curve, o.devices);
+  if (o.devices.size() >= 2) {
+    Context c(o.curve, o.devices);
+    // --replicate-below L: keys of up to 2^L generators live WHOLE on every device and the independent MSMs of a commit round are
+    // dealt to the devices (amsm.h AMSM_BASES_REPLICATE) instead of point-sharding a small key into latency-bound slivers
+    if (o.replicate_log2 >= 0) check(amsm_ctx_set_replicate_below(c.get(), (size_t)1 << o.replicate_log2), "amsm_ctx_set_replicate_below");
+    return c;
+  }
   return Context(o.curve, o.device);
 }
 static void dump_records(const Opt& o, const std::vector<uint8_t>& acc, const std::vector<uint8_t>& proof) {
@@ -456,7 +464,7 @@ int main(int argc, char** argv) {
   Opt o;
   if (argc < 4) {
     fprintf(stderr, "usage: %s <scheme|all> <log_min> <log_max> [--shape harness|n2|both] [--reps R] [--sponge sha256|poseidon] "
-                    "[--curve 0|1] [--constant] [--uniform] [--no-roundtrip] [--device D | --devices a,b,..] [--seed S] [--dump FILE] [--cold]\n", argv[0]);
+                    "[--curve 0|1] [--constant] [--uniform] [--no-roundtrip] [--device D | --devices a,b,..] [--seed S] [--dump FILE] [--cold] [--replicate-below L]\n", argv[0]);
     return 2;
   }
   o.scheme = argv[1];
@@ -479,6 +487,7 @@ int main(int argc, char** argv) {
         if (*p == ',') p++;
       }
     }
+    else if (a == "--replicate-below" && i + 1 < argc) o.replicate_log2 = atoi(argv[++i]);
     else if (a == "--seed" && i + 1 < argc) o.seed = strtoull(argv[++i], nullptr, 0);
     else if (a == "--dump" && i + 1 < argc) o.dump = argv[++i];
     else {
