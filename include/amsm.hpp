@@ -44,8 +44,11 @@ class Context {
   }
   // One context over several devices (amsm_ctx_create_multi): keys loaded through it are sharded, every MSM / commit / grouped
   // MSM / IPA round runs on all of them with one exchange of partial sums.  An empty list = the host backend.
-  Context(int curve, const std::vector<int>& devices) {
+  // replicate_below > 0: keys of up to that many generators are REPLICATED on every device instead (amsm.h AMSM_BASES_REPLICATE:
+  // the independent MSMs of a commit round are dealt to the devices whole, no exchange)
+  Context(int curve, const std::vector<int>& devices, size_t replicate_below = 0) {
     check(amsm_ctx_create_multi(&h_, curve, devices.data(), (int)devices.size()), "amsm_ctx_create_multi");
+    if (replicate_below) check(amsm_ctx_set_replicate_below(h_, replicate_below), "amsm_ctx_set_replicate_below");
   }
   ~Context() { amsm_ctx_destroy(h_); }
   int num_devices() const { return amsm_ctx_num_devices(h_); }

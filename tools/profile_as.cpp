@@ -50,13 +50,9 @@ struct Opt {
 };
 
 static Context make_context(const Opt& o) {
-  if (o.devices.size() >= 2) {
-    Context c(o.curve, o.devices);
-    // --replicate-below L: keys of up to 2^L generators live WHOLE on every device and the independent MSMs of a commit round are
-    // dealt to the devices (amsm.h AMSM_BASES_REPLICATE) instead of point-sharding a small key into latency-bound slivers
-    if (o.replicate_log2 >= 0) check(amsm_ctx_set_replicate_below(c.get(), (size_t)1 << o.replicate_log2), "amsm_ctx_set_replicate_below");
-    return c;
-  }
+  // --replicate-below L: keys of up to 2^L generators live WHOLE on every device and the independent MSMs of a commit round are
+  // dealt to the devices (amsm.h AMSM_BASES_REPLICATE) instead of point-sharding a small key into latency-bound slivers
+  if (o.devices.size() >= 2) return Context(o.curve, o.devices, o.replicate_log2 >= 0 ? (size_t)1 << o.replicate_log2 : 0);
   return Context(o.curve, o.device);
 }
 static void dump_records(const Opt& o, const std::vector<uint8_t>& acc, const std::vector<uint8_t>& proof) {
