@@ -398,15 +398,17 @@ def main() -> int:
 # (`--device -1`: product code, never oracle/): the full size where one run fits the leg's time box on the GPU box's host, else
 # the largest size that does -- the entry names the size it ran; nothing is extrapolated.
 SCHEME_RUNS = (
-    ("trivial_pc_as", 10, ["--reps", "5"], "", 10),                                   # config 1 on the GPU context
-    ("trivial_pc_as", 10, ["--reps", "5", "--device", "-1"], "_host_backend", None),  # config 1 as it reads: no GPU
-    ("ipa_pc_as", 16, ["--reps", "3"], "", 16),                                       # config 2
-    ("ipa_pc_as", 20, ["--reps", "2", "--curve", "1"], "_bls12_381", 17),             # config 3 (BLS12-381 G1); CPU: 2^17 (2^20: minutes)
-    ("r1cs_nark_as", 18, ["--reps", "3"], "", 18),                                    # config 4
-    ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"], "_uniform_witness", 18),
-    ("hp_as", 22, ["--reps", "3"], "", 22),                                           # config 5
-    ("hp_as", 22, ["--reps", "3", "--constant"], "_harness_constant_inputs", 22),
+    ("trivial_pc_as", 10, ["--reps", "5"], "", {"harness": 10, "n2": 10}),                     # config 1 on the GPU context
+    ("trivial_pc_as", 10, ["--reps", "5", "--device", "-1"], "_host_backend", None),           # config 1 as it reads: no GPU
+    ("ipa_pc_as", 16, ["--reps", "3"], "", {"harness": 16, "n2": 16}),                         # config 2
+    ("ipa_pc_as", 20, ["--reps", "2", "--curve", "1"], "_bls12_381", {"harness": 16, "n2": 16}),  # config 3; CPU at 2^16 (2^20: minutes)
+    ("r1cs_nark_as", 18, ["--reps", "3"], "", {"harness": 18, "n2": 18}),                      # config 4
+    ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"], "_uniform_witness", {"harness": 18, "n2": 18}),
+    ("hp_as", 22, ["--reps", "3"], "", {"harness": 20, "n2": 22}),                             # config 5; CPU harness-zk at 2^20
+    ("hp_as", 22, ["--reps", "3", "--constant"], "_harness_constant_inputs", {"harness": 20, "n2": 20}),
 )
+# rough cost of a CPU run (seconds on 16 threads of the GPU box's host, measured in round 6): longest first onto the lanes
+CPU_LEG_COST = {("hp_as", 22): 22, ("hp_as", 20): 14, ("ipa_pc_as", 16): 9, ("r1cs_nark_as", 18): 10, ("trivial_pc_as", 10): 0.1}
 CPU_LEG_TIMEOUT_S = 70  # per run; the runs go side by side on disjoint cores (cpu_scheme_rates)
 
 
@@ -446,12 +448,15 @@ def cpu_scheme_rates(exe, out):
     box: 128-256 cores), else one after the other; each bounded by CPU_LEG_TIMEOUT_S.  One repetition, no warm-up (--cold)."""
     import subprocess
     from concurrent.futures import ThreadPoolExecutor
-    # one process per (entry, shape): side by side they take as long as the slowest (hp_as 2^22 harness-zk: ~30 s on 16 threads)
-    jobs = [(scheme, lg, extra, tag, (cpu, shape)) for scheme, lg, extra, tag, cpu in SCHEME_RUNS if cpu is not None
+    # one process per (entry, shape), longest first, at most FOUR at a time: fourteen side by side (224 threads on the box's 256
+    # hardware threads) ran the same proves 4-15x slower than seven did (round 6, profiles/r06_experiments.md) -- a CPU figure
+    # measured under that contention would flatter the GPU
+    jobs = [(scheme, lg, extra, tag, (cpu[shape], shape)) for scheme, lg, extra, tag, cpu in SCHEME_RUNS if cpu is not None
             for shape in ("harness", "n2")]
+    jobs.sort(key=lambda j: -CPU_LEG_COST.get((j[0], j[4][0]), 5) * (1.5 if j[4][1] == "harness" else 1.0))
     cores = os.cpu_count() or 1
-    threads = max(1, min(16, cores // len(jobs) if cores >= 4 * len(jobs) else cores))  # caller + helpers per run
-    side_by_side = max(1, min(len(jobs), cores // threads))
+    threads = max(1, min(16, cores))  # caller + helpers per run
+    side_by_side = max(1, min(4, len(jobs), cores // (2 * threads)))  # (never more than half the hardware threads busy)
     out["cpu"] = {"backend": "libamsm.so host backend (AMSM_DEVICE_HOST: window-parallel signed-digit Pippenger, vector loops on the host pool; "
                              "product code -- not oracle/, not ark-ec)", "threads_per_run": threads, "runs_side_by_side": side_by_side,
                   "host_cores": cores, "cpu_model": cpu_model(), "repetitions": 1,

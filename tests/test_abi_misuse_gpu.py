@@ -15,7 +15,7 @@ import ctypes as C
 from accumulation_amd import ffi
 lib = ffi.load()
 NOT_CTX_FIRST = {"amsm_bases_len", "amsm_bases_free", "amsm_bases_precomputed", "amsm_bases_num_shards", "amsm_bases_window_bits",
-                 "amsm_bases_shard_range", "amsm_bases_device_ptr", "amsm_bases_memory", "amsm_matrix_rows", "amsm_matrix_free", "amsm_ctx_destroy"}
+                 "amsm_bases_shard_range", "amsm_bases_device_ptr", "amsm_bases_memory", "amsm_bases_replicas", "amsm_matrix_rows", "amsm_matrix_free", "amsm_ctx_destroy"}
 PREFIXES = ("amsm_msm", "amsm_ctx", "amsm_bases", "amsm_vec", "amsm_dev", "amsm_ipa", "amsm_matrix", "amsm_hp", "amsm_pedersen",
             "amsm_partials", "amsm_points_fold")
 for curve in (ffi.AMSM_PALLAS, ffi.AMSM_BLS12_381_G1):
