@@ -48,6 +48,7 @@ struct Slot {  // buffers and events of one MSM in flight (the streams belong to
   DevBuf keys_a, keys_b, vals_a, vals_b, start, items, item_off, partials, buckets, red_out, fold_out, heavy, misc,
       sort_tmp, scan_tmp, prep_small, heavy_scratch;
   DevBuf red2_rc;  // row / column sums of the bucket reduction (k_red2_sums)
+  DevBuf red_ticket;  // one arrival counter per bucket set (k_bucket_reduce_fold_quad; zeroed at allocation, left clear by the kernel)
   DevBuf ds_flags;  // the direct sum's two flag words (zeroed at allocation, left clear by k_fold_quad)
   DevBuf bpl_grp, bpl_order;  // bucket-per-lane pipeline: group headers, bucket order (entries live in vals_a / vals_b)
   // the MSM this slot carries, kept until it is collected: a bucket-per-lane MSM whose prep reports a skewed input is
@@ -195,6 +196,7 @@ struct amsm_ctx {
   unsigned long long n_direct = 0;  // MSMs summed straight from a small key's 512-points-per-generator table (k_direct_sum)
   int direct_max_log2 = 15;         // keys of up to 2^this generators carry that table (AMSM_DIRECT_SUM_MAX_LOG2; 0: none)
   unsigned direct_rr = 0;           // which stream the next direct sum of a batch takes
+  bool fused_fold = true;  // AMSM_FUSED_FOLD=0: the quad bucket reduction and its fold as two launches (round 5's tail; A/B)
   bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline
                           // (AMSM_BPL_PROBE=0: find out from the prep's overflow flag only -- the safety net either way)
   unsigned long long n_bpl = 0, n_bpl_fallbacks = 0;  // MSMs that took it / that were re-run chunked (skewed digits)

@@ -39,6 +39,10 @@ void launch_fold(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* 
 // the same two kernels with a quad of lanes per logical lane (ec.h: xyzz_add_quad): red_blocks = 4x
 template <class Fq>
 void launch_bucket_reduce_quad(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* out);
+// round 6: both in one launch (msm_kernels.h: k_bucket_reduce_fold_quad); partial: n_sets * red_blocks records, ticket: n_sets zeroed words
+template <class Fq>
+void launch_bucket_reduce_fold_quad(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* partial, u32* ticket, u32* out,
+                                    const u32* flags, u32* host_mirror);
 template <class Fq>
 void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags, u32* host_mirror = nullptr,
                       bool clear_flags = false);  // clear_flags: the two words are zeroed once they have been copied out

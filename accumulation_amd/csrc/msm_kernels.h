@@ -811,6 +811,79 @@ __global__ void __launch_bounds__(256)
   block_reduce_xyzz_quad<Fq>(total, lds);
   if (threadIdx.x == 0) xyzz_store<Fq>(out, (size_t)set * gridDim.x + blockIdx.x, total);
 }
+// Round 6: k_bucket_reduce_quad and k_fold_quad as ONE launch.  The blocks of a set leave their partial records as before and
+// take a ticket; the LAST block of the set to arrive folds the set's gridDim.x records (the quad fold's schedule), exports the
+// sum to the C-ABI radix, mirrors it (and, for set 0, the MSM's flag words) into page-locked memory and clears the ticket for
+// the slot's next MSM.  What it saves is the dependent launch between two latency chains -- the second kernel's dispatch, its
+// drain and the ~5 us hand-over -- in every blocking MSM of up to 2^17 buckets and in every round of an IPA opening.
+// partial: n_sets * gridDim.x records of scratch; ticket: n_sets words, zero on entry.
+template <class Fq>
+__global__ void __launch_bounds__(256)
+    k_bucket_reduce_fold_quad(const u32* __restrict__ buckets, MsmGeom g, u32* partial, u32* __restrict__ ticket, u32* __restrict__ out,
+                              const u32* __restrict__ flags, u32* __restrict__ mirror) {
+  __shared__ __attribute__((aligned(16))) u32 lds[4 * 4 * Fq::W];
+  __shared__ u32 s_last;
+  const u32 set = blockIdx.y;
+  {
+    const u32 t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;  // logical lane: owns buckets [t*s, (t+1)*s)
+    XYZZ<Fq> total = xyzz_inf<Fq>();
+    if (t < g.red_threads) {
+      const u32 lo = t * g.red_s;
+      XYZZ<Fq> run = xyzz_inf<Fq>(), sum = xyzz_inf<Fq>();
+      XYZZ<Fq> bk = xyzz_load<Fq>(buckets, (size_t)set * g.nb + lo + g.red_s - 1);
+      for (int k = (int)g.red_s - 1; k >= 0; k--) {
+        XYZZ<Fq> nx = bk;
+        if (k > 0) nx = xyzz_load<Fq>(buckets, (size_t)set * g.nb + lo + k - 1);
+        xyzz_add_quad<Fq>(run, bk);
+        xyzz_add_quad<Fq>(sum, run);
+        bk = nx;
+      }
+      total = xyzz_mul_small_quad<Fq>(run, lo);
+      xyzz_add_quad<Fq>(total, sum);
+    }
+    block_reduce_xyzz_quad<Fq>(total, lds);
+    if (threadIdx.x == 0) {
+      xyzz_store<Fq>(partial, (size_t)set * gridDim.x + blockIdx.x, total);
+      __threadfence();  // the record is visible device-wide before the ticket is
+      s_last = atomicAdd(ticket + set, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // acquire: the other blocks' records (other XCDs' L2s) are read from memory
+  const u32 n = gridDim.x;
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  {
+    const u32 k0 = threadIdx.x >> 2, nq = blockDim.x >> 2;
+    const u32* in = partial + (size_t)set * n * (4 * Fq::W);
+    for (u32 k = k0; k < n; k += nq) {
+      const XYZZ<Fq> p = xyzz_load<Fq>(in, k);  // (written by other workgroups of THIS launch: read behind the fence above)
+      xyzz_add_quad<Fq>(acc, p);
+    }
+  }
+  __syncthreads();  // (lds is reused)
+  block_reduce_xyzz_quad<Fq>(acc, lds);
+  if (threadIdx.x == 0) {
+    XYZZ<Fq> e;
+    e.x = fe_export<Fq>(acc.x);
+    e.y = fe_export<Fq>(acc.y);
+    e.zz = fe_export<Fq>(acc.zz);
+    e.zzz = fe_export<Fq>(acc.zzz);
+    xyzz_store<Fq>(out, set, e);
+    if (mirror) xyzz_store<Fq>(mirror, set, e);
+    if (flags && set == 0) {
+      const u32 f0 = flags[0], f1 = flags[1];
+      out[(size_t)gridDim.y * (4 * Fq::W)] = f0;
+      out[(size_t)gridDim.y * (4 * Fq::W) + 1] = f1;
+      if (mirror) {
+        mirror[(size_t)gridDim.y * (4 * Fq::W)] = f0;
+        mirror[(size_t)gridDim.y * (4 * Fq::W) + 1] = f1;
+      }
+    }
+    ticket[set] = 0;
+    if (mirror) __threadfence_system();
+  }
+}
 template <class Fq>
 __global__ void __launch_bounds__(256) k_fold_quad(const u32* __restrict__ in, u32 n, u32* __restrict__ out,
                                                    const u32* __restrict__ flags, u32* __restrict__ mirror, u32 clear_flags) {

@@ -113,8 +113,8 @@ int main() {
                      {"accumulators_only", {1, 0, 0, 0}, 3}, {"no_inputs_init", {0}, 1}};
     for (int zk = 0; zk < 2; zk++)
       for (auto& s : scenarios) {
-        run_template(ctx, ck, s.per_iteration, zk != 0, s.iterations);
-        printf("scenario %s %s ok\n", s.name, zk ? "zk" : "no_zk");
+        run_template(ctx, ck, s.per_iteration, zk != 0, check_iterations(s.iterations));
+        printf("scenario %s %s ok %zu\n", s.name, zk ? "zk" : "no_zk", check_iterations(s.iterations));
       }
     // deterministic run for the cross-check with the Python mirror
     for (int zk = 0; zk < 2; zk++) {

@@ -98,8 +98,8 @@ int main() {
                      {"simple_accumulation", {1, 1}, 3},     {"multiple_inputs_accumulation", {1, 1, 2, 3}, 2},
                      {"accumulators_only", {1, 0, 0, 0}, 3}, {"no_inputs_init", {0}, 1}};
     for (auto& s : scenarios) {
-      run_template(ctx, pp, s.per_iteration, s.iterations);
-      printf("scenario %s ok\n", s.name);
+      run_template(ctx, pp, s.per_iteration, check_iterations(s.iterations));
+      printf("scenario %s ok %zu\n", s.name, check_iterations(s.iterations));
     }
     Accumulator acc = run_template(ctx, pp, {1, 1, 2, 3}, 1);
     print_words("acc_comm", acc.instance.commitment.elem.xy.data(), acc.instance.commitment.elem.xy.size(),

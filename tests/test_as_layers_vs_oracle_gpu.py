@@ -316,57 +316,66 @@ def test_blinded_commitments_start_comm_prod_from_comm_c(nark_env):
 # ---------------------------------------------------------------------------------------------------------------
 # ipa_pc_as: the combine step
 # ---------------------------------------------------------------------------------------------------------------
+def ipa_as_case(ctx, degree, n_first, n_second, make_zk, seed):
+    """two chained ipa_pc_as proves -- n_first inputs, then n_second more plus the first accumulator -- with the combine step of
+    the FIRST prove (src/ipa_pc_as/mod.rs:254-421) recomputed by the big-int oracle from the recorded Fiat-Shamir challenges; the
+    second accumulation must verify and decide.  (tools/fuzz_schemes.py draws the shape; the test below fixes one.)"""
+    from accumulation_amd import ipa_pc_as as M
+    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
+    from accumulation_amd.sponge import Sha256Sponge
+    from tests.test_ipa_gpu import generate_inputs
+    AS = M.AtomicASForInnerProductArgPC
+    pp = IpaPC.setup(ctx, degree, seed=11 + seed)
+    pk, vk, dk = AS.index(pp, degree)
+    env = (ctx, pp)
+    rng = SchemeRng(3 + seed)
+    ins = generate_inputs(env, pk, n_first + n_second, make_zk, rng, degree=min(degree, 11) if degree == 15 else degree)
+    log = []
+
+    class Rec(RecordingSponge):
+        def __init__(self):
+            super().__init__(Sha256Sponge(), log)
+    old_cls = AS.sponge_cls
+    AS.sponge_cls = Rec
+    try:
+        zk_rng = RecordingRng(5 + seed) if make_zk else None
+        acc, proof = AS.prove(pk, ins[:n_first], [], zk_rng, None)
+        n_log = len(log)
+        acc2, proof2 = AS.prove(pk, ins[n_first:], [acc.instance], RecordingRng(6 + seed) if make_zk else None, None)
+    finally:
+        AS.sponge_cls = old_cls
+    assert AS.verify(ctx, vk, ins[n_first:], [acc.instance], acc2.instance, proof2, None) and AS.decide(dk, acc2, None)
+    # first prove: squeezes = [linear-combination challenges (n_first), challenge point (1)] on the AS fork's two clones
+    assert n_first >= 2  # (with one input the two squeezes have the same length: the shape below would be ambiguous)
+    first = [v for _, v in log[:n_log]]
+    i_lc = next(i for i, v in enumerate(first) if len(v) == n_first)
+    lc = first[i_lc]
+    point = next(v for v in first[i_lc + 1:] if len(v) == 1)[0]
+    checks = []
+    AS._succinct_checks(ctx, pk.verifier_key.ipa_svk, ins[:n_first], False, checks)
+    xis = [[int(x) for x in cp.challenges] for cp, _ in checks]
+    fks = [pt(fk) for _, fk in checks]
+    rnd = None
+    lin = None
+    if make_zk:
+        lin = [v % C.r for v in proof.random_linear_polynomial]
+        rnd = {"lin_comm": pt(proof.random_linear_polynomial_commitment), "commitment_randomness": proof.commitment_randomness}
+    comb, randomized = oa.ipa_as_combine(C, fks, lc, pt((pk.verifier_key.ipa_svk.s[0], pk.verifier_key.ipa_svk.s[1])), rnd)
+    assert pt(acc.instance.ipa_commitment.comm) == randomized
+    assert acc.instance.point % C.r == point % C.r
+    assert acc.instance.evaluation % C.r == oa.ipa_as_evaluate_combined(C, xis, lc, point, lin)
+    poly = oa.ipa_as_combined_polynomial(C, xis, lc, lin)
+    ev = 0
+    for k in reversed(poly):
+        ev = (ev * point + k) % C.r
+    assert ev == acc.instance.evaluation % C.r
+
+
 @pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
 def test_ipa_pc_as_combine_vs_oracle(make_zk):
     from accumulation_amd import Context, ffi
-    from accumulation_amd import ipa_pc_as as M
-    from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
-    from accumulation_amd.scalar_field import Fr
-    from accumulation_amd.sponge import Sha256Sponge
-    from tests.test_ipa_gpu import generate_inputs
     ctx = Context(ffi.AMSM_PALLAS)
     try:
-        fr = Fr(ctx.curve)
-        AS = M.AtomicASForInnerProductArgPC
-        pp = IpaPC.setup(ctx, 15, seed=11)
-        pk, vk, dk = AS.index(pp, 15)
-        env = (ctx, pp)
-        rng = SchemeRng(3)
-        ins = generate_inputs(env, pk, 3, make_zk, rng)
-        log = []
-
-        class Rec(RecordingSponge):
-            def __init__(self):
-                super().__init__(Sha256Sponge(), log)
-        old_cls = AS.sponge_cls
-        AS.sponge_cls = Rec
-        try:
-            zk_rng = RecordingRng(5) if make_zk else None
-            acc, proof = AS.prove(pk, ins[:2], [], zk_rng, None)
-            acc2, proof2 = AS.prove(pk, ins[2:], [acc.instance], RecordingRng(6) if make_zk else None, None)
-        finally:
-            AS.sponge_cls = old_cls
-        assert AS.verify(ctx, vk, ins[2:], [acc.instance], acc2.instance, proof2, None) and AS.decide(dk, acc2, None)
-        # first prove: squeezes = [linear-combination challenges (2), challenge point (1)] on the AS fork's two clones
-        lc = [v for _, v in log if len(v) == 2][0]
-        point = [v for _, v in log if len(v) == 1][0][0]
-        checks = []
-        AS._succinct_checks(ctx, pk.verifier_key.ipa_svk, ins[:2], False, checks)
-        xis = [[int(x) for x in cp.challenges] for cp, _ in checks]
-        fks = [pt(fk) for _, fk in checks]
-        rnd = None
-        lin = None
-        if make_zk:
-            lin = [v % C.r for v in proof.random_linear_polynomial]
-            rnd = {"lin_comm": pt(proof.random_linear_polynomial_commitment), "commitment_randomness": proof.commitment_randomness}
-        comb, randomized = oa.ipa_as_combine(C, fks, lc, pt((pk.verifier_key.ipa_svk.s[0], pk.verifier_key.ipa_svk.s[1])), rnd)
-        assert pt(acc.instance.ipa_commitment.comm) == randomized
-        assert acc.instance.point % C.r == point % C.r
-        assert acc.instance.evaluation % C.r == oa.ipa_as_evaluate_combined(C, xis, lc, point, lin)
-        poly = oa.ipa_as_combined_polynomial(C, xis, lc, lin)
-        ev = 0
-        for k in reversed(poly):
-            ev = (ev * point + k) % C.r
-        assert ev == acc.instance.evaluation % C.r
+        ipa_as_case(ctx, 15, 2, 1, make_zk, 0)
     finally:
         ctx.close()

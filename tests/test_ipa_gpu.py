@@ -155,8 +155,9 @@ def test_ipa_commit_open_check(env, hiding):
     assert not IpaPC.check(vk, comm, (point + 1) % c.r, value, proof)
 
 
-def generate_inputs(env, pk, num_inputs, make_zk, rng):
+def generate_inputs(env, pk, num_inputs, make_zk, rng, degree=None):
     """src/ipa_pc_as/mod.rs:930-1004: random polynomial, commit, random point, evaluate, open"""
+    degree = DEGREE if degree is None else degree
     from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
     from accumulation_amd.ipa_pc_as import InputInstance
     from accumulation_amd.scalar_field import Fr
@@ -164,7 +165,7 @@ def generate_inputs(env, pk, num_inputs, make_zk, rng):
     fr = Fr(ctx.curve)
     out = []
     for _ in range(num_inputs):
-        coeffs = [rng.field() % fr.r for _ in range(DEGREE + 1)]
+        coeffs = [rng.field() % fr.r for _ in range(degree + 1)]
         poly = ctx.upload(fr.to_limbs_many(coeffs))
         comm, rand = IpaPC.commit(pk.ipa_ck, poly, make_zk, rng)
         point = rng.field() % fr.r

@@ -3,8 +3,12 @@
     bucket-per-lane pipeline (2^19, 2^20], scalar vectors from uniform to constant through every mixture in between (a random
     share of equal values, few distinct values, small ranges, top-of-field values, sparse), device vectors, batches, host slices;
   * grouped MSMs and (AMSM_BPS=2 contexts) plain MSMs of 2^16 .. 2^17 pairs through the bucket-split pipeline, both curves;
-  * contexts with the skew probe on and off (the overflow re-run on its own).
-Usage: python tools/fuzz_pipelines.py [seconds] [seed]"""
+  * contexts with the skew probe on and off (the overflow re-run on its own);
+  * round 6 -- LONG MSMs over ONE bucket set (amsm_ctx_shared_bucket_msms: more pairs than the 2^20-pair window of a 20-bit key):
+    keys of 2^21 generators, (2^20, 2^21] pairs, vectors whose RANGES differ -- uniform / skewed / witness-like (a share of boolean
+    wires) per range, so that a skewed range sends the whole MSM back to independent ranges --, device vectors, batches and host
+    slices, single-device keys and keys sharded over two "devices" (2^22 generators: every shard runs its own shared set).
+Usage: python tools/fuzz_pipelines.py [seconds] [seed] [--long-share P]   (P: share of iterations spent on the long MSMs, default 0.2)"""
 import os
 import sys
 import time
@@ -15,10 +19,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401,E402
 
-from accumulation_amd import CommitterKey, Context, VariableBaseMSM  # noqa: E402
+from accumulation_amd import CommitterKey, Context, MultiContext, VariableBaseMSM  # noqa: E402
 from oracle import cref, pyref as o  # noqa: E402
 from tests import helpers as h  # noqa: E402
 
+LONG_SHARE = 0.2
+if "--long-share" in sys.argv:
+    i = sys.argv.index("--long-share")
+    LONG_SHARE = float(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rs = np.random.RandomState(seed)
@@ -77,6 +86,30 @@ def scalars(c, n):
     return base, kind
 
 
+def ranged_scalars(c, n):
+    """a vector of more than 2^20 scalars whose 2^20-pair ranges are drawn apart: uniform, one of the skewed kinds of scalars(), or
+    witness-like (uniform values with a share of boolean wires)"""
+    parts, kinds = [], []
+    for lo in range(0, n, 1 << 20):
+        m = min(1 << 20, n - lo)
+        u = rs.rand()
+        if u < 0.55:
+            v, kind = cref.rng_frs(c.curve_id, int(rs.randint(1 << 30)), m), "uniform"
+        elif u < 0.75:
+            v = cref.rng_frs(c.curve_id, int(rs.randint(1 << 30)), m)
+            share = float(rs.choice([0.01, 0.1, 0.5, 0.9]))
+            pick = rs.rand(m) < share
+            bits = np.zeros_like(v)
+            bits[:, 0] = rs.randint(0, 2, size=m)
+            v[pick] = bits[pick]
+            kind = f"witness_{share}"
+        else:
+            v, kind = scalars(c, m)
+        parts.append(v)
+        kinds.append(kind)
+    return np.concatenate(parts), "+".join(kinds)
+
+
 def check(c, xy, sc, got, inf, off, what):
     n = min(len(sc), len(xy) - off)
     ref, rinf = cref.msm(c.curve_id, xy[off:off + n], sc[:n], threads=THREADS)
@@ -85,11 +118,46 @@ def check(c, xy, sc, got, inf, off, what):
         sys.exit(1)
 
 
-n_cases = n_big = n_small = 0
+n_cases = n_big = n_small = n_long = 0
 stats = {}
 while time.time() < t_end:
     c = o.PALLAS if rs.rand() < 0.75 else o.BLS12_381_G1
-    if rs.rand() < 0.6:  # ---- 2^20 / 2^21-generator key, bucket-per-lane range and around it
+    if rs.rand() < LONG_SHARE:  # ---- more pairs than the key's window: ONE bucket set for all ranges (round 5's Share; round 6's soak)
+        sharded = rs.rand() < 0.3
+        probe = int(rs.rand() < 0.7)
+        os.environ["AMSM_BPL_PROBE"] = str(probe)
+        try:
+            ctx = MultiContext(c.curve_id, [0, 0]) if sharded else Context(c.curve_id)
+        finally:
+            del os.environ["AMSM_BPL_PROBE"]
+        kn = (1 << 22) if sharded else (1 << 21)
+        ck = CommitterKey.generate(ctx, int(rs.randint(1 << 30)), kn)
+        xy, _ = ck.read()
+        for _ in range(int(rs.randint(2, 4))):
+            n = kn if (sharded or rs.rand() < 0.5) else int(rs.randint((1 << 20) + 1, kn + 1))
+            off = 0 if sharded else int(rs.randint(0, kn - n + 1))
+            mode = rs.choice(["device", "host", "batch"]) if not sharded else rs.choice(["device", "host"])
+            if mode in ("device", "host"):
+                sc, kind = ranged_scalars(c, n)
+                arg = ctx.upload(sc) if mode == "device" else sc
+                got, inf = VariableBaseMSM.multi_scalar_mul(ck, arg, base_off=off)
+                check(c, xy, sc, got, inf, off, f"long {mode} {kind} probe={probe} sharded={sharded}")
+                n_cases += 1
+                n_long += 1
+            else:
+                vecs = [ranged_scalars(c, n) for _ in range(int(rs.randint(2, 4)))]
+                pts, infs = VariableBaseMSM.multi_scalar_mul_batch(ck, [ctx.upload(v) for v, _ in vecs], mont=False, base_off=off)
+                for j, (v, kind) in enumerate(vecs):
+                    check(c, xy, v, pts[j], infs[j], off, f"long batch[{j}] {kind} probe={probe}")
+                    n_cases += 1
+                    n_long += 1
+        for g in range(2 if sharded else 1):
+            st = (ctx.shard(g) if sharded else ctx).pipeline_stats()
+            for k, v in st.items():
+                stats[k] = stats.get(k, 0) + v
+        ck.free()
+        ctx.close()
+    elif rs.rand() < 0.6:  # ---- 2^20 / 2^21-generator key, bucket-per-lane range and around it
         probe = int(rs.rand() < 0.6)
         ctx = ctx_with(c.curve_id, AMSM_BPL_PROBE=probe)
         kn = (1 << 20) if rs.rand() < 0.8 else (1 << 21)
@@ -149,4 +217,4 @@ while time.time() < t_end:
             stats[k] = stats.get(k, 0) + v
         ck.free()
         ctx.close()
-print(f"fuzz_pipelines: {n_cases} MSMs checked ({n_big} calls on 2^20+ keys, {n_small} small), all bit-exact; seed {seed}; pipelines {stats}", flush=True)
+print(f"fuzz_pipelines: {n_cases} MSMs checked ({n_big} calls on 2^20+ keys, {n_small} small, {n_long} LONG MSMs of > 2^20 pairs), all bit-exact; seed {seed}; pipelines {stats}", flush=True)

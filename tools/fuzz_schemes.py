@@ -1,8 +1,11 @@
 """Randomised runs of the accumulation layers against the big-int oracle (oracle/pyref_as.py), beyond the fixed scenarios of
 tests/test_as_layers_vs_oracle_gpu.py: hp_as proves with random vector lengths, numbers of inputs / old accumulators, zk on or
 off and fresh seeds, and r1cs_nark_as accumulation CHAINS of random shape (new inputs and subsets of the earlier accumulators per
-step); every combined instance, witness vector, proof commitment and decide() must match the oracle bit for bit.
-Usage: python tools/fuzz_schemes.py [seconds] [seed]"""
+step); every combined instance, witness vector, proof commitment and decide() must match the oracle bit for bit.  Round 6:
+ipa_pc_as chains (random degree 2^k - 1, 2-4 inputs then 0-2 more plus the first accumulator, zk on or off: the first prove's
+combine step against the oracle, the second verified and decided) and trivial_pc_as chains (random degree, random template shape:
+every step verified, the last accumulator decided, and its commitment recomputed by the oracle's naive MSM over the key).
+Usage: python tools/fuzz_schemes.py [seconds] [seed] [--host]   (--host: the library's host backend, no GPU needed)"""
 import os
 import sys
 import time
@@ -21,13 +24,15 @@ from tests.test_as_layers_vs_oracle_gpu import hp_case  # noqa: E402
 from tests.test_hp_as_scheme_gpu import SchemeRng  # noqa: E402
 from tests.test_r1cs_nark_gpu import dummy_circuit  # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+HOST = "--host" in sys.argv
+argv = [a for a in sys.argv if a != "--host"]
+budget = float(argv[1]) if len(argv) > 1 else 60.0
+seed = int(argv[2]) if len(argv) > 2 else 1
 rs = np.random.RandomState(seed)
 C = o.PALLAS
-ctx = Context(ffi.AMSM_PALLAS)
+ctx = Context(ffi.AMSM_PALLAS, device=ffi.AMSM_DEVICE_HOST if HOST else 0)
 t_end = time.time() + budget
-n_cases = n_chains = n_steps = 0
+n_cases = n_chains = n_steps = n_ipa = n_trivial = 0
 
 
 def nark_env():
@@ -62,10 +67,51 @@ def nark_chain():
     assert T.oa.nark_as_decide(C, A, B, C_, env[3], env[4], ref) and AS.decide(dk, acc, None)
 
 
+def ipa_chain():
+    T.ipa_as_case(ctx, int(rs.choice([3, 7, 15, 31])), int(rs.randint(2, 5)), int(rs.randint(0, 3)), bool(rs.rand() < 0.5),
+                  int(rs.randint(1, 1 << 20)))
+
+
+def trivial_chain():
+    from accumulation_amd.trivial_pc_as import ASForTrivialPC as AS, TrivialPC
+    import tests.test_trivial_pc_as_scheme_gpu as TT
+    degree = int(rs.choice([1, 2, 5, 11, 30]))
+    pp = TrivialPC.setup(ctx, degree)
+    env = (ctx, pp)
+    ck, _ = TrivialPC.trim(pp, degree)
+    pk, vk, dk = AS.index(pp, degree)
+    rng = SchemeRng(int(rs.randint(1, 1 << 20)))
+    shape = [int(rs.randint(0, 4)) for _ in range(int(rs.randint(1, 5)))]
+    if shape[0] == 0 and sum(shape) == 0:
+        shape[0] = 1
+    inputs = TT.generate_inputs(env, ck, sum(shape), rng)
+    old, start = [], 0
+    for k in shape:
+        step = inputs[start:start + k]
+        start += k
+        acc, proof = AS.prove(pk, step, old, None, None)
+        assert AS.verify(ctx, vk, [i.instance for i in step], [a.instance for a in old], acc.instance, proof, None)
+        old.append(acc)
+    assert AS.decide(dk, old[-1], None)
+    xy, inf = ck.read()
+    gens = [h.np_to_point(C, xy[i], inf[i]) for i in range(degree + 1)]
+    cm = old[-1].instance.commitment
+    assert h.np_to_point(C, cm.elem[0], cm.elem[1]) == o.msm_naive(C, gens, [c % C.r for c in old[-1].witness.coeffs])
+
+
 while time.time() < t_end:
-    if rs.rand() < 0.35:
+    u = rs.rand()
+    if u < 0.25:
         nark_chain()
         n_chains += 1
+        continue
+    if u < 0.40:
+        ipa_chain()
+        n_ipa += 1
+        continue
+    if u < 0.55:
+        trivial_chain()
+        n_trivial += 1
         continue
     n = int(rs.choice([1, 2, 3, 7, 23, 64, 257]))
     ck = PedersenCommitment.setup(ctx, n, seed=int(rs.randint(1 << 30)))
@@ -85,4 +131,5 @@ while time.time() < t_end:
             raise
         n_cases += 1
     ck.free()
-print(f"fuzz_schemes ok: {n_cases} hp_as proves and {n_chains} r1cs_nark_as chains ({n_steps} accumulation steps) against the oracle in {budget:.0f} s (seed {seed})")
+print(f"fuzz_schemes ok: {n_cases} hp_as proves, {n_chains} r1cs_nark_as chains ({n_steps} accumulation steps), {n_ipa} ipa_pc_as chains and "
+      f"{n_trivial} trivial_pc_as chains against the oracle in {budget:.0f} s (seed {seed}{', host backend' if HOST else ''})")
