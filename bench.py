@@ -59,6 +59,8 @@ def main() -> int:
     ap.add_argument("--no-precompute", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-schemes", action="store_true", help="skip the accumulations/sec lines (second half of the metric)")
+    ap.add_argument("--cpu-leg-max-log2", type=int, default=None,
+                    help="cap the sizes of the accumulations' CPU legs (tests: the same code path in seconds; every entry names its size)")
     ap.add_argument("--no-bls", action="store_true", help="skip config.pairs_per_s_bls12_381_2p20 (BASELINE config 3's MSM)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-gpu: functional check of the N > 1 path with every rank on GPU 0 (numbers meaningless)")
@@ -383,7 +385,7 @@ def main() -> int:
     if rank == 0:
         if not args.no_schemes and args.log2n == 20 and args.curve == "pallas":
             if world == 1:
-                result["accumulations"] = scheme_rates()
+                result["accumulations"] = scheme_rates(cpu_leg_max_log2=args.cpu_leg_max_log2)
             else:
                 # the N-GPU form of BASELINE configs 2-5 (strong scaling: the same sizes as the N = 1 line's `accumulations`): ONE
                 # process over the N devices through amsm_ctx_create_multi, after the ranks' process group is gone (the other
@@ -441,7 +443,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_scheme_rates(exe, out):
+def cpu_scheme_rates(exe, out, max_log2=None):
     """The CPU side of accumulations/sec (the reference's harness times prove / verify / decide on the CPU, examples/scaling-as.rs:94-122):
     every GPU entry of `out` gets a `cpu` sub-object from the SAME profile_as command on the library's host backend (--device -1).  The
     runs are separate processes with AMSM_HOST_THREADS helpers each, started side by side when the host has cores for all of them (a GPU
@@ -451,8 +453,8 @@ def cpu_scheme_rates(exe, out):
     # one process per (entry, shape), longest first, at most FOUR at a time: fourteen side by side (224 threads on the box's 256
     # hardware threads) ran the same proves 4-15x slower than seven did (round 6, profiles/r06_experiments.md) -- a CPU figure
     # measured under that contention would flatter the GPU
-    jobs = [(scheme, lg, extra, tag, (cpu[shape], shape)) for scheme, lg, extra, tag, cpu in SCHEME_RUNS if cpu is not None
-            for shape in ("harness", "n2")]
+    jobs = [(scheme, lg, extra, tag, (cpu[shape] if max_log2 is None else min(cpu[shape], max_log2), shape))
+            for scheme, lg, extra, tag, cpu in SCHEME_RUNS if cpu is not None for shape in ("harness", "n2")]
     jobs.sort(key=lambda j: -CPU_LEG_COST.get((j[0], j[4][0]), 5) * (1.5 if j[4][1] == "harness" else 1.0))
     cores = os.cpu_count() or 1
     threads = max(1, min(16, cores))  # caller + helpers per run
@@ -499,7 +501,7 @@ def cpu_scheme_rates(exe, out):
             out[key]["cpu"] = e
 
 
-def scheme_rates(devices=None):
+def scheme_rates(devices=None, cpu_leg_max_log2=None):
     """accumulations/sec (one `prove` = one accumulation; BASELINE.json's second metric) through the C++ scheme drivers:
     tools/profile_as.cpp, the reference's harness (examples/scaling-as.rs:38-138), at the sizes of BASELINE.json's configs --
     the harness's shape (1 input + the same accumulator twice, zk) and the n_all = 2 no-zk shape -- after the timed region
@@ -559,7 +561,7 @@ def scheme_rates(devices=None):
                 except Exception as e:  # noqa: BLE001
                     out[f"{scheme}_2^{lg}{tag}" + ("" if sponge == "poseidon" else "_sha256")] = {"error": f"{type(e).__name__}: {e}"}
         if not multi:
-            cpu_scheme_rates(exe, out)
+            cpu_scheme_rates(exe, out, cpu_leg_max_log2)
     except Exception as e:  # noqa: BLE001
         out["error"] = f"{type(e).__name__}: {e}"
     return out

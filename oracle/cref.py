@@ -70,8 +70,13 @@ def fq_limbs(curve_id: int) -> int:
 
 
 def msm(curve_id: int, bases_xy: np.ndarray, scalars: np.ndarray, is_inf: Optional[np.ndarray] = None,
-        threads: int = 1) -> Tuple[np.ndarray, bool]:
-    """ark-ec-style CPU MSM.  bases_xy (n, 2L) uint64 Montgomery affine; scalars (n, 4) canonical."""
+        threads: Optional[int] = None) -> Tuple[np.ndarray, bool]:
+    """ark-ec-style CPU MSM.  bases_xy (n, 2L) uint64 Montgomery affine; scalars (n, 4) canonical.
+    threads: window-parallel workers (the result does not depend on it); None = min(cores, 20) -- the checker should not be the slow
+    part of a parity test (round 6: the GPU suite spent most of its 13 minutes in single-threaded oracle MSMs); 1 = ark-ec's default
+    features, what bench.py's `single_thread_value` times."""
+    if threads is None:
+        threads = max(1, min(os.cpu_count() or 1, 20))
     L = fq_limbs(curve_id)
     b = np.ascontiguousarray(bases_xy, dtype=np.uint64).reshape(-1, 2 * L)
     s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)

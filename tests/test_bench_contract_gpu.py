@@ -22,7 +22,8 @@ def _line(out):
 
 
 def test_default_line_n1(built_lib):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3"], capture_output=True,
+    # (--cpu-leg-max-log2 14: the CPU legs of `accumulations` at <= 2^14 -- the same code path in seconds instead of a minute)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--cpu-leg-max-log2", "14"], capture_output=True,
                        text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
@@ -48,6 +49,7 @@ def test_default_line_n1(built_lib):
         c = v["cpu"]
         assert c["verified"] is True and c["accumulations_per_s"] > 0 and c["log2_size"] >= 10, (k, c)
         assert ("gpu_over_cpu_prove" in c) == bool(c.get("full_size")), (k, c)
+        assert c["log2_size"] <= 14 and c["full_size"] == (c["log2_size"] == int(k.split("^")[1].split("_")[0])), (k, c)
     for k in ("trivial_pc_as_2^10_harness_1in_2acc_zk", "ipa_pc_as_2^16_n2_1in_1acc_nozk", "r1cs_nark_as_2^18_n2_1in_1acc_nozk",
               "hp_as_2^22_n2_1in_1acc_nozk", "ipa_pc_as_2^20_n2_1in_1acc_nozk_bls12_381"):
         assert acc[k]["cpu"].get("verified") is True, (k, acc[k]["cpu"])
