@@ -150,6 +150,51 @@ class ShardedMSM:
         return np.array(outs, dtype=np.uint64), np.array(infs, dtype=bool)
 
 
+class ReplicatedMSM:
+    """The one-process-per-GPU form of a REPLICATED key (round 6; the one-process form is amsm.h AMSM_BASES_REPLICATE): every
+    rank holds the WHOLE committer key and the whole scalar vectors -- what a small key wants, where point-sharding 2^18
+    generators eight ways leaves every GPU a 2^15-pair sliver per MSM -- and MSM v of a batch runs, whole, on rank v mod world.
+    The data path has no exchange of partial sums at all; because every rank of a torchrun job needs every result, the ranks
+    all-gather the finished AFFINE points once per batch (2L + 1 u64 each).  `r1cs_nark_as::prove` issues 2-8 independent
+    commitments per round (src/r1cs_nark_as/r1cs_nark/mod.rs:216-218,234-236,251,261; src/r1cs_nark_as/mod.rs:394-410)."""
+
+    def __init__(self, ck, group=None):
+        import torch.distributed as dist
+        self.ck, self.ctx, self.group = ck, ck.ctx, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def msm_batch(self, vecs, mont: bool = True):
+        """len(vecs) MSMs over the key -> (k x 2L u64, k bools), identical on every rank, in call order"""
+        import torch
+        import torch.distributed as dist
+        from .engine import VariableBaseMSM
+        k, L2 = len(vecs), 2 * self.ctx.fq_limbs
+        mine = [v for i, v in enumerate(vecs) if i % self.world == self.rank]
+        slots = -(-k // self.world) if k else 0
+        buf = np.zeros((max(slots, 1), L2 + 1), dtype=np.uint64)
+        if mine:
+            pts, infs = VariableBaseMSM.multi_scalar_mul_batch(self.ck, mine, mont=mont)
+            buf[: len(mine), :L2] = pts
+            buf[: len(mine), L2] = np.asarray(infs, dtype=np.uint64)
+        if self.world == 1:
+            allb = buf[None]
+        else:
+            # (affine results live on the host: gathered as CPU tensors over gloo, or through a device tensor over RCCL)
+            t = torch.from_numpy(buf.view(np.int64).copy()).reshape(-1)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.to(f"cuda:{self.ctx.device}")
+            out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t, group=self.group)
+            allb = out.cpu().numpy().view(np.uint64).reshape((self.world,) + buf.shape)
+        pts = np.zeros((k, L2), dtype=np.uint64)
+        infs = np.zeros((k,), dtype=bool)
+        for v in range(k):
+            row = allb[v % self.world][v // self.world]
+            pts[v], infs[v] = row[:L2], bool(row[L2])
+        return pts, infs
+
+
 class ShardedCommitterKey:
     """A committer key whose generators are spread over the ranks: rank r holds [lo_r, hi_r) (`shard_bounds`) as an
     ordinary HBM-resident `engine.CommitterKey`, and every vector the schemes commit to is sharded the same way (rank r

@@ -148,3 +148,48 @@ def test_sharded_msm_world2_gloo_on_the_host_backend(n, cref, built_lib):
     for rank, out, inf, outs, infs in res:
         assert inf == rinf and out == ref.tolist(), rank
         assert infs == [rinf, rinf2, rinf] and outs == [ref.tolist(), ref2.tolist(), ref.tolist()], rank
+
+
+# ---- REPLICATED keys, the one-process-per-GPU form (round 6): whole MSMs dealt to the ranks, one all-gather of affine results --------
+def _worker_replicated(rank, world, init_file, n, q):
+    from accumulation_amd import CommitterKey, Context, ffi
+    from accumulation_amd.dist import ReplicatedMSM
+    from oracle import cref
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        c = o.PALLAS
+        xy = cref.rng_points(c.curve_id, 0x5EED1001, n)
+        ctx = Context(ffi.AMSM_PALLAS, device=ffi.AMSM_DEVICE_HOST)
+        ck = CommitterKey.load(ctx, xy, None, ffi.AMSM_BASES_DEFAULT)  # the WHOLE key on every rank
+        vecs = [ctx.upload(cref.rng_frs(c.curve_id, 0x5EED0100 + j, n)) for j in range(5)]
+        outs, infs = ReplicatedMSM(ck).msm_batch(vecs, mont=False)
+        none, _ = ReplicatedMSM(ck).msm_batch([], mont=False)
+        q.put((rank, np.asarray(outs).tolist(), [bool(x) for x in infs], len(none)))
+        ck.free()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_replicated_msm_over_gloo_on_the_host_backend(world, cref, built_lib):
+    """five MSMs over a replicated key on two / three gloo ranks of the library's host backend: rank r computes MSMs r, r + world,
+    .. whole, one all-gather of the affine results, every rank ends with all five in call order -- equal to the CPU restatement"""
+    n = 3000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "init")
+        procs = [ctx.Process(target=_worker_replicated, args=(r, world, init_file, n, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    c = o.PALLAS
+    pts = cref.rng_points(c.curve_id, 0x5EED1001, n)
+    refs = [cref.msm(c.curve_id, pts, cref.rng_frs(c.curve_id, 0x5EED0100 + j, n)) for j in range(5)]
+    for rank, outs, infs, n_none in res:
+        assert n_none == 0
+        assert infs == [bool(r[1]) for r in refs] and outs == [r[0].tolist() for r in refs], rank
