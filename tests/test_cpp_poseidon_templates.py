@@ -31,7 +31,7 @@ def _six_scenarios(name, device):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     lines = out.stdout.splitlines()
     assert "done" in lines[-1] and not any(ln.startswith("exception") for ln in lines)
-    ok = [ln for ln in lines if ln.startswith("scenario ") and ln.endswith(" ok")]
+    ok = [ln for ln in lines if ln.startswith("scenario ") and " ok " in ln + " "]  # ("scenario <name> [zk] ok <iterations>")
     if name != "r1cs_nark":  # the NARK alone is not an accumulation scheme: its check has prove / verify lines instead
         expected = 6 if name == "trivial_pc_as" else 12  # six scenarios (x zk / no-zk where the scheme has a zk mode)
         assert len(ok) == expected, out.stdout[-3000:]
