@@ -446,19 +446,20 @@ def cpu_model():
 def cpu_scheme_rates(exe, out, max_log2=None):
     """The CPU side of accumulations/sec (the reference's harness times prove / verify / decide on the CPU, examples/scaling-as.rs:94-122):
     every GPU entry of `out` gets a `cpu` sub-object from the SAME profile_as command on the library's host backend (--device -1).  The
-    runs are separate processes with AMSM_HOST_THREADS helpers each, started side by side when the host has cores for all of them (a GPU
-    box: 128-256 cores), else one after the other; each bounded by CPU_LEG_TIMEOUT_S.  One repetition, no warm-up (--cold)."""
+    runs are separate processes with AMSM_HOST_THREADS helpers each, one after the other (see below), each bounded by
+    CPU_LEG_TIMEOUT_S.  One repetition, no warm-up (--cold: measured within 3 % of a warmed-up repetition when the run has the box
+    to itself)."""
     import subprocess
     from concurrent.futures import ThreadPoolExecutor
-    # one process per (entry, shape), longest first, at most FOUR at a time: fourteen side by side (224 threads on the box's 256
-    # hardware threads) ran the same proves 4-15x slower than seven did (round 6, profiles/r06_experiments.md) -- a CPU figure
-    # measured under that contention would flatter the GPU
+    # one process per (entry, shape), ONE AT A TIME: the host backend's MSMs share the memory system -- four runs of 16 threads side
+    # by side on a 2 x 64-core box ran the hp_as 2^22 prove 3.4x slower than the same run alone (6.2-7.4 s against 1.85 s; fourteen
+    # side by side: 4-15x; profiles/r06_experiments.md section 3) -- a CPU figure measured under contention would flatter the GPU
     jobs = [(scheme, lg, extra, tag, (cpu[shape] if max_log2 is None else min(cpu[shape], max_log2), shape))
             for scheme, lg, extra, tag, cpu in SCHEME_RUNS if cpu is not None for shape in ("harness", "n2")]
     jobs.sort(key=lambda j: -CPU_LEG_COST.get((j[0], j[4][0]), 5) * (1.5 if j[4][1] == "harness" else 1.0))
     cores = os.cpu_count() or 1
     threads = max(1, min(16, cores))  # caller + helpers per run
-    side_by_side = max(1, min(4, len(jobs), cores // (2 * threads)))  # (never more than half the hardware threads busy)
+    side_by_side = 1
     out["cpu"] = {"backend": "libamsm.so host backend (AMSM_DEVICE_HOST: window-parallel signed-digit Pippenger, vector loops on the host pool; "
                              "product code -- not oracle/, not ark-ec)", "threads_per_run": threads, "runs_side_by_side": side_by_side,
                   "host_cores": cores, "cpu_model": cpu_model(), "repetitions": 1,
