@@ -43,6 +43,10 @@ void launch_bucket_reduce_quad(hipStream_t st, u32 red_blocks, const u32* bucket
 template <class Fq>
 void launch_bucket_reduce_fold_quad(hipStream_t st, u32 red_blocks, const u32* buckets, MsmGeom g, u32* partial, u32* ticket, u32* out,
                                     const u32* flags, u32* host_mirror);
+// round 6: the jump fold of an IPA opening (msm_kernels.h: k_ipa_jump_accum): n_lists lists, m0 (a multiple of 64) outputs
+template <class Fq>
+void launch_ipa_jump_accum(hipStream_t st, const u32* table, const u32* entries, const u32* list_off, const u32* list_slot, u32 n_lists,
+                           u32 m0, u32 nb, u32* buckets);
 template <class Fq>
 void launch_fold_quad(hipStream_t st, u32 n_sets, const u32* in, u32 n_per_set, u32* out, const u32* flags, u32* host_mirror = nullptr,
                       bool clear_flags = false);  // clear_flags: the two words are zeroed once they have been copied out

@@ -929,6 +929,60 @@ __global__ void __launch_bounds__(256) k_fold_quad(const u32* __restrict__ in, u
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 6: the JUMP FOLD of an IPA opening (ark_poly_commit::ipa_pc::open ext, under src/ipa_pc_as/mod.rs:454).  After j rounds the
+// reference holds the folded key B_k = sum_t S_t G_(t m0 + k), k < m0 = n / 2^j, S_t = the product of the round challenges picked
+// by the bits of t -- here the opening never folded the key (every round was a grouped MSM over the ORIGINAL generators), and its
+// late rounds are latency chains of ~0.36 ms whatever their logical size.  This kernel computes all m0 folded generators at once so
+// that the last log2(m0) rounds can run on the host: m0 MSMs of 2^j pairs that SHARE one scalar vector S and read their bases at
+// stride m0.  Shared scalars => shared digits: the host recodes S once (signed c-bit digits over the key's window table
+// T_w[i] = 2^(c w) G_i), splits every |digit| into two bytes (lo + 256 hi) and sorts the (t, w) pairs by byte value -- one list per
+// (byte half, value).  A workgroup of 8 waves takes one list: wave q adds entries q, q + 8, .. for 64 outputs k at once (lane = k:
+// the 64 points T_w[t m0 + k ..] of an entry are ONE contiguous row of the table: coalesced), an LDS tree adds the 8 waves' sums,
+// and the list's sum lands in bucket (value - 1) of set (half m0 + k).  The sets then go through the ordinary weighted bucket
+// reduction (k_bucket_reduce_fold_quad: sum_v v bucket_v) and the host adds lo + 2^8 hi per output.
+// entries[e] = (w * stride + t * m0) | neg << 31;  list_off[l] .. list_off[l + 1]: list l's entries;  list_slot[l] = half * nb + value - 1.
+// buckets: 2 m0 sets of nb records, ZEROED by the launcher (a value without entries stays the identity).  grid = (lists, m0 / 64).
+// ---------------------------------------------------------------------------------------------
+constexpr u32 JUMP_WAVES = 8;
+template <class Fq>
+__global__ void __launch_bounds__(64 * JUMP_WAVES)
+    k_ipa_jump_accum(const u32* __restrict__ table, const u32* __restrict__ entries, const u32* __restrict__ list_off,
+                     const u32* __restrict__ list_slot, u32 m0, u32 nb, u32* __restrict__ buckets) {
+  __shared__ __attribute__((aligned(16))) u32 lds[(JUMP_WAVES / 2) * 64 * 4 * Fq::W];
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 k = blockIdx.y * 64u + lane;
+  const u32 lo = list_off[blockIdx.x], hi = list_off[blockIdx.x + 1];
+  XYZZ<Fq> acc = xyzz_inf<Fq>();
+  {
+    u32 e = lo + wave;
+    u32 w0 = e < hi ? entries[e] : 0u;
+    Affine<Fq> pt = affine_load<Fq>(table, (size_t)(w0 & 0x7fffffffu) + k);
+    for (; e < hi; e += JUMP_WAVES) {
+      const u32 en = e + JUMP_WAVES < hi ? entries[e + JUMP_WAVES] : w0;
+      const Affine<Fq> nx = affine_load<Fq>(table, (size_t)(en & 0x7fffffffu) + k);  // the next row is requested before this addition
+      xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (w0 >> 31) != 0u));
+      w0 = en;
+      pt = nx;
+    }
+  }
+  // 8 -> 4 -> 2 -> 1 waves through LDS (slot = wave within the receiving half, one record per lane)
+#pragma unroll 1
+  for (u32 h = JUMP_WAVES / 2; h >= 1u; h >>= 1) {
+    if (wave >= h && wave < 2u * h) xyzz_store<Fq>(lds, (size_t)(wave - h) * 64u + lane, acc);
+    __syncthreads();
+    if (wave < h) {
+      const XYZZ<Fq> o = xyzz_load<Fq>(lds, (size_t)wave * 64u + lane);
+      xyzz_add<Fq>(acc, o);
+    }
+    __syncthreads();
+  }
+  if (wave == 0u) {
+    const u32 slot = list_slot[blockIdx.x], half = slot / nb, v = slot - half * nb;
+    xyzz_store<Fq>(buckets, ((size_t)half * m0 + k) * nb + v, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Key preparation
 // ---------------------------------------------------------------------------------------------
 // Batched XYZZ -> affine (Montgomery's trick): lane g converts points g, g + T, g + 2T, ... (T = lanes of the grid, so a

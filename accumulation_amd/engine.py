@@ -84,6 +84,11 @@ class Context:
         except Exception:
             pass
 
+    @property
+    def is_host(self) -> bool:
+        """a context of the library's host backend (amsm_ctx_is_host)"""
+        return bool(self._lib.amsm_ctx_is_host(self._h))
+
     def memory(self) -> dict:
         """Device memory the context holds (amsm_ctx_memory): MSM workspace, live vectors, the allocator's free lists."""
         ws, live, pooled = C.c_size_t(), C.c_size_t(), C.c_size_t()

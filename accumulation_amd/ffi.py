@@ -136,6 +136,7 @@ SIGNATURES = {
     "amsm_ctx_set_replicate_below": (C.c_int, [_vp, _sz]),
     "amsm_bases_replicas": (C.c_int, [_vp]),
     "amsm_ctx_replicated_msms": (C.c_ulonglong, [_vp]),
+    "amsm_ipa_jump_fold": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "amsm_msm_oneshot": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _sz, C.c_int, _vp, _vp]),
     "amsm_vec_random": (C.c_int, [_vp, C.c_uint64, _sz, C.c_int, _vp]),
     "amsm_vec_hadamard": (C.c_int, [_vp, _vp, _vp, _vp, _sz]),

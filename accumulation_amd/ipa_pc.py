@@ -225,9 +225,19 @@ class InnerProductArgPC:
         # expansion, the grouped MSM, both inner products, their h' multiples and one normalisation of L and R.
         hp_xy = None if h_prime[1] else np.ascontiguousarray(h_prime[0], dtype=np.uint64)
         prev_x = None
+        jumped = None
         while n > 1:
             half = n // 2
             j = len(xs) - (log_n - log_key)  # challenges since cur_key was formed
+            # Round 6 -- the JUMP FOLD: once the vectors are down to JUMP_M entries, the key folded by the j challenges so far
+            # (JUMP_M generators) comes from ONE pass over the key's window table (amsm_ipa_jump_fold) and the remaining
+            # log2(JUMP_M) rounds -- ~0.36 ms each on the device whatever their logical size -- run on the host over those few
+            # generators; the final folded key falls out of the last fold instead of one more full-size MSM.  Keys that do not
+            # qualify (AMSM_E_UNSUPPORTED: folded / plain keys, 20-bit tables, sharded keys) keep their rounds on the device.
+            if n == cls._jump_m() and j >= 1 and key.num_shards == 1:
+                jumped = cls._host_rounds(ctx, fr, cur_key, log_key, xs, j, n, coeffs, z, h_prime, round_challenge, l_vec, r_vec)
+                if jumped is not None:
+                    break
             xi = fr.to_limbs_many(xs[len(xs) - j:]) if j else None
             xy = np.zeros((2, 2 * ctx.fq_limbs), dtype=np.uint64)
             inf = np.zeros((2,), dtype=np.uint8)
@@ -249,6 +259,11 @@ class InnerProductArgPC:
                     cur_key.free()
                 cur_key, log_key = folded, log_key - 1
             n = half
+        if jumped is not None:
+            if cur_key is not key:
+                cur_key.free()
+            final_key, c = jumped
+            return Proof(l_vec, r_vec, final_key, c, hiding_comm, proof_rand)
         since = xs[log_n - log_key:]
         if since:
             s_vec = SuccinctCheckPolynomial(since).compute_coeffs(ctx)
@@ -265,6 +280,51 @@ class InnerProductArgPC:
         if xs:
             c = (c + pow(xs[-1], -1, fr.r) * fr.from_limbs(head[1])) % fr.r
         return Proof(l_vec, r_vec, (final_key, not final_key.any()), c, hiding_comm, proof_rand)
+
+    @staticmethod
+    def _jump_m() -> int:
+        """vector length at which an opening jumps to the host (AMSM_IPA_JUMP=0: never; =M: at M entries, a power of two >= 64)"""
+        import os
+        return int(os.environ.get("AMSM_IPA_JUMP", "64"))
+
+    @classmethod
+    def _host_rounds(cls, ctx, fr: Fr, cur_key, log_key: int, xs: List[int], j: int, n: int, coeffs: FrVector, z: FrVector, h_prime,
+                     round_challenge: int, l_vec, r_vec):
+        """The last log2(n) rounds of `open` on the host over the n generators amsm_ipa_jump_fold returns (the key folded by the j
+        challenges since cur_key was formed).  Appends to xs, l_vec, r_vec; returns (final_comm_key, c), or None when the key does
+        not qualify.  The same operations as the reference's loop (ark_poly_commit::ipa_pc::open ext): l = <c_r, key_l> + <c_r, z_l> h',
+        r = <c_l, key_r> + <c_l, z_r> h', then c_l += x^-1 c_r, z_l += x z_r, key_l += x key_r."""
+        w = 2 * ctx.fq_limbs
+        xy = np.zeros((n, w), dtype=np.uint64)
+        inf = np.zeros((n,), dtype=np.uint8)
+        xi = fr.to_limbs_many(xs[len(xs) - j:])
+        rc = ctx._lib.amsm_ipa_jump_fold(ctx._h, cur_key._h, log_key, _ptr(xi), j, _ptr(xy), _ptr(inf))
+        if rc == ffi.AMSM_E_UNSUPPORTED:
+            return None
+        ffi.check(rc, "amsm_ipa_jump_fold")
+        B = [(xy[k].copy(), bool(inf[k])) for k in range(n)]
+        # the fold of c and z by the last challenge is still pending on the device (amsm_ipa_round_fused applies it lazily)
+        cz = [[fr.from_limbs(v) for v in vec.view(0, 2 * n).download()] for vec in (coeffs, z)]
+        x, xinv = xs[-1], pow(xs[-1], -1, fr.r)
+        c = [(cz[0][i] + xinv * cz[0][n + i]) % fr.r for i in range(n)]
+        zz = [(cz[1][i] + x * cz[1][n + i]) % fr.r for i in range(n)]
+        hp = [] if h_prime[1] else [h_prime]
+        while n > 1:
+            half = n // 2
+            ip_l = sum(c[half + i] * zz[i] for i in range(half)) % fr.r       # <c_r, z_l>
+            ip_r = sum(c[i] * zz[half + i] for i in range(half)) % fr.r       # <c_l, z_r>
+            l_pt = _lincomb(ctx, B[:half] + hp, c[half:n] + ([ip_l] if hp else []), fr)
+            r_pt = _lincomb(ctx, B[half:n] + hp, c[:half] + ([ip_r] if hp else []), fr)
+            l_vec.append(l_pt)
+            r_vec.append(r_pt)
+            round_challenge = cls._challenge(fr, [round_challenge.to_bytes(16, "little"), l_pt, r_pt])
+            xs.append(round_challenge)
+            x, xinv = round_challenge, pow(round_challenge, -1, fr.r)
+            c = [(c[i] + xinv * c[half + i]) % fr.r for i in range(half)]
+            zz = [(zz[i] + x * zz[half + i]) % fr.r for i in range(half)]
+            B = [_lincomb(ctx, [B[i], B[half + i]], [1, x], fr) for i in range(half)]
+            n = half
+        return B[0], c[0]
 
     @staticmethod
     def _fold_rounds(ctx, log_n: int) -> int:

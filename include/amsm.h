@@ -515,6 +515,19 @@ int amsm_ipa_round_fused(amsm_ctx* ctx, const amsm_bases* key, const uint64_t* x
 /* d_out[p] (p < 2^k) = coefficients of prod_{i=1..k} (1 + xi_i X^(2^(k-i))):
  * `SuccinctCheckPolynomial::compute_coeffs` (ext), call sites src/ipa_pc_as/mod.rs:400 and under :836. k <= 32. */
 int amsm_ipa_check_poly_coeffs(amsm_ctx* ctx, const uint64_t* xi_mont, size_t k, void* d_out);
+/* Round 6 -- the JUMP FOLD of an opening that never folded its key: after j rounds (challenges xi_mont[0 .. j), the first one pairs the
+ * two halves of the key) the reference holds the folded key `key_l[i] += key_r[i] * xi` applied j times (ark_poly_commit::ipa_pc ext,
+ * under src/ipa_pc_as/mod.rs:454): m0 = 2^(log_key - j) generators B_k = sum_t S_t G_(t m0 + k), S_t = the product of the challenges
+ * the bits of t pick.  This call computes all m0 of them from the key's window table in one pass (m0 MSMs of 2^j pairs that share
+ * one scalar vector: one digit sort on the host, one accumulation launch whose waves read 64 outputs' points as one contiguous
+ * table row, the ordinary weighted bucket reduction) so that the driver can run the LAST log2(m0) rounds -- latency chains of
+ * ~0.36 ms each on the device whatever their logical size -- on the host over those few generators, and take the final folded key
+ * from there instead of from one more full-size MSM.  out_xy_mont: m0 * 2 * limbs u64.
+ * AMSM_E_UNSUPPORTED when the key does not qualify (a single-device precomputed key with equal-width windows covering 256 bits --
+ * the tables of keys of up to 2^16 and of 2^18 / 2^19 generators --, m0 a multiple of 64; the host backend takes any key): the
+ * caller then keeps running its rounds through amsm_ipa_round_fused.  Proofs do not depend on the choice. */
+int amsm_ipa_jump_fold(amsm_ctx* ctx, const amsm_bases* key, size_t log_key, const uint64_t* xi_mont, size_t j,
+                       uint64_t* out_xy_mont, uint8_t* out_is_inf);
 
 /* ---- R1CS matrices (row-sparse) for the NARK prover -------------------------------------------- */
 typedef struct amsm_matrix amsm_matrix;

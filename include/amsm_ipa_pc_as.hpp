@@ -210,6 +210,74 @@ struct InnerProductArgPC {
     return out;
   }
 
+  // vector length at which an opening jumps to the host (AMSM_IPA_JUMP=0: never; =M: at M entries, a power of two >= 64)
+  static size_t jump_m() {
+    const char* e = std::getenv("AMSM_IPA_JUMP");
+    return e ? (size_t)std::atol(e) : 64;
+  }
+  // The last log2(cur) rounds of `open` on the host over the `cur` generators amsm_ipa_jump_fold returned (the key folded by the
+  // challenges so far): the reference's own loop (ark_poly_commit::ipa_pc::open ext) -- l = <c_r, key_l> + <c_r, z_l> h',
+  // r = <c_l, key_r> + <c_l, z_r> h', then c_l += x^-1 c_r, z_l += x z_r, key_l += x key_r.  The fold of c and z by the last
+  // challenge is still pending on the device (amsm_ipa_round_fused applies it lazily): applied here first.
+  static void host_rounds(Context& ctx, const FrX& fr, const std::vector<uint64_t>& bxy, const std::vector<uint8_t>& binf, size_t cur,
+                          const FrVector& coeffs, const FrVector& z, const Affine& h_prime, Fr rc_canon, std::vector<Fr>& xs, Proof& proof) {
+    const size_t w = 2 * (size_t)ctx.fq_limbs();
+    std::vector<Affine> B(cur);
+    for (size_t k = 0; k < cur; k++) {
+      B[k].xy.assign(bxy.begin() + (long)(k * w), bxy.begin() + (long)((k + 1) * w));
+      B[k].infinity = binf[k] != 0;
+    }
+    std::vector<Fr> cv(2 * cur), zv(2 * cur);
+    amsm::check(amsm_dev_download(ctx.get(), cv.data(), coeffs.ptr(), 2 * cur * sizeof(Fr)), "amsm_dev_download");
+    amsm::check(amsm_dev_download(ctx.get(), zv.data(), z.ptr(), 2 * cur * sizeof(Fr)), "amsm_dev_download");
+    Fr x = xs.back(), xinv = fr.inv(x);
+    std::vector<Fr> c(cur), zz(cur);
+    for (size_t i = 0; i < cur; i++) {
+      c[i] = fr.add(cv[i], fr.mul(xinv, cv[cur + i]));
+      zz[i] = fr.add(zv[i], fr.mul(x, zv[cur + i]));
+    }
+    const Fr one = fr.one();
+    while (cur > 1) {
+      const size_t half = cur / 2;
+      Fr ip_l = fr.zero(), ip_r = fr.zero();
+      for (size_t i = 0; i < half; i++) {
+        ip_l = fr.add(ip_l, fr.mul(c[half + i], zz[i]));  // <c_r, z_l>
+        ip_r = fr.add(ip_r, fr.mul(c[i], zz[half + i]));  // <c_l, z_r>
+      }
+      hp_as::LincombJob jl, jr;
+      for (size_t i = 0; i < half; i++) {
+        jl.first.push_back(&B[i]);
+        jl.second.push_back(c[half + i]);
+        jr.first.push_back(&B[half + i]);
+        jr.second.push_back(c[i]);
+      }
+      if (!h_prime.infinity) {
+        jl.first.push_back(&h_prime);
+        jl.second.push_back(ip_l);
+        jr.first.push_back(&h_prime);
+        jr.second.push_back(ip_r);
+      }
+      std::vector<Affine> lr = hp_as::host_lincomb_batch(ctx, {jl, jr});
+      proof.l_vec.push_back(lr[0]);
+      proof.r_vec.push_back(lr[1]);
+      rc_canon = Challenge(fr).bytes(le_bytes(rc_canon, 16)).point(lr[0]).point(lr[1]).squeeze_canonical();
+      x = fr.to_mont(rc_canon);
+      xinv = fr.inv(x);
+      xs.push_back(x);
+      std::vector<hp_as::LincombJob> folds(half);
+      for (size_t i = 0; i < half; i++) {
+        c[i] = fr.add(c[i], fr.mul(xinv, c[half + i]));
+        zz[i] = fr.add(zz[i], fr.mul(x, zz[half + i]));
+        folds[i] = {{&B[i], &B[half + i]}, {one, x}};
+      }
+      std::vector<Affine> nb = hp_as::host_lincomb_batch(ctx, folds);
+      for (size_t i = 0; i < half; i++) B[i] = nb[i];
+      cur = half;
+    }
+    proof.final_comm_key = B[0];
+    proof.c = c[0];
+  }
+
   // open_individual_opening_challenges for ONE polynomial with opening challenge 1
   static Proof open(const CommitterKey& ck, const FrVector& polynomial, const Commitment& commitment, const Fr& point, const Fr& rand,
                     bool hiding, const hp_as::Rng& rng) {
@@ -266,8 +334,26 @@ struct InnerProductArgPC {
     // One library call per round (amsm_ipa_round_fused): the previous round's fold of c and z (in place), the scalar
     // expansion, the grouped MSM, both inner products, their h' multiples and one normalisation of L and R.
     const size_t w = 2 * (size_t)ctx.fq_limbs();
+    bool jumped = false;
     while (cur > 1) {
       size_t half = cur / 2, j = xs.size() - (log_n - log_key);  // challenges since cur_key was formed
+      // Round 6 -- the JUMP FOLD: once the vectors are down to jump_m() entries, the key folded by the j challenges so far comes
+      // from ONE pass over the key's window table (amsm_ipa_jump_fold) and the remaining rounds -- ~0.36 ms each on the device
+      // whatever their logical size -- run on the host over those few generators (host_rounds below); the final folded key falls
+      // out of the last fold instead of one more full-size MSM.  A key that does not qualify (AMSM_E_UNSUPPORTED: folded / plain
+      // keys, 20-bit tables, sharded keys) keeps its rounds on the device.  The proof does not depend on the choice.
+      if (cur == jump_m() && j >= 1 && amsm_bases_num_shards(cur_key->get()) == 1) {
+        std::vector<uint64_t> bxy(cur * w);
+        std::vector<uint8_t> binf(cur);
+        const int rc = amsm_ipa_jump_fold(ctx.get(), cur_key->get(), log_key, reinterpret_cast<const uint64_t*>(xs.data() + (xs.size() - j)), j,
+                                          bxy.data(), binf.data());
+        if (rc == AMSM_OK) {
+          host_rounds(ctx, fr, bxy, binf, cur, coeffs, z, h_prime, rc_canon, xs, proof);
+          jumped = true;
+          break;
+        }
+        if (rc != AMSM_E_UNSUPPORTED) amsm::check(rc, "amsm_ipa_jump_fold");
+      }
       std::vector<uint64_t> lr_xy(2 * w);
       uint8_t lr_inf[2] = {0, 0};
       Fr ips[2];  // <c_r, z_l>, <c_l, z_r>
@@ -292,6 +378,11 @@ struct InnerProductArgPC {
         log_key--;
       }
       cur = half;
+    }
+    if (jumped) {
+      proof.hiding_comm = hiding_comm;
+      proof.rand = proof_rand;
+      return proof;
     }
     std::vector<Fr> since(xs.begin() + (long)(log_n - log_key), xs.end());
     if (!since.empty()) {

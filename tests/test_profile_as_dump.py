@@ -170,3 +170,42 @@ def test_cpp_driver_over_replicated_keys_same_bytes(built_lib, tmp_path):
             one, _ = cpp_dump(tmp_path, scheme, lg, shape, "poseidon", 0, extra=extra)
             many, _ = cpp_dump(tmp_path, scheme, lg, shape, "poseidon", 0, extra=extra + dev8)
             assert one == many, (scheme, shape, extra)
+
+
+# ---- the jump fold of the IPA opening (round 6): the last rounds on the host over amsm_ipa_jump_fold's generators -----------------------
+def _cpp_dump_env(tmp_path, env, *args, **kw):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return cpp_dump(tmp_path, *args, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("shape", ["n2", "harness"])
+def test_ipa_jump_fold_does_not_change_the_proof_on_the_host_backend(built_lib, tmp_path, shape):
+    """AMSM_IPA_JUMP=0 (every round through amsm_ipa_round_fused, the final key from the check polynomial's MSM) against jumps at 4 and
+    at 16 entries (the C++ driver's host rounds): the same accumulator and proof bytes -- and equal to the Python mirror's"""
+    ref, _ = _cpp_dump_env(tmp_path, {"AMSM_IPA_JUMP": "0"}, "ipa_pc_as", 7, shape, "poseidon", -1)
+    for m in ("4", "16"):
+        got, _ = _cpp_dump_env(tmp_path, {"AMSM_IPA_JUMP": m}, "ipa_pc_as", 7, shape, "poseidon", -1)
+        assert got == ref, m
+    os.environ["AMSM_IPA_JUMP"] = "8"
+    try:
+        compare(tmp_path, "ipa_pc_as", 7, shape, "poseidon", -1)  # mirror (jumping at 8) == C++ (jumping at 8) == the above
+    finally:
+        del os.environ["AMSM_IPA_JUMP"]
+
+
+@pytest.mark.gpu
+def test_ipa_jump_fold_on_the_device_same_bytes(built_lib, tmp_path):
+    """BASELINE config 2's size on the GPU: the jump at 64 entries after ten device rounds (the default) against no jump at all"""
+    for shape in ("n2", "harness"):
+        ref, _ = _cpp_dump_env(tmp_path, {"AMSM_IPA_JUMP": "0"}, "ipa_pc_as", 16, shape, "poseidon", 0)
+        got, _ = _cpp_dump_env(tmp_path, {"AMSM_IPA_JUMP": "64"}, "ipa_pc_as", 16, shape, "poseidon", 0)
+        big, _ = _cpp_dump_env(tmp_path, {"AMSM_IPA_JUMP": "256"}, "ipa_pc_as", 16, shape, "poseidon", 0)
+        assert got == ref and big == ref, shape
