@@ -936,14 +936,17 @@ __global__ void __launch_bounds__(256) k_fold_quad(const u32* __restrict__ in, u
 // that the last log2(m0) rounds can run on the host: m0 MSMs of 2^j pairs that SHARE one scalar vector S and read their bases at
 // stride m0.  Shared scalars => shared digits: the host recodes S once (signed c-bit digits over the key's window table
 // T_w[i] = 2^(c w) G_i), splits every |digit| into two bytes (lo + 256 hi) and sorts the (t, w) pairs by byte value -- one list per
-// (byte half, value).  A workgroup of 8 waves takes one list: wave q adds entries q, q + 8, .. for 64 outputs k at once (lane = k:
-// the 64 points T_w[t m0 + k ..] of an entry are ONE contiguous row of the table: coalesced), an LDS tree adds the 8 waves' sums,
-// and the list's sum lands in bucket (value - 1) of set (half m0 + k).  The sets then go through the ordinary weighted bucket
-// reduction (k_bucket_reduce_fold_quad: sum_v v bucket_v) and the host adds lo + 2^8 hi per output.
-// entries[e] = (w * stride + t * m0) | neg << 31;  list_off[l] .. list_off[l + 1]: list l's entries;  list_slot[l] = half * nb + value - 1.
-// buckets: 2 m0 sets of nb records, ZEROED by the launcher (a value without entries stays the identity).  grid = (lists, m0 / 64).
+// (byte half, value), cut into PIECES of a few dozen entries so that the launch fills the chip.  A workgroup of JUMP_WAVES waves takes
+// one piece: wave q adds entries q, q + JUMP_WAVES, .. for 64 outputs k at once (lane = k: the 64 points T_w[t m0 + k ..] of an entry are
+// ONE contiguous row of the table: coalesced), an LDS tree adds the waves' sums, and the piece's sum lands in bucket (value - 1) of set
+// ((piece number within its list, half), k) -- pieces of one list are buckets of the SAME weight in different sets.  The sets then go
+// through the ordinary weighted bucket reduction (k_bucket_reduce_fold_quad: sum_v v bucket_v) and the host adds the sets of an
+// output: lo + 2^8 hi.
+// entries[e] = (w * stride + t * m0) | neg << 31;  list_off[l] .. list_off[l + 1]: piece l's entries;  list_slot[l] = (2 piece + half) nb +
+// value - 1.  buckets: 2 n_pieces_max m0 sets of nb records, ZEROED by the launcher (a value without entries stays the identity).
+// grid = (pieces, m0 / 64).
 // ---------------------------------------------------------------------------------------------
-constexpr u32 JUMP_WAVES = 8;
+constexpr u32 JUMP_WAVES = 4;  // (8 waves of 159 VGPRs: ONE workgroup per CU -- 250 us for 2^16 generators; 4: three per CU)
 template <class Fq>
 __global__ void __launch_bounds__(64 * JUMP_WAVES)
     k_ipa_jump_accum(const u32* __restrict__ table, const u32* __restrict__ entries, const u32* __restrict__ list_off,
@@ -977,8 +980,8 @@ __global__ void __launch_bounds__(64 * JUMP_WAVES)
     __syncthreads();
   }
   if (wave == 0u) {
-    const u32 slot = list_slot[blockIdx.x], half = slot / nb, v = slot - half * nb;
-    xyzz_store<Fq>(buckets, ((size_t)half * m0 + k) * nb + v, acc);
+    const u32 slot = list_slot[blockIdx.x], grp = slot / nb, v = slot - grp * nb;  // grp = 2 * piece + half
+    xyzz_store<Fq>(buckets, ((size_t)grp * m0 + k) * nb + v, acc);
   }
 }
 

@@ -403,14 +403,14 @@ SCHEME_RUNS = (
     ("trivial_pc_as", 10, ["--reps", "5"], "", {"harness": 10, "n2": 10}),                     # config 1 on the GPU context
     ("trivial_pc_as", 10, ["--reps", "5", "--device", "-1"], "_host_backend", None),           # config 1 as it reads: no GPU
     ("ipa_pc_as", 16, ["--reps", "3"], "", {"harness": 16, "n2": 16}),                         # config 2
-    ("ipa_pc_as", 20, ["--reps", "2", "--curve", "1"], "_bls12_381", {"harness": 16, "n2": 16}),  # config 3; CPU at 2^16 (2^20: minutes)
+    ("ipa_pc_as", 20, ["--reps", "2", "--curve", "1"], "_bls12_381", {"harness": 18, "n2": 18}),  # config 3; CPU at 2^18 (2^20: a minute)
     ("r1cs_nark_as", 18, ["--reps", "3"], "", {"harness": 18, "n2": 18}),                      # config 4
     ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"], "_uniform_witness", {"harness": 18, "n2": 18}),
     ("hp_as", 22, ["--reps", "3"], "", {"harness": 20, "n2": 22}),                             # config 5; CPU harness-zk at 2^20
     ("hp_as", 22, ["--reps", "3", "--constant"], "_harness_constant_inputs", {"harness": 20, "n2": 20}),
 )
 # rough cost of a CPU run (seconds on 16 threads of the GPU box's host, measured in round 6): longest first onto the lanes
-CPU_LEG_COST = {("hp_as", 22): 22, ("hp_as", 20): 14, ("ipa_pc_as", 16): 9, ("r1cs_nark_as", 18): 10, ("trivial_pc_as", 10): 0.1}
+CPU_LEG_COST = {("hp_as", 22): 12, ("hp_as", 20): 7, ("ipa_pc_as", 18): 7, ("ipa_pc_as", 16): 1.5, ("r1cs_nark_as", 18): 3, ("trivial_pc_as", 10): 0.1}
 CPU_LEG_TIMEOUT_S = 70  # per run; the runs go side by side on disjoint cores (cpu_scheme_rates)
 
 

@@ -35,7 +35,7 @@ def test_jump_fold_vs_oracle_and_physical_folds(c, log_key, j):
     try:
         fr = Fr(ctx.curve)
         n = 1 << log_key
-        ck = CommitterKey.generate(ctx, 0x1F0 + log_key, n, ffi.AMSM_BASES_PRECOMPUTE)
+        ck = CommitterKey.generate(ctx, 0x1F0 + log_key, n, ffi.AMSM_BASES_PRECOMPUTE | ffi.AMSM_BASES_NO_DIRECT_TABLE)
         xs = [o.rng_scalar(0x1F1, r) % (1 << 128) or 1 for r in range(j)]
         rc, xy, inf = _jump(ctx, ck, log_key, xs, fr)
         assert rc == ffi.AMSM_OK
@@ -79,7 +79,11 @@ def test_keys_that_do_not_qualify_are_refused_not_miscomputed():
         fr = Fr(ctx.curve)
         plain = CommitterKey.generate(ctx, 5, 1 << 8, ffi.AMSM_BASES_NO_PRECOMPUTE)
         assert _jump(ctx, plain, 8, [3, 5], fr)[0] == ffi.AMSM_E_UNSUPPORTED          # no window table
-        pre = CommitterKey.generate(ctx, 5, 1 << 8, ffi.AMSM_BASES_PRECOMPUTE)
+        ds = CommitterKey.generate(ctx, 5, 1 << 8, ffi.AMSM_BASES_PRECOMPUTE)
+        assert ds.tables()["direct_sum_table"] > 0
+        assert _jump(ctx, ds, 8, [3, 5], fr)[0] == ffi.AMSM_E_UNSUPPORTED             # its rounds are direct sums: faster than the host's
+        ds.free()
+        pre = CommitterKey.generate(ctx, 5, 1 << 8, ffi.AMSM_BASES_PRECOMPUTE | ffi.AMSM_BASES_NO_DIRECT_TABLE)
         assert _jump(ctx, pre, 8, [3, 5, 7], fr)[0] == ffi.AMSM_E_UNSUPPORTED         # m0 = 32: not a multiple of 64
         assert _jump(ctx, pre, 8, [3, 0], fr)[0] == ffi.AMSM_E_INVALID_ARG            # a zero challenge
         assert _jump(ctx, pre, 8, [3, 5], fr)[0] == ffi.AMSM_OK
@@ -98,6 +102,7 @@ def test_opening_with_and_without_the_jump_same_proof(hiding, monkeypatch):
     from accumulation_amd.scalar_field import Fr
     from tests.test_hp_as_scheme_gpu import SchemeRng
     c = o.PALLAS
+    monkeypatch.setenv("AMSM_DIRECT_SUM_MAX_LOG2", "0")  # (keys with a direct-sum table keep their rounds on the device: none here)
     ctx = Context(c.curve_id)
     try:
         fr = Fr(ctx.curve)
@@ -114,6 +119,8 @@ def test_opening_with_and_without_the_jump_same_proof(hiding, monkeypatch):
             comm, rand = IpaPC.commit(ck, poly, hiding, rng)
             proofs.append((comm, IpaPC.open(ck, poly, comm, point, rand, hiding, rng)))
         (c0, p0), (c1, p1) = proofs
+        if not ctx.is_host:  # the jump really ran: the key qualifies
+            assert _jump(ctx, ck.comm_key, 9, [3, 5, 7], fr)[0] == 0
 
         def pts(v):
             return [(np.asarray(a).tolist(), bool(b)) for a, b in v]
