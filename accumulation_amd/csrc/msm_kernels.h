@@ -957,14 +957,19 @@ __global__ void __launch_bounds__(64 * JUMP_WAVES)
   const u32 lo = list_off[blockIdx.x], hi = list_off[blockIdx.x + 1];
   XYZZ<Fq> acc = xyzz_inf<Fq>();
   {
+    // entry words run TWO iterations ahead of their row, rows one ahead of their addition: an iteration used to be the entry's
+    // latency + max(the row's, the addition's) -- ~7 us, 100 us per workgroup (rocprofv3, round 6) -- with the address of the next row
+    // already in a register it is the longer of the two
     u32 e = lo + wave;
     u32 w0 = e < hi ? entries[e] : 0u;
+    u32 w1 = e + JUMP_WAVES < hi ? entries[e + JUMP_WAVES] : w0;
     Affine<Fq> pt = affine_load<Fq>(table, (size_t)(w0 & 0x7fffffffu) + k);
     for (; e < hi; e += JUMP_WAVES) {
-      const u32 en = e + JUMP_WAVES < hi ? entries[e + JUMP_WAVES] : w0;
-      const Affine<Fq> nx = affine_load<Fq>(table, (size_t)(en & 0x7fffffffu) + k);  // the next row is requested before this addition
+      const u32 w2 = e + 2u * JUMP_WAVES < hi ? entries[e + 2u * JUMP_WAVES] : w1;
+      const Affine<Fq> nx = affine_load<Fq>(table, (size_t)(w1 & 0x7fffffffu) + k);  // the next row is requested before this addition
       xyzz_madd<Fq>(acc, affine_neg_if<Fq>(pt, (w0 >> 31) != 0u));
-      w0 = en;
+      w0 = w1;
+      w1 = w2;
       pt = nx;
     }
   }
