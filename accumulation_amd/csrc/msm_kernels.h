@@ -853,16 +853,24 @@ __global__ void __launch_bounds__(256)
   __threadfence();  // acquire: the other blocks' records (other XCDs' L2s) are read from memory
   const u32 n = gridDim.x;
   XYZZ<Fq> acc = xyzz_inf<Fq>();
-  {
+  const u32* in = partial + (size_t)set * n * (4 * Fq::W);
+  if (n <= 4u) {
+    // a handful of records (the small sets of 8-bit windows: ONE): the first quad adds them one after the other -- the workgroup
+    // tree would be 7 more dependent additions on identities
+    if (threadIdx.x < 4u)
+      for (u32 k = 0; k < n; k++) {
+        const XYZZ<Fq> p = xyzz_load<Fq>(in, k);  // (written by other workgroups of THIS launch: read behind the fence above)
+        xyzz_add_quad<Fq>(acc, p);
+      }
+  } else {
     const u32 k0 = threadIdx.x >> 2, nq = blockDim.x >> 2;
-    const u32* in = partial + (size_t)set * n * (4 * Fq::W);
     for (u32 k = k0; k < n; k += nq) {
-      const XYZZ<Fq> p = xyzz_load<Fq>(in, k);  // (written by other workgroups of THIS launch: read behind the fence above)
+      const XYZZ<Fq> p = xyzz_load<Fq>(in, k);
       xyzz_add_quad<Fq>(acc, p);
     }
+    __syncthreads();  // (lds is reused)
+    block_reduce_xyzz_quad<Fq>(acc, lds);
   }
-  __syncthreads();  // (lds is reused)
-  block_reduce_xyzz_quad<Fq>(acc, lds);
   if (threadIdx.x == 0) {
     XYZZ<Fq> e;
     e.x = fe_export<Fq>(acc.x);
