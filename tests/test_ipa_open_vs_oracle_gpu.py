@@ -111,12 +111,13 @@ def test_pallas_2p16_opening(hiding, fold_above):
     _assert_equal(got, ref, accepted, ref_ok)
 
 
-@pytest.mark.parametrize("hiding,fold_above", [(False, None), (True, 17)], ids=["no_zk_default_schedule", "zk_fold_down_to_2p17"])
-def test_bls12_381_2p20_opening(hiding, fold_above):
+@pytest.mark.parametrize("hiding,fold_above,log_n", [(False, None, 20), (True, 16, 18)], ids=["no_zk_default_schedule", "zk_2p18_fold_down_to_2p16"])
+def test_bls12_381_2p20_opening(hiding, fold_above, log_n):
     """BASELINE config 3 (the 384-bit field path).  Default: five physical folds (the first through the 20-bit key's window
     multiples, the top four of which sit off the 20-bit grid -- MsmGeom::n_narrow), then 15 rounds over the 2^15-point key;
-    17: three folds, then 17 rounds of grouped MSMs over a plain 2^17-point key (8-bit windows, the chunked pipeline)"""
-    got, ref, accepted, ref_ok, stats = _open_both_ways(o.BLS12_381_G1, 20, hiding, fold_above)
+    the zk run (at 2^18: the suite's time budget): two folds, then 16 rounds of grouped MSMs over a plain 2^16-point key (8-bit
+    windows, the chunked pipeline with 128-bucket sets)"""
+    got, ref, accepted, ref_ok, stats = _open_both_ways(o.BLS12_381_G1, log_n, hiding, fold_above)
     _assert_equal(got, ref, accepted, ref_ok)
     assert stats["fallbacks"] == 0
 
