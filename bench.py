@@ -406,6 +406,10 @@ SCHEME_RUNS = (
     ("ipa_pc_as", 20, ["--reps", "2", "--curve", "1"], "_bls12_381", {"harness": 18, "n2": 18}),  # config 3; CPU at 2^18 (2^20: a minute)
     ("r1cs_nark_as", 18, ["--reps", "3"], "", {"harness": 18, "n2": 18}),                      # config 4
     ("r1cs_nark_as", 18, ["--reps", "3", "--uniform"], "_uniform_witness", {"harness": 18, "n2": 18}),
+    # N > 1 only (`accumulations_multi_device`): config 4 with its 2^18-generator keys REPLICATED on every device instead of sharded --
+    # the round's independent commitments are dealt to the devices whole, no exchange (amsm.h AMSM_BASES_REPLICATE)
+    ("r1cs_nark_as", 18, ["--reps", "3", "--uniform", "--replicate-below", "18"], "_uniform_witness_replicated_keys", None),
+    ("r1cs_nark_as", 18, ["--reps", "3", "--replicate-below", "18"], "_replicated_keys", None),
     ("hp_as", 22, ["--reps", "3"], "", {"harness": 20, "n2": 22}),                             # config 5; CPU harness-zk at 2^20
     ("hp_as", 22, ["--reps", "3", "--constant"], "_harness_constant_inputs", {"harness": 20, "n2": 20}),
 )
@@ -536,6 +540,8 @@ def scheme_rates(devices=None, cpu_leg_max_log2=None):
         for scheme, lg, extra, tag, _cpu in SCHEME_RUNS:
             if multi and ("--device" in extra or "--curve" in extra):
                 continue  # the host backend has no devices to spread over; BASELINE config 3 names ONE GPU
+            if not multi and "--replicate-below" in extra:
+                continue  # (one device: nothing to replicate on)
             for sponge in ("poseidon", "sha256"):
                 if (tag or multi) and sponge == "sha256":
                     continue

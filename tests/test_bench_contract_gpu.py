@@ -128,7 +128,8 @@ def test_eight_rank_branch_on_one_gpu(built_lib, strong):
     if not strong:  # the N-GPU form of the `accumulations` half: the C++ harness over ONE context of eight shards (all on GPU 0 here)
         acc = d["accumulations_multi_device"]
         assert "--devices 0,0,0,0,0,0,0,0" in acc["driver"] and "error" not in acc
-        for key in ("trivial_pc_as_2^10_n2_1in_1acc_nozk", "ipa_pc_as_2^16_harness_1in_2acc_zk", "ipa_pc_as_2^16_n2_1in_1acc_nozk",
+        for key in ("r1cs_nark_as_2^18_n2_1in_1acc_nozk_uniform_witness_replicated_keys", "r1cs_nark_as_2^18_harness_1in_2acc_zk_replicated_keys",
+                    "trivial_pc_as_2^10_n2_1in_1acc_nozk", "ipa_pc_as_2^16_harness_1in_2acc_zk", "ipa_pc_as_2^16_n2_1in_1acc_nozk",
                     "r1cs_nark_as_2^18_harness_1in_2acc_zk", "r1cs_nark_as_2^18_n2_1in_1acc_nozk", "hp_as_2^22_harness_1in_2acc_zk",
                     "hp_as_2^22_n2_1in_1acc_nozk"):
             assert acc[key]["verified"] is True and acc[key]["accumulations_per_s"] > 0, (key, acc[key])
