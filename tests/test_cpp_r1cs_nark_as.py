@@ -15,8 +15,11 @@ EXE = os.path.join(ROOT, "build", "r1cs_nark_as_check")
 def build():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     libdir = os.path.join(ROOT, "accumulation_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE,
+    # (compiled beside the target and moved into place: pytest -n workers build and RUN the same program at the same time)
+    tmp = EXE + f".{os.getpid()}"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", tmp,
                            "-L", libdir, "-l:libamsm.so", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+    os.replace(tmp, EXE)
 
 
 def test_cpp_r1cs_nark_as_compiles(built_lib):
