@@ -196,6 +196,7 @@ struct amsm_ctx {
   unsigned long long n_direct = 0;  // MSMs summed straight from a small key's 512-points-per-generator table (k_direct_sum)
   int direct_max_log2 = 15;         // keys of up to 2^this generators carry that table (AMSM_DIRECT_SUM_MAX_LOG2; 0: none)
   unsigned direct_rr = 0;           // which stream the next direct sum of a batch takes
+  bool host_halves = true;  // AMSM_HOST_HALVES=0: a lone host slice over a 20-bit key as ONE range (upload, then the MSM: rounds 1-5; A/B)
   bool fused_fold = true;  // AMSM_FUSED_FOLD=0: the quad bucket reduction and its fold as two launches (round 5's tail; A/B)
   bool bpl_probe = true;  // sample every candidate vector's digits first and send skewed ones straight to the chunked pipeline
                           // (AMSM_BPL_PROBE=0: find out from the prep's overflow flag only -- the safety net either way)
