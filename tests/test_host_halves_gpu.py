@@ -1,4 +1,4 @@
-"""A LONE host slice of (2^19, 2^20] pairs over a 20-bit key -- the reference's one blocking `commit(&ck, &[Fr], ..)` at a time
+"""A LONE host slice of [3 x 2^18, 2^20] pairs over a 20-bit key -- the reference's one blocking `commit(&ck, &[Fr], ..)` at a time
 (src/hp_as/mod.rs:372-385,911-918) -- runs as two ranges over ONE bucket set so that the second half uploads while the first is
 sorted and accumulated (round 6; api_pipeline.inc: host_halves_apply).  Results against the CPU restatement, for uniform vectors,
 for vectors whose second (or first) half is skewed (the halves' overflow sends the call back to the one-range form), with base
@@ -25,7 +25,7 @@ def env(cref):
     ctx.close()
 
 
-@pytest.mark.parametrize("n,off", [(N, 0), (N, 4096), ((1 << 19) + 129, 7), (700001, 1000), (N - 63, 1)])
+@pytest.mark.parametrize("n,off", [(N, 0), (N, 4096), (3 << 18, 7), (900001, 1000), (N - 63, 1)])
 def test_uniform_slices_take_the_halved_form(env, cref, n, off):
     from accumulation_amd import VariableBaseMSM
     c, ctx, ck, xy = env
@@ -39,10 +39,10 @@ def test_uniform_slices_take_the_halved_form(env, cref, n, off):
     assert after["bucket_per_lane"] - before["bucket_per_lane"] == 2  # two ranges, one reduction
 
 
-def test_at_and_below_2p19_one_range(env, cref):
+def test_below_three_quarters_one_range(env, cref):
     from accumulation_amd import VariableBaseMSM
     c, ctx, ck, xy = env
-    for n in (1 << 19, (1 << 19) + 64):
+    for n in (1 << 19, (3 << 18) - 1):
         sc = cref.rng_frs(c.curve_id, 0x4A3, n)
         before = ctx.pipeline_stats()["shared_bucket_sets"]
         got, ginf = VariableBaseMSM.multi_scalar_mul(ck, sc)
