@@ -275,7 +275,8 @@ int amsm_msm_batch_device(amsm_ctx* ctx, const amsm_bases* bases, size_t base_of
 /* amsm_msm_batch_device over a WHOLE sharded key with the scalars already sharded: d_slices[v * n_dev + g] is the slice of
  * vector v for shard g -- (hi_g - lo_g) scalars resident on device g (allocated / produced through amsm_ctx_shard(ctx, g)).
  * No scalar crosses a device boundary: only the partial sums do (weak scaling: what bench.py --gpus N times in its
- * single-process mode).  A single-device context accepts n_dev = 1. */
+ * single-process mode).  A single-device context accepts n_dev = 1.  A key WITHOUT shards on a multi-device context (a
+ * replicated or folded key: its vectors are whole) has no slices to take: AMSM_E_INVALID_ARG. */
 int amsm_msm_batch_sharded_device(amsm_ctx* ctx, const amsm_bases* bases, const void* const* d_slices, size_t n_vecs,
                                   int scalars_mont, uint64_t* out_xy_mont, uint8_t* out_is_inf);
 

@@ -61,7 +61,7 @@ def test_batches_dealt_over_three_devices(cref, c):
         assert multi._lib.amsm_ctx_collectives(multi._h) == 0  # no exchange of partial records ever happened
         # per-shard slices make no sense for a key without shards: refused, not misread
         import ctypes as C
-        ptrs = (C.c_void_p * 6)(*([dv_r[0].ptr] * 6))
+        ptrs = (C.c_void_p * 6)(*([dv_r[0].ptr.value] * 6))
         out6, inf6 = np.zeros((2, 2 * multi.fq_limbs), dtype=np.uint64), np.zeros((2,), dtype=np.uint8)
         assert lib.amsm_msm_batch_sharded_device(multi._h, ckr._h, ptrs, 2, 1, out6.ctypes.data_as(C.c_void_p),
                                                  inf6.ctypes.data_as(C.c_void_p)) == ffi.AMSM_E_INVALID_ARG
