@@ -42,6 +42,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (the pool's host driver supports dmabuf IPC only: RCCL's multi-process rendezvous needs this before the HIP runtime starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PREHEAT_MSMS = 40  # untimed MSMs before the warm-up steps: the device reaches its steady clocks (see main())
