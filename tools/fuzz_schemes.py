@@ -5,7 +5,9 @@ step); every combined instance, witness vector, proof commitment and decide() mu
 ipa_pc_as chains (random degree 2^k - 1, 2-4 inputs then 0-2 more plus the first accumulator, zk on or off: the first prove's
 combine step against the oracle, the second verified and decided) and trivial_pc_as chains (random degree, random template shape:
 every step verified, the last accumulator decided, and its commitment recomputed by the oracle's naive MSM over the key).
-Usage: python tools/fuzz_schemes.py [seconds] [seed] [--host]   (--host: the library's host backend, no GPU needed)"""
+Usage: python tools/fuzz_schemes.py [seconds] [seed] [--host] [--bls12-381]   (--host: the library's host backend, no GPU needed;
+--bls12-381: every layer over BLS12-381 G1 / its scalar field instead of Pallas -- the reference's own tests run the layers on Pallas
+only, BASELINE config 3 runs ipa_pc_as on BLS12-381)"""
 import os
 import sys
 import time
@@ -25,12 +27,14 @@ from tests.test_hp_as_scheme_gpu import SchemeRng  # noqa: E402
 from tests.test_r1cs_nark_gpu import dummy_circuit  # noqa: E402
 
 HOST = "--host" in sys.argv
-argv = [a for a in sys.argv if a != "--host"]
+BLS = "--bls12-381" in sys.argv
+argv = [a for a in sys.argv if a not in ("--host", "--bls12-381")]
 budget = float(argv[1]) if len(argv) > 1 else 60.0
 seed = int(argv[2]) if len(argv) > 2 else 1
 rs = np.random.RandomState(seed)
-C = o.PALLAS
-ctx = Context(ffi.AMSM_PALLAS, device=ffi.AMSM_DEVICE_HOST if HOST else 0)
+C = o.BLS12_381_G1 if BLS else o.PALLAS
+T.C = C  # (the layer helpers read their module's curve when they run)
+ctx = Context(C.curve_id, device=ffi.AMSM_DEVICE_HOST if HOST else 0)
 t_end = time.time() + budget
 n_cases = n_chains = n_steps = n_ipa = n_trivial = 0
 
@@ -132,4 +136,4 @@ while time.time() < t_end:
         n_cases += 1
     ck.free()
 print(f"fuzz_schemes ok: {n_cases} hp_as proves, {n_chains} r1cs_nark_as chains ({n_steps} accumulation steps), {n_ipa} ipa_pc_as chains and "
-      f"{n_trivial} trivial_pc_as chains against the oracle in {budget:.0f} s (seed {seed}{', host backend' if HOST else ''})")
+      f"{n_trivial} trivial_pc_as chains against the oracle on {C.name} in {budget:.0f} s (seed {seed}{', host backend' if HOST else ''})")
