@@ -86,7 +86,24 @@ class Sha256 {
 //   std::vector<Fr> squeeze_field_elements(size_t count, unsigned n_bits)    the same for `[Truncated(n_bits); count]`: ONE
 //                                                    squeeze (a Poseidon sponge cuts the windows out of one bit stream)
 //   S fork(const char* domain)
+//   void for_curve(int curve)                        OPTIONAL: a sponge whose field is the curve's base field (the reference's
+//                                                    `PoseidonSponge<ConstraintF<G>>`) re-creates itself for the context's curve; the
+//                                                    drivers call it on every sponge they are handed (a default-constructed
+//                                                    argument knows no context) or create, before the first absorb
 // Sha256Sponge: same construction as accumulation_amd/sponge.py:Sha256Sponge (byte-identical challenges).
+template <class S>
+auto sponge_for_curve(S& s, int curve, int) -> decltype(s.for_curve(curve), void()) {
+  s.for_curve(curve);
+}
+template <class S>
+void sponge_for_curve(S&, int, long) {}
+template <class S>
+S fresh_sponge(int curve) {
+  S s;
+  sponge_for_curve(s, curve, 0);
+  return s;
+}
+
 class Sha256Sponge {
  public:
   Sha256Sponge() {
@@ -321,6 +338,7 @@ class ASForHadamardProducts {
                                              Sponge sponge = Sponge()) {
     Context& ctx = pk.ctx();
     FrOps fr{amsm_ctx_curve(ctx.get())};
+    sponge_for_curve(sponge, amsm_ctx_curve(ctx.get()), 0);
     const bool make_zk = (bool)rng;
     size_t num_all = inputs.size() + old_accumulators.size();
     if (!make_zk)  // :664-673
@@ -421,6 +439,7 @@ class ASForHadamardProducts {
                      const std::vector<InputInstance>& old_accumulator_instances, const InputInstance& new_accumulator_instance,
                      const Proof& proof, Sponge sponge = Sponge()) {
     FrOps fr{amsm_ctx_curve(ctx.get())};
+    sponge_for_curve(sponge, amsm_ctx_curve(ctx.get()), 0);
     size_t num_all = input_instances.size() + old_accumulator_instances.size();
     const bool make_zk = proof.hiding_comms.has_value();
     if (num_all == 0) {

@@ -123,7 +123,7 @@ struct InnerProductArgPC {
   struct Challenge {
     const FrX& fr;
     Sponge sp;
-    explicit Challenge(const FrX& f) : fr(f), sp(Sponge().fork("IPA-PC")) {}
+    explicit Challenge(const FrX& f) : fr(f), sp(hp_as::fresh_sponge<Sponge>(f.curve).fork("IPA-PC")) {}
     Challenge& point(const Affine& p) {
       sp.absorb_point(p);
       return *this;
@@ -576,7 +576,7 @@ class AtomicASForInnerProductArgPC {
     std::vector<Check> checks;
     succinct_checks(ctx, pk.verifier_key.ipa_svk, ins, olds, checks);
     mark("succinct checks");
-    Sponge as_sponge = Sponge().fork("AS-FOR-IPA-PC-2020");
+    Sponge as_sponge = hp_as::fresh_sponge<Sponge>(amsm_ctx_curve(ctx.get())).fork("AS-FOR-IPA-PC-2020");
     Combined comb = combine(ctx, fr, pk.verifier_key.ipa_svk, checks, proof, as_sponge);
     mark("combine");
     // combined check polynomial on the device: sum_i alpha_i * h_i (+ random linear polynomial)  :391-404
@@ -640,7 +640,7 @@ class AtomicASForInnerProductArgPC {
       Affine lc = deterministic_commit(vk.ipa_ck_linear, proof->random_linear_polynomial);
       if (!(lc == proof->random_linear_polynomial_commitment)) return false;
     }
-    Sponge as_sponge = Sponge().fork("AS-FOR-IPA-PC-2020");
+    Sponge as_sponge = hp_as::fresh_sponge<Sponge>(amsm_ctx_curve(ctx.get())).fork("AS-FOR-IPA-PC-2020");
     Combined comb = combine(ctx, fr, vk.ipa_svk, checks, proof, as_sponge);
     if (!(comb.randomized.comm == new_acc.ipa_commitment.comm)) return false;
     Fr challenge_canon = new_challenge(fr, as_sponge, comb.combined, comb.alphas_canon, checks,

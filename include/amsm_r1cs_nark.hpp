@@ -233,6 +233,7 @@ struct R1CSNark {
     const CommitterKey& ck = *ipk.ck;
     Context& ctx = ck.ctx();
     FrOps fr{amsm_ctx_curve(ctx.get())};
+    hp_as::sponge_for_curve(sponge, amsm_ctx_curve(ctx.get()), 0);
     const bool make_zk = (bool)rng;
     std::vector<Fr> in_m;
     for (auto& x : input) in_m.push_back(fr.to_mont(x));
@@ -279,6 +280,7 @@ struct R1CSNark {
     const CommitterKey& ck = *ivk.ck;
     Context& ctx = ck.ctx();
     FrOps fr{amsm_ctx_curve(ctx.get())};
+    hp_as::sponge_for_curve(sponge, amsm_ctx_curve(ctx.get()), 0);
     const FirstRoundMessage& first = proof.first_msg;
     const SecondRoundMessage& second = proof.second_msg;
     if (first.randomness.has_value() != second.randomness.has_value()) return false;

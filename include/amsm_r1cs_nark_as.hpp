@@ -132,6 +132,7 @@ class ASForR1CSNark {
     const CommitterKey& ck = *ipk.ck;
     Context& ctx = ck.ctx();
     FrOps fr{amsm_ctx_curve(ctx.get())};
+    hp_as::sponge_for_curve(sponge, amsm_ctx_curve(ctx.get()), 0);
     Sponges sp = sponges(sponge);
     const auto& info = ipk.index_info;
     const size_t in_len = info.num_instance_variables, wit_len = info.num_variables - in_len;
@@ -230,6 +231,7 @@ class ASForR1CSNark {
   static bool verify(Context& ctx, const VerifierKey& vk, std::vector<InputInstance> ins, const std::vector<AccumulatorInstance>& olds,
                      const AccumulatorInstance& new_acc, const Proof& proof, Sponge sponge = Sponge()) {
     FrOps fr{amsm_ctx_curve(ctx.get())};
+    hp_as::sponge_for_curve(sponge, amsm_ctx_curve(ctx.get()), 0);
     Sponges sp = sponges(sponge);
     const bool make_zk = proof.randomness.has_value();
     const size_t in_len = vk.num_instance_variables;

@@ -134,6 +134,7 @@ class ASForTrivialPC {
                                              Sponge sponge = Sponge()) {
     Context& ctx = pk.ctx();
     FrOps fr{amsm_ctx_curve(ctx.get())};
+    hp_as::sponge_for_curve(sponge, amsm_ctx_curve(ctx.get()), 0);
     if (inputs.empty() && accs.empty())  // default input :349-364
       inputs.push_back(Input{InputInstance::zero(ctx), LabeledPolynomial{{fr.zero()}, {}, {}}});
     std::vector<const InputInstance*> instances;
@@ -180,6 +181,7 @@ class ASForTrivialPC {
                      const std::vector<InputInstance>& old_accumulator_instances, const InputInstance& new_acc, const Proof& proof,
                      Sponge sponge = Sponge()) {
     FrOps fr{amsm_ctx_curve(ctx.get())};
+    hp_as::sponge_for_curve(sponge, amsm_ctx_curve(ctx.get()), 0);
     std::vector<const InputInstance*> instances;
     InputInstance dflt = InputInstance::zero(ctx);
     try {

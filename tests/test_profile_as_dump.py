@@ -55,10 +55,10 @@ def first_difference(a, b):
     return None if d.size == 0 else f"{d.size} bytes differ, the first at offset {int(d[0])} of {len(a)}"
 
 
-def compare(tmp_path, scheme, lg, shape, sponge, device, seed=0):
-    from accumulation_amd import Context, ffi
-    (acc_cpp, proof_cpp), _ = cpp_dump(tmp_path, scheme, lg, shape, sponge, device, seed)
-    ctx = Context(ffi.AMSM_PALLAS, device=device)
+def compare(tmp_path, scheme, lg, shape, sponge, device, seed=0, curve=0):
+    from accumulation_amd import Context
+    (acc_cpp, proof_cpp), _ = cpp_dump(tmp_path, scheme, lg, shape, sponge, device, seed, extra=("--curve", str(curve)) if curve else ())
+    ctx = Context(curve, device=device)
     try:
         acc_py, proof_py = harness_mirror.SCHEMES[scheme](ctx, lg, shape == "harness", sponge, seed)
     finally:
@@ -74,6 +74,14 @@ def compare(tmp_path, scheme, lg, shape, sponge, device, seed=0):
 @pytest.mark.parametrize("scheme,lg", [("hp_as", 7), ("r1cs_nark_as", 6), ("ipa_pc_as", 5), ("trivial_pc_as", 6)])
 def test_cpp_driver_bytes_equal_the_mirror_on_the_host_backend(built_lib, tmp_path, scheme, lg, shape, sponge):
     compare(tmp_path, scheme, lg, shape, sponge, -1, seed=3)
+
+
+@pytest.mark.parametrize("shape", ["n2", "harness"])
+@pytest.mark.parametrize("scheme,lg", [("hp_as", 6), ("r1cs_nark_as", 5), ("ipa_pc_as", 4), ("trivial_pc_as", 5)])
+def test_cpp_driver_bytes_equal_the_mirror_over_bls12_381(built_lib, tmp_path, scheme, lg, shape):
+    """the drivers are not tied to Pallas (BASELINE config 3 runs ipa_pc_as on BLS12-381): 48-byte points, the 381-bit sponge field"""
+    from accumulation_amd import ffi
+    compare(tmp_path, scheme, lg, shape, "poseidon", -1, seed=4, curve=ffi.AMSM_BLS12_381_G1)
 
 
 def test_ser_mirror_against_the_big_int_wire_format_oracle(built_lib):
@@ -108,6 +116,14 @@ def test_ser_mirror_against_the_big_int_wire_format_oracle(built_lib):
     s = Ser(ctx)
     assert s.hp_accumulator(acc) == want_acc and s.hp_proof(proof) == want_proof
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_cpp_driver_bytes_equal_the_mirror_over_bls12_381_on_the_gpu(built_lib, tmp_path):
+    """ipa_pc_as at d + 1 = 2^16 over BLS12-381 with the reference's sponge over ITS base field (BASELINE config 3's curve; the 2^20
+    opening itself is oracle-checked through the mirror in tests/test_ipa_open_vs_oracle_gpu.py)"""
+    from accumulation_amd import ffi
+    compare(tmp_path, "ipa_pc_as", 16, "harness", "poseidon", 0, curve=ffi.AMSM_BLS12_381_G1)
 
 
 # ---- GPU: the sizes of BASELINE.json's configs, the reference's sponge -------------------------------------------------------------

@@ -241,7 +241,7 @@ static void profile_nark_as(const Opt& o, int lg, bool harness_shape) {
     } else {
       wit = std::make_shared<FrVector>(ctx, std::vector<Fr>{am, bm});
     }
-    auto sp = AS::sponges(Sponge());
+    auto sp = AS::sponges(hp_as::fresh_sponge<Sponge>(o.curve));  // (a sponge over THIS curve's base field before it is forked)
     r1cs_nark::Proof proof = Nark::prove(ipk, inst, wit, zk_rng, sp.nark);
     return r1cs_nark_as::Input{r1cs_nark_as::InputInstance{inst, proof.first_msg}, proof.second_msg};
   };
