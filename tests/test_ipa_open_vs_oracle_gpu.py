@@ -122,6 +122,16 @@ def test_bls12_381_2p20_opening(hiding, fold_above, log_n):
     assert stats["fallbacks"] == 0
 
 
+@pytest.mark.parametrize("hiding", [False, True], ids=["no_zk", "zk"])
+def test_bls12_381_2p16_opening_with_the_jump_fold(hiding):
+    """BLS12-381 at d + 1 = 2^16 with the key never folded physically: ten rounds of grouped MSMs over the 16-bit table, the jump fold
+    to 64 generators (round 6: amsm_ipa_jump_fold over the 384-bit field) and six rounds on the host -- the one schedule of this
+    curve that takes the jump (the default folds once, and a folded key is plain)"""
+    got, ref, accepted, ref_ok, stats = _open_both_ways(o.BLS12_381_G1, 16, hiding, 99)
+    _assert_equal(got, ref, accepted, ref_ok)
+    assert stats["fallbacks"] == 0
+
+
 def test_pallas_2p20_opening_grouped_msms_stay_on_the_bucket_per_lane_pipeline():
     """never fold: twenty rounds, each ONE grouped MSM of 2^20 pairs over the 20-bit key (two bucket sets on the
     bucket-per-lane pipeline -- round 3 sent these to the 17-bit twin and the chunked pipeline)"""
