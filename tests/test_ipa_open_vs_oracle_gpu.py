@@ -22,7 +22,7 @@ from tests.test_r1cs_nark_gpu import RecordingRng
 pytestmark = pytest.mark.gpu
 
 
-def _open_both_ways(curve, log_n, hiding, fold_above, oracle_threads=None):
+def _open_both_ways(curve, log_n, hiding, fold_above, oracle_threads=None, probe_jump=False):
     from accumulation_amd import Context
     from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
     from accumulation_amd.scalar_field import Fr
@@ -74,6 +74,9 @@ def _open_both_ways(curve, log_n, hiding, fold_above, oracle_threads=None):
         got = {"l_vec": [pt(p) for p in proof.l_vec], "r_vec": [pt(p) for p in proof.r_vec], "final_comm_key": pt(proof.final_comm_key),
                "c": proof.c % c.r, "hiding_comm": None if proof.hiding_comm is None else pt(proof.hiding_comm),
                "rand": None if proof.rand is None else proof.rand % c.r}
+        if probe_jump:  # does this key qualify for the jump fold (then the opening above took it: ipa_pc.py open)?
+            from tests.test_ipa_jump_gpu import _jump
+            stats["jump_rc"] = _jump(ctx, ck.comm_key, log_n, [3 + 2 * r for r in range(log_n - 6)], fr)[0]
         return got, ref, accepted, ref_ok, stats
     finally:
         ctx.close()
@@ -127,9 +130,9 @@ def test_bls12_381_2p16_opening_with_the_jump_fold(hiding):
     """BLS12-381 at d + 1 = 2^16 with the key never folded physically: ten rounds of grouped MSMs over the 16-bit table, the jump fold
     to 64 generators (round 6: amsm_ipa_jump_fold over the 384-bit field) and six rounds on the host -- the one schedule of this
     curve that takes the jump (the default folds once, and a folded key is plain)"""
-    got, ref, accepted, ref_ok, stats = _open_both_ways(o.BLS12_381_G1, 16, hiding, 99)
+    got, ref, accepted, ref_ok, stats = _open_both_ways(o.BLS12_381_G1, 16, hiding, 99, probe_jump=True)
     _assert_equal(got, ref, accepted, ref_ok)
-    assert stats["fallbacks"] == 0
+    assert stats["fallbacks"] == 0 and stats["jump_rc"] == 0
 
 
 def test_pallas_2p20_opening_grouped_msms_stay_on_the_bucket_per_lane_pipeline():
