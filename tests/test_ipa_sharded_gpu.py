@@ -17,8 +17,12 @@ def same_pt(a, b):
 @pytest.mark.parametrize("devices", [(0, 0), (0, 0, 0), (0,) * 8], ids=["2_shards", "3_shards", "8_shards"])
 @pytest.mark.parametrize("log_n", [6, 10, 16])
 def test_grouped_msm_over_a_sharded_key(devices, log_n):
+    _grouped(devices, log_n, ffi.AMSM_PALLAS)
+
+
+def _grouped(devices, log_n, curve):
     from accumulation_amd import CommitterKey
-    one, multi = Context(ffi.AMSM_PALLAS), MultiContext(ffi.AMSM_PALLAS, devices)
+    one, multi = Context(curve), MultiContext(curve, devices)
     try:
         n = (1 << log_n) + (5 if log_n == 10 else 0)
         k1, kN = CommitterKey.generate(one, 0x1DA1, n), CommitterKey.generate(multi, 0x1DA1, n)
@@ -41,11 +45,24 @@ def test_grouped_msm_over_a_sharded_key(devices, log_n):
 @pytest.mark.parametrize("devices,degree", [((0, 0), 63), ((0, 0, 0), 1023), ((0,) * 8, (1 << 16) - 1)], ids=["2x64", "3x1024", "8x65536"])
 def test_ipa_open_and_accumulate_over_a_sharded_key(devices, degree, make_zk):
     """the whole opening (every L_j, R_j, the final key, c, the hiding terms) and one ipa_pc_as accumulation"""
+    _open_and_accumulate(devices, degree, make_zk, ffi.AMSM_PALLAS)
+
+
+@pytest.mark.parametrize("make_zk", [False, True], ids=["no_zk", "zk"])
+def test_sharded_key_over_bls12_381(make_zk):
+    """the same over BLS12-381 (192-byte partial records, the 384-bit field's kernels; BASELINE config 3's curve): grouped MSMs over three
+    shards and a whole 2^10 opening + accumulation"""
+    if not make_zk:
+        _grouped((0, 0, 0), 10, ffi.AMSM_BLS12_381_G1)
+    _open_and_accumulate((0, 0, 0), 1023, make_zk, ffi.AMSM_BLS12_381_G1)
+
+
+def _open_and_accumulate(devices, degree, make_zk, curve):
     from accumulation_amd.ipa_pc import InnerProductArgPC as IpaPC
     from accumulation_amd.ipa_pc_as import AtomicASForInnerProductArgPC as AS, InputInstance
     from accumulation_amd.scalar_field import Fr
     out = []
-    for ctx in (Context(ffi.AMSM_PALLAS), MultiContext(ffi.AMSM_PALLAS, devices)):
+    for ctx in (Context(curve), MultiContext(curve, devices)):
         try:
             fr = Fr(ctx.curve)
             pp = IpaPC.setup(ctx, degree, seed=0xABCDEF)

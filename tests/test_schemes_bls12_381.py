@@ -21,7 +21,7 @@ def _run(seconds, seed, *flags):
 
 @pytest.mark.gpu
 def test_layers_over_bls12_381_on_the_gpu(built_lib):
-    _run(10, 31)
+    _run(6, 31)
 
 
 def test_layers_over_bls12_381_on_the_host_backend(built_lib):
