@@ -102,17 +102,17 @@ def test_sharded_msm_world2_gloo(n, cref):
 
 
 # ---- the PRODUCT engine on the library's host backend (round 5): the same two-rank exchange, no stand-in ----------------------------
-def _worker_host_backend(rank, world, init_file, n, q):
+def _worker_host_backend(rank, world, init_file, n, q, curve="pallas"):
     from accumulation_amd import CommitterKey, Context, ffi
     from accumulation_amd.dist import HipEngine
     from oracle import cref
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     try:
-        c = o.PALLAS
+        c = o.CURVES[curve]
         xy = cref.rng_points(c.curve_id, 0x5EED1001, n)
         sc, sc2 = cref.rng_scalars(0x5EED0001, n), cref.rng_scalars(0x5EED0002, n)
         lo, hi = shard_bounds(n, rank, world)
-        ctx = Context(ffi.AMSM_PALLAS, device=ffi.AMSM_DEVICE_HOST)
+        ctx = Context(c.curve_id, device=ffi.AMSM_DEVICE_HOST)
         ck = CommitterKey.load(ctx, xy[lo:hi], None, ffi.AMSM_BASES_DEFAULT)
         sm = ShardedMSM(HipEngine(ctx, ck))
         a, b = ctx.upload(sc[lo:hi]), ctx.upload(sc2[lo:hi])
@@ -125,8 +125,8 @@ def _worker_host_backend(rank, world, init_file, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [2, 5000])
-def test_sharded_msm_world2_gloo_on_the_host_backend(n, cref, built_lib):
+@pytest.mark.parametrize("n,curve", [(2, "pallas"), (5000, "pallas"), (1500, "bls12_381_g1")])
+def test_sharded_msm_world2_gloo_on_the_host_backend(n, curve, cref, built_lib):
     """accumulation_amd.dist.HipEngine over a host-backend context (libamsm.so itself: amsm_msm_partial[_batch]_device,
     amsm_partials_combine[_batch]) on two gloo ranks without a GPU -- the N > 1 torchrun form of the product, not of a stand-in"""
     world = 2
@@ -134,14 +134,14 @@ def test_sharded_msm_world2_gloo_on_the_host_backend(n, cref, built_lib):
     q = ctx.Queue()
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "init")
-        procs = [ctx.Process(target=_worker_host_backend, args=(r, world, init_file, n, q)) for r in range(world)]
+        procs = [ctx.Process(target=_worker_host_backend, args=(r, world, init_file, n, q, curve)) for r in range(world)]
         for p in procs:
             p.start()
         res = [q.get(timeout=300) for _ in range(world)]
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
-    c = o.PALLAS
+    c = o.CURVES[curve]  # (BLS12-381: 192-byte partial records through the same all-gather)
     pts = cref.rng_points(c.curve_id, 0x5EED1001, n)
     ref, rinf = cref.msm(c.curve_id, pts, cref.rng_scalars(0x5EED0001, n))
     ref2, rinf2 = cref.msm(c.curve_id, pts, cref.rng_scalars(0x5EED0002, n))
@@ -151,15 +151,15 @@ def test_sharded_msm_world2_gloo_on_the_host_backend(n, cref, built_lib):
 
 
 # ---- REPLICATED keys, the one-process-per-GPU form (round 6): whole MSMs dealt to the ranks, one all-gather of affine results --------
-def _worker_replicated(rank, world, init_file, n, q):
+def _worker_replicated(rank, world, init_file, n, q, curve="pallas"):
     from accumulation_amd import CommitterKey, Context, ffi
     from accumulation_amd.dist import ReplicatedMSM
     from oracle import cref
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     try:
-        c = o.PALLAS
+        c = o.CURVES[curve]
         xy = cref.rng_points(c.curve_id, 0x5EED1001, n)
-        ctx = Context(ffi.AMSM_PALLAS, device=ffi.AMSM_DEVICE_HOST)
+        ctx = Context(c.curve_id, device=ffi.AMSM_DEVICE_HOST)
         ck = CommitterKey.load(ctx, xy, None, ffi.AMSM_BASES_DEFAULT)  # the WHOLE key on every rank
         vecs = [ctx.upload(cref.rng_frs(c.curve_id, 0x5EED0100 + j, n)) for j in range(5)]
         outs, infs = ReplicatedMSM(ck).msm_batch(vecs, mont=False)
@@ -171,8 +171,8 @@ def _worker_replicated(rank, world, init_file, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_replicated_msm_over_gloo_on_the_host_backend(world, cref, built_lib):
+@pytest.mark.parametrize("world,curve", [(2, "pallas"), (3, "pallas"), (2, "bls12_381_g1")])
+def test_replicated_msm_over_gloo_on_the_host_backend(world, curve, cref, built_lib):
     """five MSMs over a replicated key on two / three gloo ranks of the library's host backend: rank r computes MSMs r, r + world,
     .. whole, one all-gather of the affine results, every rank ends with all five in call order -- equal to the CPU restatement"""
     n = 3000
@@ -180,14 +180,14 @@ def test_replicated_msm_over_gloo_on_the_host_backend(world, cref, built_lib):
     q = ctx.Queue()
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "init")
-        procs = [ctx.Process(target=_worker_replicated, args=(r, world, init_file, n, q)) for r in range(world)]
+        procs = [ctx.Process(target=_worker_replicated, args=(r, world, init_file, n, q, curve)) for r in range(world)]
         for p in procs:
             p.start()
         res = [q.get(timeout=300) for _ in range(world)]
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
-    c = o.PALLAS
+    c = o.CURVES[curve]
     pts = cref.rng_points(c.curve_id, 0x5EED1001, n)
     refs = [cref.msm(c.curve_id, pts, cref.rng_frs(c.curve_id, 0x5EED0100 + j, n)) for j in range(5)]
     for rank, outs, infs, n_none in res:
