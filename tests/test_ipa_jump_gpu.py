@@ -87,6 +87,15 @@ def test_keys_that_do_not_qualify_are_refused_not_miscomputed():
         assert _jump(ctx, pre, 8, [3, 5, 7], fr)[0] == ffi.AMSM_E_UNSUPPORTED         # m0 = 32: not a multiple of 64
         assert _jump(ctx, pre, 8, [3, 0], fr)[0] == ffi.AMSM_E_INVALID_ARG            # a zero challenge
         assert _jump(ctx, pre, 8, [3, 5], fr)[0] == ffi.AMSM_OK
+        # edges of j: no challenge at all (the key itself, or a refusal -- never something else), more challenges than the key has bits
+        rc, xy, inf = _jump(ctx, pre, 8, [], fr)
+        assert rc in (ffi.AMSM_OK, ffi.AMSM_E_UNSUPPORTED, ffi.AMSM_E_INVALID_ARG)
+        if rc == ffi.AMSM_OK:
+            kxy, kinf = pre.read()
+            assert np.array_equal(xy, kxy) and np.array_equal(inf, kinf)
+        from accumulation_amd.engine import _ptr
+        assert ctx._lib.amsm_ipa_jump_fold(ctx._h, pre._h, 8, _ptr(fr.to_limbs_many([3] * 9)), 9, _ptr(xy), _ptr(inf)) == ffi.AMSM_E_INVALID_ARG
+        assert _jump(ctx, pre, 9, [3], fr)[0] == ffi.AMSM_E_INVALID_ARG  # log_key beyond the key
         plain.free()
         pre.free()
     finally:
