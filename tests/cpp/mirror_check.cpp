@@ -26,6 +26,15 @@ int main() {
     // canonical host scalars through the BigInt entry point
     FrVector a_canon = FrVector::random(ctx, 11, n, false);
     print_point("msm_a_bigint", VariableBaseMSM::multi_scalar_mul(ck, a_canon.to_host()));
+    // the ark-ec call shape itself (amsm_msm_oneshot): bases AND scalars are host slices of this call; an identity base by flag
+    {
+      std::vector<uint64_t> gens = ck.read(0, n);
+      print_point("oneshot_a", VariableBaseMSM::multi_scalar_mul(ctx, gens.data(), nullptr, n, a_canon.to_host()));
+      std::vector<uint8_t> inf(n, 0);
+      inf[7] = 1;
+      print_point("oneshot_a_without_7", VariableBaseMSM::multi_scalar_mul(ctx, gens.data(), inf.data(), n, a_canon.to_host()));
+      print_point("oneshot_a_first_300", VariableBaseMSM::multi_scalar_mul(ctx, gens.data(), nullptr, 300, a_canon.to_host()));
+    }
     // a + 3 b  (combine_vectors), a o b (compute_hp)
     Fr one = {0x5b2b3e9cfffffffdull, 0x992c350be3420567ull, 0xffffffffffffffffull, 0x3fffffffffffffffull};  // R mod r
     Fr three;

@@ -56,6 +56,8 @@ def _mirror_matches_oracle(cref, device):
     ai, bi, a2i, b2i = (h.np_to_ints(v) for v in (a, b, a2, b2))
     Pa, Pb = msm(ai), msm(bi)
     assert pt("commit_a") == Pa and pt("msm_a_bigint") == Pa and pt("commit_b") == Pb
+    assert pt("oneshot_a") == Pa and pt("oneshot_a_without_7") == msm([0 if i == 7 else v for i, v in enumerate(ai)])
+    assert pt("oneshot_a_first_300") == msm(ai[:300] + [0] * (n - 300))  # min(bases.len(), scalars.len()) pairs
     assert pt("commit_a_plus_3b") == o.add(c, Pa, o.mul(c, 3, Pb))
     assert pt("commit_a_had_b") == msm(o.compute_hp(c, ai, bi))
     assert pt("commit_a_hiding_3") == o.add(c, Pa, o.mul(c, 3, H))
