@@ -43,7 +43,7 @@ struct SchemeRng {  // tests/test_hp_as_scheme_gpu.py:SchemeRng
 };
 
 static std::vector<InputInstance> generate_inputs(Context& ctx, const ProverKey& pk, size_t num, bool make_zk, SchemeRng& rng) {
-  ipa_pc::FrX fr(AMSM_PALLAS);
+  ipa_pc::FrX fr(amsm_ctx_curve(ctx.get()));
   hp_as::Rng prng([&rng]() { return rng.field(); });
   std::vector<InputInstance> out;
   for (size_t t = 0; t < num; t++) {
@@ -99,7 +99,7 @@ static void print_fr(const char* name, const Fr& canonical) {
 int main() {
   try {
     Context ctx = check_context(AMSM_PALLAS);
-    ipa_pc::FrX fr(AMSM_PALLAS);
+    ipa_pc::FrX fr(amsm_ctx_curve(ctx.get()));
     ipa_pc::CommitterKey pp = Ipa::setup(ctx, DEGREE, 0xABCDEF);
     // the polynomial commitment alone: open / check round trip and its two rejections (tests/test_ipa_gpu.py)
     for (int zk = 0; zk < 2; zk++) {

@@ -43,18 +43,18 @@ struct SchemeRng {  // tests/test_hp_as_scheme_gpu.py:SchemeRng
 };
 
 static std::vector<Input> generate_inputs(Context& ctx, const r1cs_nark::IndexProverKey& ipk, size_t num, bool make_zk, SchemeRng& rng) {
-  hp_as::FrOps fr{AMSM_PALLAS};
+  hp_as::FrOps fr{amsm_ctx_curve(ctx.get())};
   const Fr one = {1, 0, 0, 0};
   hp_as::Rng prng = make_zk ? hp_as::Rng([&rng]() { return rng.field(); }) : hp_as::Rng();
   std::vector<Input> out;
   for (size_t t = 0; t < num; t++) {
     Fr a = rng.field(), b = rng.field();
     Fr am = fr.to_mont(a), bm = fr.to_mont(b), abm = fr.mul(am, bm), ab;
-    check(amsm_fr_from_mont(AMSM_PALLAS, abm.data(), 1, ab.data()), "from_mont");
+    check(amsm_fr_from_mont(amsm_ctx_curve(ctx.get()), abm.data(), 1, ab.data()), "from_mont");
     std::vector<Fr> inst{one, ab};
     for (size_t k = 1; k < NUM_INPUTS; k++) inst.push_back(a);
     auto wit = std::make_shared<FrVector>(ctx, std::vector<Fr>{am, bm});
-    auto sp = AS::sponges(TestSponge());
+    auto sp = AS::sponges(hp_as::fresh_sponge<TestSponge>(amsm_ctx_curve(ctx.get())));
     r1cs_nark::Proof proof = Nark::prove(ipk, inst, wit, prng, sp.nark);
     out.push_back(Input{InputInstance{inst, proof.first_msg}, proof.second_msg});
   }

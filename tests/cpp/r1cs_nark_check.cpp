@@ -52,7 +52,7 @@ static void print_fr(const char* name, const Fr& x) {
 int main() {
   try {
     Context ctx = check_context(AMSM_PALLAS);
-    hp_as::FrOps fr{AMSM_PALLAS};
+    hp_as::FrOps fr{amsm_ctx_curve(ctx.get())};
     const size_t num_inputs = 5, num_constraints = 100, n_inst = num_inputs + 1;
     const Fr one = {1, 0, 0, 0};
     // DummyCircuit: instance = [1, a*b, a, ..., a], witness = [a, b]; num_constraints - 1 copies of a * b = c, one empty
@@ -76,7 +76,7 @@ int main() {
       for (int round = 0; round < 3; round++) {
         Fr a = rng.field(), b = rng.field();  // canonical (< 2^254 < r)
         Fr am = fr.to_mont(a), bm = fr.to_mont(b), abm = fr.mul(am, bm), ab;
-        check(amsm_fr_from_mont(AMSM_PALLAS, abm.data(), 1, ab.data()), "from_mont");
+        check(amsm_fr_from_mont(amsm_ctx_curve(ctx.get()), abm.data(), 1, ab.data()), "from_mont");
         std::vector<Fr> inst{one, ab};
         for (size_t k = 1; k < num_inputs; k++) inst.push_back(a);
         auto wit = std::make_shared<FrVector>(ctx, std::vector<Fr>{am, bm});
