@@ -61,3 +61,11 @@ def test_six_scenarios_with_poseidon_over_bls12_381_on_the_host_backend(built_li
     pallas = _six_scenarios(name, -1)
     bls = _six_scenarios(name, -1, curve=1)
     assert bls != pallas  # (it really ran another curve: the printed accumulators differ)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ipa_pc_as", "r1cs_nark_as"])
+def test_six_scenarios_with_poseidon_over_bls12_381(built_lib, name):
+    """... and on the GPU: the same lines as the host backend prints, accumulators included (device kernels of the 384-bit field
+    under the drivers: direct sums, SpMV, vector kernels, the fused IPA rounds)"""
+    assert _six_scenarios(name, 0, curve=1) == _six_scenarios(name, -1, curve=1)
