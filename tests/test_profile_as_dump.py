@@ -186,6 +186,12 @@ def test_cpp_driver_over_replicated_keys_same_bytes(built_lib, tmp_path):
             one, _ = cpp_dump(tmp_path, scheme, lg, shape, "poseidon", 0, extra=extra)
             many, _ = cpp_dump(tmp_path, scheme, lg, shape, "poseidon", 0, extra=extra + dev8)
             assert one == many, (scheme, shape, extra)
+    # ipa_pc_as at 2^14 / 2^16: the opening's rounds (grouped MSMs, the jump fold where the key qualifies) run over the PRIMARY's copy of a
+    # replicated key
+    for lg in (14, 16):
+        one, _ = cpp_dump(tmp_path, "ipa_pc_as", lg, "harness", "poseidon", 0)
+        many, _ = cpp_dump(tmp_path, "ipa_pc_as", lg, "harness", "poseidon", 0, extra=("--devices", "0,0,0", "--replicate-below", "18"))
+        assert one == many, ("ipa_pc_as", lg)
 
 
 # ---- the jump fold of the IPA opening (round 6): the last rounds on the host over amsm_ipa_jump_fold's generators -----------------------
