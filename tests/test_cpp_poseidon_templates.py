@@ -58,9 +58,9 @@ def test_six_scenarios_with_poseidon_on_the_host_backend(built_lib, name):
 def test_six_scenarios_with_poseidon_over_bls12_381_on_the_host_backend(built_lib, name):
     """the same programs over BLS12-381 G1 (AMSM_CHECK_CURVE=1; tests/cpp/check_device.hpp): the reference instantiates its template
     over Pallas only, the drivers are generic -- every scenario must prove, verify and decide with the sponge over the 381-bit field"""
-    pallas = _six_scenarios(name, -1)
     bls = _six_scenarios(name, -1, curve=1)
-    assert bls != pallas  # (it really ran another curve: the printed accumulators differ)
+    if name != "r1cs_nark":  # (it really ran the other curve: the printed points have 2 x 6 words)
+        assert any(len(ln.split()) == 14 for ln in bls.splitlines()), bls[-1500:]
 
 
 @pytest.mark.gpu

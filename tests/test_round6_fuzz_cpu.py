@@ -10,6 +10,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_round6_fuzz_short_on_the_host_backend(built_lib):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_round6.py"), "12", "7", "--host"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_round6.py"), "8", "7", "--host"], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "fuzz_round6 ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

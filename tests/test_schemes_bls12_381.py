@@ -25,4 +25,4 @@ def test_layers_over_bls12_381_on_the_gpu(built_lib):
 
 
 def test_layers_over_bls12_381_on_the_host_backend(built_lib):
-    _run(15, 32, "--host")
+    _run(8, 32, "--host")
