@@ -95,7 +95,7 @@ def test_keys_that_do_not_qualify_are_refused_not_miscomputed():
             assert np.array_equal(xy, kxy) and np.array_equal(inf, kinf)
         from accumulation_amd.engine import _ptr
         assert ctx._lib.amsm_ipa_jump_fold(ctx._h, pre._h, 8, _ptr(fr.to_limbs_many([3] * 9)), 9, _ptr(xy), _ptr(inf)) == ffi.AMSM_E_INVALID_ARG
-        assert _jump(ctx, pre, 9, [3], fr)[0] in (ffi.AMSM_E_INVALID_ARG, ffi.AMSM_E_UNSUPPORTED)  # log_key beyond the key: refused
+        assert _jump(ctx, pre, 9, [3], fr)[0] == ffi.AMSM_E_INVALID_ARG  # log_key beyond the key
         plain.free()
         pre.free()
     finally:
