@@ -119,11 +119,13 @@ def test_ser_mirror_against_the_big_int_wire_format_oracle(built_lib):
 
 
 @pytest.mark.gpu
-def test_cpp_driver_bytes_equal_the_mirror_over_bls12_381_on_the_gpu(built_lib, tmp_path):
-    """ipa_pc_as at d + 1 = 2^16 over BLS12-381 with the reference's sponge over ITS base field (BASELINE config 3's curve; the 2^20
-    opening itself is oracle-checked through the mirror in tests/test_ipa_open_vs_oracle_gpu.py)"""
+@pytest.mark.parametrize("scheme,lg", [("ipa_pc_as", 16), ("r1cs_nark_as", 12), ("hp_as", 14), ("trivial_pc_as", 10)])
+def test_cpp_driver_bytes_equal_the_mirror_over_bls12_381_on_the_gpu(built_lib, tmp_path, scheme, lg):
+    """over BLS12-381 with the reference's sponge over ITS base field (BASELINE config 3's curve; ipa_pc_as at d + 1 = 2^16 -- the
+    2^20 opening itself is oracle-checked through the mirror in tests/test_ipa_open_vs_oracle_gpu.py -- and the other three drivers
+    at sizes that reach the device kernels of the 384-bit field)"""
     from accumulation_amd import ffi
-    compare(tmp_path, "ipa_pc_as", 16, "harness", "poseidon", 0, curve=ffi.AMSM_BLS12_381_G1)
+    compare(tmp_path, scheme, lg, "harness", "poseidon", 0, curve=ffi.AMSM_BLS12_381_G1)
 
 
 # ---- GPU: the sizes of BASELINE.json's configs, the reference's sponge -------------------------------------------------------------
