@@ -159,6 +159,16 @@ def test_cpp_driver_over_sharded_keys_same_bytes(built_lib, tmp_path, devices):
         assert one == many, (scheme, devices)
 
 
+@pytest.mark.gpu
+def test_cpp_driver_over_sharded_keys_same_bytes_over_bls12_381(built_lib, tmp_path):
+    """the same over BLS12-381 (192-byte partial records between the shards), three shards, all four schemes at small sizes"""
+    bls = ("--curve", "1")
+    for scheme, lg in (("hp_as", 14), ("r1cs_nark_as", 12), ("ipa_pc_as", 11), ("trivial_pc_as", 10)):
+        one, _ = cpp_dump(tmp_path, scheme, lg, "harness", "poseidon", 0, extra=bls)
+        many, _ = cpp_dump(tmp_path, scheme, lg, "harness", "poseidon", 0, extra=bls + ("--devices", "0,0,0"))
+        assert one == many, scheme
+
+
 # ---- the uniform-witness circuit of `profile_as --uniform` (rows w_i * w_i = v_i: what bench.py reports beside the harness's two-valued lines)
 @pytest.mark.parametrize("shape", ["n2", "harness"])
 def test_uniform_witness_circuit_on_the_host_backend(built_lib, tmp_path, shape):
