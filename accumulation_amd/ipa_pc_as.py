@@ -138,7 +138,9 @@ class AtomicASForInnerProductArgPC:
             sp.absorb_bytes(b"\x00")
         else:
             co = list(lin) + [0, 0]
-            sp.absorb_bytes(b"\x01" + (co[0] % fr.r).to_bytes(32, "little") + (co[1] % fr.r).to_bytes(32, "little"))
+            # `Option<Vec<u8>>`: the tag is an item of its own (one sponge element), then the byte string (packed by itself)
+            sp.absorb_bytes(b"\x01")
+            sp.absorb_bytes((co[0] % fr.r).to_bytes(32, "little") + (co[1] % fr.r).to_bytes(32, "little"))
         for a, cp in addends:
             sp.absorb_bytes(int(a).to_bytes((LINEAR_COMBINATION_CHALLENGE_SIZE + 7) // 8, "little"))
             sp.absorb_bytes(cp.to_bytes(fr))

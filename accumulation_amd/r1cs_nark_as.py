@@ -188,7 +188,9 @@ class ASForR1CSNark:
         if proof_randomness is None:
             s.absorb_bytes(b"\x00")
         else:
-            s.absorb_bytes(b"\x01" + b"".join((x % fr.r).to_bytes(32, "little") for x in proof_randomness.r1cs_r_input))
+            # `Option<ProofRandomness>`: the tag is an item of its own (one sponge element), then `to_bytes!(r1cs_r_input)` packed by itself
+            s.absorb_bytes(b"\x01")
+            s.absorb_bytes(b"".join((x % fr.r).to_bytes(32, "little") for x in proof_randomness.r1cs_r_input))
             for p in (proof_randomness.comm_r_a, proof_randomness.comm_r_b, proof_randomness.comm_r_c):
                 s.absorb_point(p)
         return [1] + s.squeeze_field_elements(num - 1, CHALLENGE_SIZE)

@@ -788,7 +788,8 @@ class AtomicASForInnerProductArgPC {
     } else {
       std::vector<Fr> co = *lin;
       co.resize(2, fr.zero());
-      std::vector<uint8_t> b{1};
+      sp.absorb_bytes({1});  // `Option<Vec<u8>>`: the tag is an item of its own (one sponge element), then the byte string by itself
+      std::vector<uint8_t> b;
       for (int i = 0; i < 2; i++) {
         auto x = le_bytes(fr.canon(co[i]));
         b.insert(b.end(), x.begin(), x.end());

@@ -365,10 +365,8 @@ class ASForR1CSNark {
     if (!pr) {
       s.absorb_bytes({0});
     } else {
-      std::vector<uint8_t> b{1};
-      auto rb = canonical_bytes(pr->r1cs_r_input);
-      b.insert(b.end(), rb.begin(), rb.end());
-      s.absorb_bytes(b);
+      s.absorb_bytes({1});  // `Option<ProofRandomness>`: the tag is an item of its own (one sponge element) ...
+      s.absorb_bytes(canonical_bytes(pr->r1cs_r_input));  // ... then `to_bytes!(r1cs_r_input)` packed by itself (data_structures.rs:342-348)
       s.absorb_point(pr->comm_r_a);
       s.absorb_point(pr->comm_r_b);
       s.absorb_point(pr->comm_r_c);
