@@ -92,7 +92,8 @@ def matrix_vec_mul(matrix: Matrix, input: FrVector, witness: FrVector) -> FrVect
 
 
 def hash_matrices(domain_separator: bytes, a: Matrix, b: Matrix, c: Matrix) -> bytes:
-    """:422-440 (Blake2b-256 over a canonical serialisation; not byte-compatible with ark-serialize)."""
+    """:422-440: Blake2b-256 over the domain separator and the three matrices in ark-serialize 0.2's layout of `Vec<Vec<(F, usize)>>`
+    (Matrix.serialize: u64 little-endian lengths, 32-byte canonical little-endian coefficients, column indices as u64)."""
     h = hashlib.blake2b(digest_size=32)
     h.update(domain_separator)
     for m in (a, b, c):
