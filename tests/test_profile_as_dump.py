@@ -84,7 +84,8 @@ def test_cpp_driver_bytes_equal_the_mirror_over_bls12_381(built_lib, tmp_path, s
     compare(tmp_path, scheme, lg, shape, "poseidon", -1, seed=4, curve=ffi.AMSM_BLS12_381_G1)
 
 
-def test_ser_mirror_against_the_big_int_wire_format_oracle(built_lib):
+@pytest.mark.parametrize("curve", ["pallas", "bls12_381_g1"])
+def test_ser_mirror_against_the_big_int_wire_format_oracle(built_lib, curve):
     """tests/ser_mirror.py itself (it leans on the library's primitives for points and device vectors): one hp_as accumulator
     and proof re-encoded with oracle/pyref_ser.py's big-int restatement of ark-serialize"""
     from accumulation_amd import Context, PedersenCommitment, ffi
@@ -94,8 +95,8 @@ def test_ser_mirror_against_the_big_int_wire_format_oracle(built_lib):
     from tests import helpers as h
     from tests.ser_mirror import Ser
     from tests.test_hp_as_scheme_gpu import SchemeRng, generate_inputs
-    c = o.PALLAS
-    ctx = Context(ffi.AMSM_PALLAS, device=ffi.AMSM_DEVICE_HOST)
+    c = o.CURVES[curve]
+    ctx = Context(c.curve_id, device=ffi.AMSM_DEVICE_HOST)
     ck = PedersenCommitment.setup(ctx, 11, seed=4242)
     pk, _, _ = AS.index(ck)
     inputs = generate_inputs(ctx, ck, 2, True)
