@@ -78,6 +78,22 @@ def nark_gamma(c, nark_sponge: PoseidonSponge, matrices_hash: bytes, r1cs_input:
     return sp.squeeze_nonnative(CHALLENGE_SIZE, 1)[0]
 
 
+def hash_matrices(c, domain_separator: bytes, a, b, cc) -> bytes:
+    """r1cs_nark/mod.rs:422-440: Blake2b-256 over the domain separator and `a.serialize() || b.serialize() || c.serialize()`, a matrix
+    being `Vec<Vec<(F, usize)>>` (ark-serialize 0.2: u64 little-endian lengths, 32-byte canonical elements, usize as u64).
+    Matrices: rows of (coefficient, column) pairs."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=32)
+    h.update(domain_separator)
+    for m in (a, b, cc):
+        h.update(len(m).to_bytes(8, "little"))
+        for row in m:
+            h.update(len(row).to_bytes(8, "little"))
+            for cf, col in row:
+                h.update((int(cf) % c.r).to_bytes(32, "little") + int(col).to_bytes(8, "little"))
+    return h.digest()
+
+
 def nark_as_sponges(c, sponge: PoseidonSponge):
     """src/r1cs_nark_as/mod.rs:112-125: (nark, as, hp) forks of the base sponge"""
     return sponge.fork(b"R1CS-NARK-2020"), sponge.fork(b"AS-FOR-R1CS-NARK-2020"), sponge.fork(b"AS-FOR-HP-2020")

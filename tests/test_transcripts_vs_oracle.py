@@ -137,10 +137,13 @@ def test_r1cs_nark_as_transcript(env, n_in, n_acc, make_zk):
     assert AS.verify(ctx, vk, [x.instance for x in ins], [x.instance for x in olds], acc.instance, proof, PoseidonSponge(ctx.curve))
     # ---- the oracle's derivation from the public data ----
     o_nark, o_as, o_hp = ot.nark_as_sponges(c, ot.base_sponge(c))
+    nark_hash = ot.hash_matrices(c, b"R1CS-NARK-2020", A, B, C_)        # (r1cs_nark/mod.rs:104)
+    as_hash = ot.hash_matrices(c, b"AS-FOR-R1CS-NARK-2020", A, B, C_)   # (src/r1cs_nark_as/mod.rs:694)
+    assert nark_hash == bytes(ipk.index_info.matrices_hash) and as_hash == bytes(pk.as_matrices_hash)
     in_inst = [([v % c.r for v in x.instance.r1cs_input], _first_msg(c, x.instance.first_round_message)) for x in ins]
     if not ins and not olds:  # the default input (:761-768): zero r1cs input, identity commitments, no randomness
         in_inst = [([0] * (n_inp + 1), (None, None, None, None))]
-    gammas = [None if m[3] is None else ot.nark_gamma(c, o_nark.clone(), ipk.index_info.matrices_hash, r, m) for r, m in in_inst]
+    gammas = [None if m[3] is None else ot.nark_gamma(c, o_nark.clone(), nark_hash, r, m) for r, m in in_inst]
     got_g = [int(v[0]) for p, v in sp.log if p[:1] == (NARK_PROTOCOL_NAME,)]
     assert got_g == [g for g in gammas if g is not None]
     hp_of = lambda a: (P(c, a.comm_1), P(c, a.comm_2), P(c, a.comm_3))  # noqa: E731
@@ -149,7 +152,7 @@ def test_r1cs_nark_as_transcript(env, n_in, n_acc, make_zk):
     pr = proof.randomness
     o_pr = None if pr is None else ([v % c.r for v in pr.r1cs_r_input], P(c, pr.comm_r_a), P(c, pr.comm_r_b), P(c, pr.comm_r_c))
     num_addends = len(in_inst) + len(acc_inst) + (1 if make_zk else 0)
-    beta = ot.nark_as_beta(c, o_as, pk.as_matrices_hash, acc_inst, in_inst, o_pr, num_addends)
+    beta = ot.nark_as_beta(c, o_as, as_hash, acc_inst, in_inst, o_pr, num_addends)
     got_beta = sp.squeezed(PROTOCOL_NAME)
     assert ([int(v) for v in got_beta[0]] if got_beta else []) == beta
     # the nested hp_as: its input instances are the blinded commitments (:220-286) comm_a + g comm_r_a, comm_b + g comm_r_b,
