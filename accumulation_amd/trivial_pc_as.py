@@ -6,8 +6,9 @@ SURVEY.md section 8(a) row a10 (BASELINE config 1): every commitment the scheme 
 2^10 pairs through the same ABI as the large ones (`amsm_pedersen_commit_device`); the O(d) polynomial work per
 claim -- the quotient (p(X) - v) / (X - z), evaluations at the challenge point, the linear combination of the
 witness polynomials -- is small sequential host arithmetic in the reference too and stays on the host here
-(Python integers).  The sponge is pluggable like in the other mirrors (SHA-256 stand-in; the reference's Poseidon
-parameters live in ark-sponge, which is absent), so transcripts are self-consistent, not cross-checked.
+(Python integers).  The sponge is pluggable like in the other mirrors (the SHA-256 stand-in, or sponge.PoseidonSponge: the reference's
+sponge with ark-sponge's parameters restated as recalled); what is absorbed and squeezed, and in which order, follows the reference's
+`absorb!` lists and is compared with their restatement outside the product in tests/test_transcripts_vs_oracle.py.
 """
 from __future__ import annotations
 
