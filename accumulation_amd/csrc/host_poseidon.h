@@ -16,7 +16,7 @@
 //     (canonical, little-endian), bits little-endian within a byte.  `squeeze_nonnative_field_elements_with_sizes(
 //     [Truncated(b); k])`: ONE squeeze_bits(k * b), consecutive b-bit windows, each read little-endian (src/hp_as/mod.rs:233-275).
 //   * Absorbable encodings (`to_sponge_field_elements`): native element -> itself; usize -> one element; bool / Option tag ->
-//     0 / 1; affine point -> x, y, infinity (ark-ec `ToConstraintField for GroupAffine`); byte string -> floor(CAPACITY / 8)-byte
+//     0 / 1; affine point -> x, y, infinity (ark-ec `ToConstraintField for GroupAffine`; the identity: 0, 1, 1); byte string -> floor(CAPACITY / 8)-byte
 //     little-endian chunks, one element each; a Vec -> its items in order, no length; `fork(domain)` = clone + absorb the bytes
 //     (domain.len() as u64 little-endian || domain).
 #pragma once
@@ -209,14 +209,17 @@ struct PoseidonSponge {
     c = h_to_mont<Fq>(c);
     absorb(&c, 1);
   }
-  // x, y, infinity per point (ark-ec: ToConstraintField for GroupAffine); the identity is (0, 0, 1)
+  // x, y, infinity per point (ark-ec: ToConstraintField for GroupAffine reads the three fields as they are).  The identity is
+  // (0, 1, 1): ark-ec ^0.2.0's short-Weierstrass `GroupAffine::zero()` is `new(zero, ONE, true)` -- every identity the schemes absorb
+  // comes from it (`into_affine()` of a zero sum, `InputInstance::zero()`, a deserialised flag); ark-ec 0.4 moved to (0, 0).  As
+  // recalled, like the rest of this header; rounds 4-5 absorbed (0, 0, 1).
   void absorb_points(const u64* xy, const uint8_t* inf, size_t n) {
     constexpr int N = HFe<Fq>::N;
     std::vector<HFe<Fq>> el(3 * n);
     for (size_t i = 0; i < n; i++) {
       if (inf && inf[i]) {
         el[3 * i] = h_zero<Fq>();
-        el[3 * i + 1] = h_zero<Fq>();
+        el[3 * i + 1] = h_one<Fq>();
         el[3 * i + 2] = h_one<Fq>();
       } else {
         memcpy(el[3 * i].v, xy + i * 2 * N, 8 * N);

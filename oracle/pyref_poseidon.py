@@ -161,7 +161,8 @@ class PoseidonSponge:
         self.absorb([int.from_bytes(b[i:i + ub], "little") for i in range(0, len(b), ub)])
 
     def absorb_point(self, P):
-        self.absorb([0, 0, 1] if P is None else [P[0], P[1], 0])
+        # (the identity: ark-ec ^0.2.0's `GroupAffine::zero()` = new(zero, ONE, true), fields absorbed as they are)
+        self.absorb([0, 1, 1] if P is None else [P[0], P[1], 0])
 
     def fork(self, domain: bytes) -> "PoseidonSponge":
         c = self.clone()
