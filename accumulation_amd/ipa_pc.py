@@ -158,7 +158,7 @@ class InnerProductArgPC:
     # ---- challenges ---------------------------------------------------------------------------------
     @classmethod
     def _challenge(cls, fr: Fr, parts) -> int:
-        sp = cls.sponge_cls().fork(b"IPA-PC")
+        sp = cls.sponge_cls().fork(b"IPA-PC-2020")  # `IpaPCDomain::domain()`, src/ipa_pc_as/data_structures.rs:88-94
         for p in parts:
             if isinstance(p, tuple):
                 sp.absorb_point(p)

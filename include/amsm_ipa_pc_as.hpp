@@ -119,11 +119,13 @@ struct SuccinctCheckPolynomial {
 
 template <class Sponge = Sha256Sponge>
 struct InnerProductArgPC {
-  // builder of one Fiat-Shamir challenge: fork("IPA-PC"), absorb the parts, squeeze 128 bits
+  // builder of one Fiat-Shamir challenge: the sponge of domain `IpaPCDomain` = "IPA-PC-2020" (src/ipa_pc_as/data_structures.rs:88-94;
+  // the reference's IpaPC is `InnerProductArgPC<.., DomainSeparatedSponge<CF, S, IpaPCDomain>>`, src/ipa_pc_as/mod.rs:33-39), absorb
+  // the parts, squeeze 128 bits
   struct Challenge {
     const FrX& fr;
     Sponge sp;
-    explicit Challenge(const FrX& f) : fr(f), sp(hp_as::fresh_sponge<Sponge>(f.curve).fork("IPA-PC")) {}
+    explicit Challenge(const FrX& f) : fr(f), sp(hp_as::fresh_sponge<Sponge>(f.curve).fork("IPA-PC-2020")) {}
     Challenge& point(const Affine& p) {
       sp.absorb_point(p);
       return *this;
