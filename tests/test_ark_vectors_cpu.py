@@ -81,6 +81,12 @@ def _replay(sponge_new, steps, c):
             s.absorb([int(val)])
         elif op == "absorb_point":
             s.absorb_point(av.pt(val))
+        elif op == "absorb_option_bytes":  # Option<Vec<u8>>: the tag as one element, then the byte string by itself
+            s.absorb([0 if val is None else 1])
+            if val is not None:
+                s.absorb_bytes(bytes.fromhex(val))
+        elif op == "fork":
+            s = s.fork(bytes.fromhex(val))
         elif op == "squeeze_fq":
             assert s.squeeze(len(val)) == av.ints(val), op
         elif op == "squeeze_bits":

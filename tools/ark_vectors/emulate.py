@@ -79,6 +79,24 @@ def poseidon_cases():
              {"squeeze_nonnative_truncated_128": [hex(x) for x in s.squeeze_nonnative(128, 3)]},
              {"squeeze_nonnative_truncated_128": [hex(x) for x in s.squeeze_nonnative(128, 1)]}]
     out.append({"name": "encodings", "steps": steps})
+    # one encoding per case (main.rs block 3)
+    sq = lambda s: {"squeeze_fq": [hex(x) for x in s.squeeze(2)]}  # noqa: E731
+    b = bytes(range(33))
+    s = pp.PoseidonSponge(c.p)
+    s.absorb_bytes(b)
+    out.append({"name": "bytes_only", "steps": [{"absorb_bytes": b.hex()}, sq(s)]})
+    s = pp.PoseidonSponge(c.p)
+    s.absorb_point(None)
+    out.append({"name": "identity_point", "steps": [{"absorb_point": hp(None)}, sq(s)]})
+    s = pp.PoseidonSponge(c.p)
+    s.absorb([1])
+    s.absorb_bytes(b)
+    out.append({"name": "option_some_bytes", "steps": [{"absorb_option_bytes": b.hex()}, sq(s)]})
+    s = pp.PoseidonSponge(c.p)
+    s.absorb([0])
+    out.append({"name": "option_none", "steps": [{"absorb_option_bytes": None}, sq(s)]})
+    s = pp.PoseidonSponge(c.p).fork(b"AS-FOR-HP-2020")
+    out.append({"name": "fork", "steps": [{"fork": b"AS-FOR-HP-2020".hex()}, sq(s)]})
     return out
 
 

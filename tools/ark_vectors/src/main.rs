@@ -263,6 +263,33 @@ fn poseidon_transcripts() -> String {
         steps.push(format!("{{\"squeeze_nonnative_full\": [\"{}\"]}}", hex_field(&full[0])));
         out.push(format!("{{\"name\": \"encodings\", \"steps\": [{}]}}", steps.join(", ")));
     }
+    // 3. ONE encoding per case, two native squeezes behind it: a mismatch then names the rule (DESIGN.md section 7 lists what the pin
+    //    has to settle: byte strings bare or behind a length, the identity's coordinates, the Option tag, fork)
+    {
+        let sq = |s: &mut PoseidonSponge<Fq>| -> String {
+            let v = s.squeeze_field_elements(2);
+            format!("{{\"squeeze_fq\": [{}]}}", v.iter().map(fq).collect::<Vec<_>>().join(", "))
+        };
+        let bytes: Vec<u8> = (0u8..33).collect();
+        let mut s = PoseidonSponge::<Fq>::new();
+        s.absorb(&bytes);
+        out.push(format!("{{\"name\": \"bytes_only\", \"steps\": [{{\"absorb_bytes\": \"{}\"}}, {}]}}", hex_bytes(&bytes), sq(&mut s)));
+        let mut s = PoseidonSponge::<Fq>::new();
+        let id = G::zero();
+        s.absorb(&id);
+        out.push(format!("{{\"name\": \"identity_point\", \"steps\": [{{\"absorb_point\": {}}}, {}]}}", json_point(&id, pallas::xy), sq(&mut s)));
+        let mut s = PoseidonSponge::<Fq>::new();
+        let some: Option<Vec<u8>> = Some(bytes.clone());
+        s.absorb(&some);
+        out.push(format!("{{\"name\": \"option_some_bytes\", \"steps\": [{{\"absorb_option_bytes\": \"{}\"}}, {}]}}", hex_bytes(&bytes), sq(&mut s)));
+        let mut s = PoseidonSponge::<Fq>::new();
+        let none: Option<Vec<u8>> = None;
+        s.absorb(&none);
+        out.push(format!("{{\"name\": \"option_none\", \"steps\": [{{\"absorb_option_bytes\": null}}, {}]}}", sq(&mut s)));
+        let s = PoseidonSponge::<Fq>::new();
+        let mut f = s.fork(b"AS-FOR-HP-2020");
+        out.push(format!("{{\"name\": \"fork\", \"steps\": [{{\"fork\": \"{}\"}}, {}]}}", hex_bytes(b"AS-FOR-HP-2020"), sq(&mut f)));
+    }
     let _ = G::prime_subgroup_generator();
     format!("[\n  {}\n]", out.join(",\n  "))
 }
