@@ -443,7 +443,8 @@ void amsm_poseidon_free(amsm_sponge* s);
 /* `fork(domain)`: a clone that absorbed (domain.len() as u64 LE || domain) as a byte string. */
 int amsm_poseidon_fork(const amsm_sponge* s, const uint8_t* domain, size_t n, amsm_sponge** out);
 /* absorb: native elements (base field, Montgomery); one usize / bool / Option tag; a byte string (31-byte LE chunks for
- * Pallas, 47 for BLS12-381, one element each); affine points (x, y, infinity each). */
+ * Pallas, 47 for BLS12-381, one element each); affine points (x, y, infinity each; a flagged identity absorbs as 0, 1, 1 whatever
+ * xy_mont holds: ark-ec ^0.2.0's `GroupAffine::zero()`). */
 int amsm_poseidon_absorb_native(amsm_sponge* s, const uint64_t* fq_mont, size_t n);
 int amsm_poseidon_absorb_u64(amsm_sponge* s, uint64_t v);
 int amsm_poseidon_absorb_bytes(amsm_sponge* s, const uint8_t* bytes, size_t n);
